@@ -1,0 +1,237 @@
+/*
+ * selfocc_hip.h — C ABI of the MI355X-native SelfOcc hot path (libselfocc_hip.so).
+ *
+ * Every entry point is the drop-in replacement of one native/third-party op the
+ * reference (huang-yh/SelfOcc @ 2024-10-08) calls on its hot path.  Citations are
+ * relative to the reference tree.  Conventions shared by all entry points:
+ *
+ *   - plain pointers + sizes only; all data pointers are DEVICE pointers (HBM);
+ *     the *_args structs themselves live in HOST memory and are read during the call;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); every call
+ *     is stream-ordered, does not synchronise, does not allocate, keeps no state;
+ *   - the caller allocates all outputs; output pointers that are NULL are skipped;
+ *   - return value: 0 = launched, <0 = argument error (see selfocc_last_error()),
+ *     >0 = the hipError_t of a failed launch;
+ *   - thread-safe / re-entrant (the last-error string is thread-local).
+ */
+#ifndef SELFOCC_HIP_H
+#define SELFOCC_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SELFOCC_ABI_VERSION 3
+
+int selfocc_abi_version(void);
+const char *selfocc_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * Grid <-> metre mapping.  Replaces GridMeterMapping / LinearMapping.meter2grid
+ * (model/encoder/bevformer/mappings.py:97-150).  One piece-wise linear axis:
+ *     c = m - start;  a = |c|;
+ *     g_abs = size1 == 0 ? a / range0 * size0
+ *           : a > range0 ? size0 + (a - range0) / range1 * size1 : a / range0 * size0;
+ *     g = (sign(c) * g_abs + off0) + off1          (off0/off1 = size0/size1 unless *_half)
+ * Axis order everywhere: h <-> metre y, w <-> metre x, d <-> metre z.
+ * ---------------------------------------------------------------------------------- */
+typedef struct so_axis {
+    float size0, size1;   /* cells in the inner / outer segment                        */
+    float range0, range1; /* metres covered by the inner / outer segment               */
+    float off0, off1;     /* grid offset of the axis centre (0,0 for *_half and for d) */
+    float start;          /* metre coordinate of grid 0 on the d axis, 0 for h / w     */
+    int32_t tot_len;      /* number of grid points along the axis                      */
+} so_axis;
+
+typedef struct so_mapping {
+    so_axis h, w, d;
+} so_mapping;
+
+/* ------------------------------------------------------------------------------------
+ * SDF volume rendering.  Replaces the sdfstudio-fork NeuSCustomModel.__call__ that
+ * NeuSHead drives (model/head/neus_head/neus_head.py:353,394,531) together with the
+ * head's own post-math (:366-374, 430-438, 571-587) and, in pixel-grid mode, RaySampler
+ * 'fixed'/'cellular' + Img2LiDAR (model/head/nerfacc_head/ray_sampler.py:23-68,
+ * img2lidar.py:58-69).
+ *
+ * Volume layout in HBM (ours; the reference materialises (1, C, H, W, D)):
+ *     sdf_vol  [H][W][D]               float32
+ *     feat_vol [H][W][D][feat_stride]  float32 or bf16 (raw colour coefficients then
+ *                                      semantic logits), feat_stride >= n_rgb + n_sem
+ * ---------------------------------------------------------------------------------- */
+enum {
+    SO_RAYS_EXPLICIT = 0, /* origins / dirs / dir_norm arrays, one entry per ray       */
+    SO_RAYS_PIXEL_GRID = 1 /* rays generated in-kernel from img2lidar + a pixel lattice */
+};
+enum { SO_SAMPLE_AT_START = 0, SO_SAMPLE_AT_MID = 1 };
+enum { SO_BKGD_NONE = 0, SO_BKGD_CONST = 1, SO_BKGD_PER_RAY = 2 };
+enum { SO_JITTER_NONE = 0, SO_JITTER_SINGLE = 1, SO_JITTER_PER_BIN = 2 };
+enum {
+    SO_FLAG_DEPTH_DIV_NORM = 1, /* depth /= ||K^-1 (u,v,1)|| (z-depth, as the fork does) */
+    SO_FLAG_CLAMP_RGB = 2       /* eval: clamp rgb to [0,1]                              */
+};
+enum { SO_DTYPE_F32 = 0, SO_DTYPE_BF16 = 1 };
+
+typedef struct so_render_args {
+    /* --- field ------------------------------------------------------------------- */
+    so_mapping map;
+    const float *sdf_vol;
+    const void *feat_vol; /* NULL when n_rgb + n_sem == 0 */
+    int32_t feat_dtype;   /* SO_DTYPE_* */
+    int32_t feat_stride;
+    int32_t n_rgb;        /* 0 or 3 (SH degree 0: rgb = relu(C0 * raw + 0.5))          */
+    int32_t n_sem;        /* semantic classes; per-sample softmax, weight-composited    */
+    /* --- rays -------------------------------------------------------------------- */
+    int32_t ray_mode;     /* SO_RAYS_* */
+    int32_t n_rays;       /* explicit: number of rays; pixel grid: n_cams * ny * nx     */
+    const float *origins;   /* (n_rays, 3)                                              */
+    const float *dirs;      /* (n_rays, 3) unit length                                  */
+    const float *dir_norm;  /* (n_rays)  norm of the un-normalised direction            */
+    const float *img2lidar; /* (n_cams, 4, 4) row-major pixel*depth -> world            */
+    int32_t n_cams, nx, ny;
+    float sx, sy, ox, oy;   /* pixel (u, v) = (ix * sx + ox, iy * sy + oy)              */
+    /* --- sampling ---------------------------------------------------------------- */
+    float aabb[6];          /* xmin ymin zmin xmax ymax zmax (box collider)             */
+    float near_plane;
+    int32_t n_samples;
+    int32_t sample_pos;     /* SO_SAMPLE_AT_* : where the field is evaluated            */
+    int32_t jitter_mode;    /* SO_JITTER_*                                              */
+    const float *t_rand;    /* (n_rays) or (n_rays, n_samples + 1) uniform [0,1)        */
+    /* --- NeuS -------------------------------------------------------------------- */
+    float inv_s;
+    /* --- compositing ------------------------------------------------------------- */
+    int32_t bkgd_mode;
+    float bkgd[3];
+    const float *bkgd_rays; /* (n_rays, 3) */
+    int32_t flags;
+    /* --- per-ray outputs --------------------------------------------------------- */
+    float *depth;     /* (n_rays)                                                      */
+    float *acc;       /* (n_rays)                                                      */
+    float *rgb;       /* (n_rays, 3)                                                   */
+    float *sem;       /* (n_rays, n_sem)                                               */
+    float *max_depth; /* (n_rays)  ts[argmax_s w / delta]   (neus_head.py:430-438)     */
+    float *nears;     /* (n_rays)                                                      */
+    float *fars;      /* (n_rays)                                                      */
+    /* --- per-sample outputs (training API, neus_head.py:567-577, 640) ------------- */
+    float *weights;   /* (n_rays, n_samples)                                           */
+    float *ts;        /* (n_rays, n_samples)  mid-point / dir_norm                     */
+    float *deltas;    /* (n_rays, n_samples)  (end - start) / dir_norm                 */
+    float *sdf;       /* (n_rays, n_samples)                                           */
+    float *grad;      /* (n_rays, n_samples, 3)  d sdf / d (x, y, z) in metres         */
+} so_render_args;
+
+int selfocc_render_fwd(const so_render_args *args, void *stream);
+
+/* Backward of selfocc_render_fwd with respect to the volume(s) and inv_s.  Ray
+ * geometry carries no gradient (the reference's rays come from constant matrices).
+ * Upstream gradients that are NULL count as zero.  g_sdf_vol / g_feat_vol must be
+ * zero-initialised by the caller (atomically accumulated). */
+typedef struct so_render_bwd_args {
+    so_render_args fwd;       /* same inputs as the forward call (outputs ignored)     */
+    const float *g_depth;     /* (n_rays)                                              */
+    const float *g_acc;       /* (n_rays)                                              */
+    const float *g_rgb;       /* (n_rays, 3)                                           */
+    const float *g_sem;       /* (n_rays, n_sem)                                       */
+    const float *g_weights;   /* (n_rays, n_samples)                                   */
+    const float *g_sdf;       /* (n_rays, n_samples)                                   */
+    const float *g_grad;      /* (n_rays, n_samples, 3)                                */
+    float *g_sdf_vol;         /* [H][W][D]                                             */
+    float *g_feat_vol;        /* [H][W][D][feat_stride] float32                        */
+    float *g_inv_s;           /* (1)                                                   */
+} so_render_bwd_args;
+
+int selfocc_render_bwd(const so_render_bwd_args *args, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Multi-scale deformable attention.  Replaces mmcv==2.0.1
+ * MultiScaleDeformableAttnFunction.apply(value, spatial_shapes, level_start_index,
+ * sampling_locations, attention_weights, im2col_step) at the reference call sites
+ * model/encoder/bevformer/attention/image_cross_attention.py:340-342 and
+ * model/encoder/tpvformer/attention/cross_view_hybrid_attention.py:111-113.
+ *
+ *   value   (bs, nv, heads, d)            float32
+ *   shapes  (L, 2) int32 [H_l, W_l]       starts (L) int32
+ *   loc     (bs, nq, heads, L, P, 2)      (x, y) in [0,1]
+ *   attw    (bs, nq, heads, L, P)
+ *   out     (bs, nq, heads * d)
+ * ---------------------------------------------------------------------------------- */
+int selfocc_msda_fwd(const float *value, const int32_t *shapes, const int32_t *starts,
+                     const float *loc, const float *attw, float *out,
+                     int32_t bs, int32_t nv, int32_t nq, int32_t heads, int32_t d,
+                     int32_t L, int32_t P, void *stream);
+
+/* g_value must be zero-initialised by the caller (atomically accumulated). */
+int selfocc_msda_bwd(const float *value, const int32_t *shapes, const int32_t *starts,
+                     const float *loc, const float *attw, const float *g_out,
+                     float *g_value, float *g_loc, float *g_attw,
+                     int32_t bs, int32_t nv, int32_t nq, int32_t heads, int32_t d,
+                     int32_t L, int32_t P, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Dense SDF / semantic query on a regular metre lattice + Occ3D occupancy tail.
+ * Replaces NeuSHead.get_uniform_sdf -> field.forward_geonetwork / forward_sdfnetwork
+ * (model/head/neus_head/neus_head.py:265-293) and the resample / threshold / argmax /
+ * LUT of eval_iou.py:211-250.
+ * ---------------------------------------------------------------------------------- */
+typedef struct so_query_args {
+    so_mapping map;
+    const float *sdf_vol;
+    const void *feat_vol;
+    int32_t feat_dtype, feat_stride, n_rgb, n_sem;
+    const float *xyz;     /* (n, 3) metre positions                                    */
+    int32_t n;
+    float *sdf;           /* (n)                                                       */
+    float *sem_logits;    /* (n, n_sem) raw logits (forward_geonetwork h[..., 4:])     */
+    int32_t *sem_argmax;  /* (n)                                                       */
+} so_query_args;
+
+int selfocc_field_query(const so_query_args *args, void *stream);
+
+/* Trilinear resample of a dense (H, W, D) scalar grid (+ optional (H, W, D, C) logits)
+ * at normalised coordinates, threshold, border crop, argmax + LUT: eval_iou.py:211-250.
+ *   coords (n, 3) in [0,1] along (H, W, D) of the source grid (align_corners=True)
+ *   occ    (n) int32 = (sdf <= thresh)            sem (n) int32 = occ * lut[argmax]   */
+int selfocc_occ_resample(const float *grid, const float *logits, int32_t H, int32_t W,
+                         int32_t D, int32_t C, const float *coords, int32_t n,
+                         float thresh, const int32_t *lut, float *sampled,
+                         int32_t *occ, int32_t *sem, void *stream);
+
+/* Integer confusion counts of MeanIoU._after_step (utils/metric_util.py:90-121):
+ * counts (3, n_cls + 1) int64 rows = seen / correct / positive; last column = the
+ * binary "non-empty" class.  mask may be NULL.  counts are accumulated (+=). */
+int selfocc_iou_counts(const int32_t *pred, const int32_t *target, const uint8_t *mask,
+                       int64_t n, const int32_t *class_indices, int32_t n_cls,
+                       int32_t empty_label, unsigned long long *counts, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Fused temporal reprojection photometric term.  Replaces the per-sample part of
+ * ReprojLossMonoMultiNewCombine.reproj_loss (loss/reproj_loss_mono_multi_new_combine.py
+ * :108-187 and the weighted colour composite :190-201) for one camera.
+ *   weights, ts (R, S); pix (R, 2) pixel (u, v); T_prev / T_next (4,4) row-major;
+ *   img_* (3, Hi, Wi) planar float32; curr_rgb (R, 3) = bilinear(curr image, pix)
+ * outputs per ray: l1 (R) = sum_s w' * diff, rgb_combine (R, 3), any_valid (R) in {0,1}
+ * (w' = masked, per-ray renormalised weights).
+ * ---------------------------------------------------------------------------------- */
+typedef struct so_reproj_args {
+    const float *weights, *ts, *deltas; /* deltas may be NULL (:111-116)               */
+    const float *pix, *curr_rgb;
+    const float *T_prev, *T_next;
+    const float *img_prev, *img_next;
+    int32_t R, S, Hi, Wi;
+    float img_h, img_w;                 /* self.img_size used for masks + normalisation */
+    float *l1, *rgb_combine, *any_valid;
+    float *wnorm;                       /* (R, S) renormalised weights, saved for bwd   */
+} so_reproj_args;
+
+int selfocc_reproj_fwd(const so_reproj_args *args, void *stream);
+
+/* d loss / d weights given d loss / d l1 and d loss / d rgb_combine. */
+int selfocc_reproj_bwd(const so_reproj_args *args, const float *g_l1,
+                       const float *g_rgb_combine, float *g_weights, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SELFOCC_HIP_H */

@@ -1,0 +1,92 @@
+"""CPU oracle of the SelfOcc hot path — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+package.  selfocc_amd/ never does (the product path has no CPU fallback).
+
+Two independent restatements live here:
+  * ``oracle_*.c``   — plain C, canonical float32 operation order (the checker);
+  * ``torch_port.py``— the same path written with the torch ops the reference itself
+    calls (F.grid_sample, softmax, cumprod ...), i.e. what the reference would run on
+    CPU; used to pin the C oracle and as bench.py's ``cpu_baseline`` (kind "port").
+PARITY STATUS: see the header of oracle_render.c ("parity unpinned" for the NeuS
+internals that live in the absent sdfstudio fork; lookups / mappings / MSDA / losses are
+pinned against torch ops and the imported reference modules in tests/golden).
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "_build", "liboracle.so")
+_lib = None
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, f) for f in os.listdir(_HERE) if f.startswith("oracle_") and f.endswith(".c")]
+    hdr = os.path.join(_HERE, "..", "include", "selfocc_hip.h")
+    stale = (not os.path.exists(_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs + [hdr])
+    if force or stale:
+        subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
+    return _LIB
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB)
+    return _lib
+
+
+def render_fwd(vol, rays, cfg, **kw):
+    """C oracle of selfocc_render_fwd on CPU tensors; same signature/outputs as
+    selfocc_amd.render.render_rays."""
+    from selfocc_amd import abi
+    from selfocc_amd.render import marshal_render_args
+    assert not vol.sdf.is_cuda
+    a, out, _keep = marshal_render_args(vol, rays, cfg, **kw)
+    fn = lib().oracle_render_fwd
+    fn.restype, fn.argtypes = C.c_int, [C.POINTER(abi.SoRenderArgs)]
+    rc = fn(a)
+    assert rc == 0, f"oracle_render_fwd rc={rc}"
+    return out
+
+
+def meter2grid(mapping, xyz, normalize=False):
+    import torch
+    from selfocc_amd import abi
+    m = mapping.to_abi()
+    xyz = xyz.contiguous().float()
+    out = torch.empty_like(xyz)
+    fn = lib().oracle_meter2grid
+    fn.restype = None
+    fn.argtypes = [C.POINTER(abi.SoMapping), C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    fn(m, xyz.data_ptr(), xyz.shape[0], int(normalize), out.data_ptr())
+    return out
+
+
+def field_sdf(mapping, sdf_vol, xyz, want_grad=True):
+    import torch
+    from selfocc_amd import abi
+    m = mapping.to_abi()
+    xyz = xyz.contiguous().float()
+    sdf = torch.empty(xyz.shape[0])
+    grad = torch.empty(xyz.shape[0], 3) if want_grad else None
+    fn = lib().oracle_field_sdf
+    fn.restype = None
+    fn.argtypes = [C.POINTER(abi.SoMapping), C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    fn(m, sdf_vol.contiguous().data_ptr(), xyz.data_ptr(), xyz.shape[0], sdf.data_ptr(),
+       None if grad is None else grad.data_ptr())
+    return sdf, grad
+
+
+def expf(x):
+    fn = lib().oracle_expf
+    fn.restype, fn.argtypes = C.c_float, [C.c_float]
+    return fn(x)
+
+
+def linspace01(j, n):
+    fn = lib().oracle_linspace01
+    fn.restype, fn.argtypes = C.c_float, [C.c_int, C.c_int]
+    return fn(j, n)

@@ -1,0 +1,133 @@
+"""The SelfOcc hot path written with the torch ops the reference itself calls —
+what the reference would execute on CPU.  TEST INFRASTRUCTURE ONLY (see __init__.py).
+
+Used (a) to pin the C oracle (oracle_*.c) against real ``F.grid_sample`` /
+``softmax`` / ``cumprod`` arithmetic and (b) as bench.py's ``cpu_baseline`` (kind
+"port").  Each function cites the reference lines it follows.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# ---------------------------------------------------------------------------------------
+# field lookup: model/head/nerfacc_head/bev_nerf.py:97-113 (query_density / forward) with the
+# (1, C, H, W, D) volume of pre_compute_density_color (:74-95)
+# ---------------------------------------------------------------------------------------
+def field_lookup(mapping, density_color, xyz):
+    grid = mapping.meter2grid(xyz, True)
+    grid = 2 * grid - 1
+    grid = grid.reshape(1, -1, 1, 1, 3)
+    out = F.grid_sample(density_color, grid[..., [2, 1, 0]], mode='bilinear', align_corners=True)
+    return out.permute(0, 2, 3, 4, 1).flatten(0, 3)  # n, C
+
+
+def sh0_color(raw):
+    """SHRender with deg=0, act='relu' (model/head/utils/sh_render.py:84-91)."""
+    C0 = 0.28209479177387814
+    return torch.relu(C0 * raw + 0.5)
+
+
+# ---------------------------------------------------------------------------------------
+# upstream sdfstudio pieces (absent fork; restated from the published algorithm)
+# ---------------------------------------------------------------------------------------
+def aabb_collider(origins, dirs, aabb, near_plane=0.0):
+    aabb = torch.as_tensor(aabb, dtype=origins.dtype).reshape(2, 3)
+    frac = 1.0 / (dirs + 1e-6)
+    t1 = (aabb[0, 0] - origins[:, 0:1]) * frac[:, 0:1]
+    t2 = (aabb[1, 0] - origins[:, 0:1]) * frac[:, 0:1]
+    t3 = (aabb[0, 1] - origins[:, 1:2]) * frac[:, 1:2]
+    t4 = (aabb[1, 1] - origins[:, 1:2]) * frac[:, 1:2]
+    t5 = (aabb[0, 2] - origins[:, 2:3]) * frac[:, 2:3]
+    t6 = (aabb[1, 2] - origins[:, 2:3]) * frac[:, 2:3]
+    nears = torch.max(torch.cat([torch.minimum(t1, t2), torch.minimum(t3, t4), torch.minimum(t5, t6)], 1), 1).values
+    fars = torch.min(torch.cat([torch.maximum(t1, t2), torch.maximum(t3, t4), torch.maximum(t5, t6)], 1), 1).values
+    nears = torch.clamp(nears, min=near_plane)
+    fars = torch.maximum(fars, nears + 1e-6)
+    return nears[:, None], fars[:, None]
+
+
+def uniform_bins(n_rays, n_samples, nears, fars, t_rand=None):
+    bins = torch.linspace(0.0, 1.0, n_samples + 1)[None, :]
+    if t_rand is not None:
+        if t_rand.dim() == 1:
+            t_rand = t_rand[:, None]
+        centers = (bins[..., 1:] + bins[..., :-1]) / 2.0
+        upper = torch.cat([centers, bins[..., -1:]], -1)
+        lower = torch.cat([bins[..., :1], centers], -1)
+        bins = lower + (upper - lower) * t_rand
+    return bins * fars + (1 - bins) * nears  # n_rays, S + 1
+
+
+def render_port(mapping, density_color, n_rgb, n_sem, origins, dirs, dir_norm, cfg,
+                t_rand=None, bkgd_rays=None, chunk=90000, return_samples=False):
+    """density_color: (1, 1 + n_rgb + n_sem, H, W, D).  Chunked like NeuSHead.render
+    (model/head/neus_head/neus_head.py:329-385)."""
+    outs = []
+    N = origins.shape[0]
+    for s in range(0, N, chunk):
+        e = min(N, s + chunk)
+        outs.append(_render_chunk(mapping, density_color, n_rgb, n_sem, origins[s:e], dirs[s:e],
+                                  dir_norm[s:e], cfg, None if t_rand is None else t_rand[s:e],
+                                  None if bkgd_rays is None else bkgd_rays[s:e], return_samples))
+    return {k: torch.cat([o[k] for o in outs]) for k in outs[0]}
+
+
+def _render_chunk(mapping, vol, n_rgb, n_sem, o, d, dn, cfg, t_rand, bkgd_rays, return_samples):
+    S = cfg.n_samples
+    nears, fars = aabb_collider(o, d, cfg.aabb, cfg.near_plane)
+    edges = uniform_bins(o.shape[0], S, nears, fars, t_rand)
+    starts, ends = edges[:, :-1], edges[:, 1:]
+    deltas = ends - starts
+    mids = (starts + ends) / 2
+    if cfg.sample_pos == 0:
+        pos = o[:, None, :] + d[:, None, :] * starts[..., None]
+    else:
+        pos = o[:, None, :] + d[:, None, :] * (starts + ends)[..., None] / 2
+    pos = pos.detach().requires_grad_(True)
+    with torch.enable_grad():
+        h = field_lookup(mapping, vol, pos.reshape(-1, 3))
+        sdf = h[:, 0].reshape(-1, S)
+        grad = torch.autograd.grad(sdf.sum(), pos)[0]
+    sdf = sdf.detach()
+    h = h.detach()
+    # NeuS get_alpha, cos_anneal_ratio = 1
+    true_cos = (d[:, None, :] * grad).sum(-1)
+    iter_cos = -F.relu(-true_cos)
+    est_next = sdf + iter_cos * deltas * 0.5
+    est_prev = sdf - iter_cos * deltas * 0.5
+    prev_cdf = torch.sigmoid(est_prev * cfg.inv_s)
+    next_cdf = torch.sigmoid(est_next * cfg.inv_s)
+    alpha = ((prev_cdf - next_cdf + 1e-5) / (prev_cdf + 1e-5)).clip(0.0, 1.0)
+    trans = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha + 1e-7], 1), 1)
+    weights = alpha * trans[:, :-1]
+    acc = weights.sum(-1)
+    depth = (weights * mids).sum(-1) / (acc + 1e-10)
+    if cfg.depth_div_norm:
+        depth = depth / dn
+    out = {'depth': depth, 'acc': acc, 'nears': nears[:, 0], 'fars': fars[:, 0]}
+    # head post-math, neus_head.py:366-374, 430-438
+    ts = mids / dn[:, None]
+    dz = deltas / dn[:, None]
+    eps = torch.finfo(dz.dtype).eps
+    w_ = weights.clone()
+    w_[dz < eps] = 0.
+    idx = (w_ / dz.clamp_min(eps)).argmax(dim=-1, keepdim=True)
+    out['max_depth'] = torch.gather(ts, -1, idx).squeeze(-1)
+    if n_rgb:
+        col = sh0_color(h[:, 1:1 + n_rgb]).reshape(-1, S, 3)
+        rgb = (weights[..., None] * col).sum(-2)
+        if cfg.bkgd_mode == 1:
+            rgb = rgb + torch.tensor(cfg.bkgd) * (1.0 - acc[:, None])
+        elif cfg.bkgd_mode == 2:
+            rgb = rgb + bkgd_rays * (1.0 - acc[:, None])
+        if cfg.clamp_rgb:
+            rgb = rgb.clamp(0.0, 1.0)
+        out['rgb'] = rgb
+    if n_sem:
+        sm = torch.softmax(h[:, 1 + n_rgb:], dim=-1).reshape(-1, S, n_sem)
+        out['sem'] = (weights[..., None] * sm).sum(-2)
+    if return_samples:
+        out.update(weights=weights, ts=ts, deltas=dz, sdf=sdf, grad=grad)
+    return out

@@ -1,0 +1,98 @@
+"""ctypes mirror of include/selfocc_hip.h (the C ABI of libselfocc_hip.so).
+
+Field order and types must match the header exactly; tests/test_abi.py checks
+``sizeof`` of every struct against the sizes the compiled library reports through
+its exported symbols being callable with these layouts.
+"""
+import ctypes as C
+
+ABI_VERSION = 3
+
+# enums ---------------------------------------------------------------------------
+RAYS_EXPLICIT, RAYS_PIXEL_GRID = 0, 1
+SAMPLE_AT_START, SAMPLE_AT_MID = 0, 1
+BKGD_NONE, BKGD_CONST, BKGD_PER_RAY = 0, 1, 2
+JITTER_NONE, JITTER_SINGLE, JITTER_PER_BIN = 0, 1, 2
+FLAG_DEPTH_DIV_NORM, FLAG_CLAMP_RGB = 1, 2
+DTYPE_F32, DTYPE_BF16 = 0, 1
+
+_f, _i, _p = C.c_float, C.c_int32, C.c_void_p
+
+
+class SoAxis(C.Structure):
+    _fields_ = [("size0", _f), ("size1", _f), ("range0", _f), ("range1", _f),
+                ("off0", _f), ("off1", _f), ("start", _f), ("tot_len", _i)]
+
+
+class SoMapping(C.Structure):
+    _fields_ = [("h", SoAxis), ("w", SoAxis), ("d", SoAxis)]
+
+
+class SoRenderArgs(C.Structure):
+    _fields_ = [
+        ("map", SoMapping),
+        ("sdf_vol", _p), ("feat_vol", _p),
+        ("feat_dtype", _i), ("feat_stride", _i), ("n_rgb", _i), ("n_sem", _i),
+        ("ray_mode", _i), ("n_rays", _i),
+        ("origins", _p), ("dirs", _p), ("dir_norm", _p), ("img2lidar", _p),
+        ("n_cams", _i), ("nx", _i), ("ny", _i),
+        ("sx", _f), ("sy", _f), ("ox", _f), ("oy", _f),
+        ("aabb", _f * 6), ("near_plane", _f),
+        ("n_samples", _i), ("sample_pos", _i), ("jitter_mode", _i),
+        ("t_rand", _p),
+        ("inv_s", _f),
+        ("bkgd_mode", _i), ("bkgd", _f * 3),
+        ("bkgd_rays", _p),
+        ("flags", _i),
+        ("depth", _p), ("acc", _p), ("rgb", _p), ("sem", _p), ("max_depth", _p),
+        ("nears", _p), ("fars", _p),
+        ("weights", _p), ("ts", _p), ("deltas", _p), ("sdf", _p), ("grad", _p),
+    ]
+
+
+class SoRenderBwdArgs(C.Structure):
+    _fields_ = [
+        ("fwd", SoRenderArgs),
+        ("g_depth", _p), ("g_acc", _p), ("g_rgb", _p), ("g_sem", _p),
+        ("g_weights", _p), ("g_sdf", _p), ("g_grad", _p),
+        ("g_sdf_vol", _p), ("g_feat_vol", _p), ("g_inv_s", _p),
+    ]
+
+
+class SoQueryArgs(C.Structure):
+    _fields_ = [
+        ("map", SoMapping),
+        ("sdf_vol", _p), ("feat_vol", _p),
+        ("feat_dtype", _i), ("feat_stride", _i), ("n_rgb", _i), ("n_sem", _i),
+        ("xyz", _p), ("n", _i),
+        ("sdf", _p), ("sem_logits", _p), ("sem_argmax", _p),
+    ]
+
+
+class SoReprojArgs(C.Structure):
+    _fields_ = [
+        ("weights", _p), ("ts", _p), ("deltas", _p),
+        ("pix", _p), ("curr_rgb", _p),
+        ("T_prev", _p), ("T_next", _p),
+        ("img_prev", _p), ("img_next", _p),
+        ("R", _i), ("S", _i), ("Hi", _i), ("Wi", _i),
+        ("img_h", _f), ("img_w", _f),
+        ("l1", _p), ("rgb_combine", _p), ("any_valid", _p),
+        ("wnorm", _p),
+    ]
+
+
+# every symbol include/selfocc_hip.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    "selfocc_abi_version": (C.c_int, []),
+    "selfocc_last_error": (C.c_char_p, []),
+    "selfocc_render_fwd": (C.c_int, [C.POINTER(SoRenderArgs), _p]),
+    "selfocc_render_bwd": (C.c_int, [C.POINTER(SoRenderBwdArgs), _p]),
+    "selfocc_msda_fwd": (C.c_int, [_p, _p, _p, _p, _p, _p] + [_i] * 7 + [_p]),
+    "selfocc_msda_bwd": (C.c_int, [_p] * 9 + [_i] * 7 + [_p]),
+    "selfocc_field_query": (C.c_int, [C.POINTER(SoQueryArgs), _p]),
+    "selfocc_occ_resample": (C.c_int, [_p, _p, _i, _i, _i, _i, _p, _i, _f, _p, _p, _p, _p, _p]),
+    "selfocc_iou_counts": (C.c_int, [_p, _p, _p, C.c_int64, _p, _i, _i, _p, _p]),
+    "selfocc_reproj_fwd": (C.c_int, [C.POINTER(SoReprojArgs), _p]),
+    "selfocc_reproj_bwd": (C.c_int, [C.POINTER(SoReprojArgs), _p, _p, _p, _p]),
+}
