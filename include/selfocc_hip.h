@@ -70,7 +70,10 @@ enum { SO_BKGD_NONE = 0, SO_BKGD_CONST = 1, SO_BKGD_PER_RAY = 2 };
 enum { SO_JITTER_NONE = 0, SO_JITTER_SINGLE = 1, SO_JITTER_PER_BIN = 2 };
 enum {
     SO_FLAG_DEPTH_DIV_NORM = 1, /* depth /= ||K^-1 (u,v,1)|| (z-depth, as the fork does) */
-    SO_FLAG_CLAMP_RGB = 2       /* eval: clamp rgb to [0,1]                              */
+    SO_FLAG_CLAMP_RGB = 2,      /* eval: clamp rgb to [0,1]                              */
+    SO_FLAG_EXACT = 4           /* canonical IEEE operation order (bit-exact with oracle/):
+                                   slower; default is the fast path (rcp/exp2 hardware ops,
+                                   per-ray affine grid coordinates), same results to ~1e-6  */
 };
 enum { SO_DTYPE_F32 = 0, SO_DTYPE_BF16 = 1 };
 

@@ -112,6 +112,7 @@ class RenderConfig:
     bkgd: tuple = (0.0, 0.0, 0.0)
     depth_div_norm: bool = True
     clamp_rgb: bool = False
+    exact: bool = False               # canonical IEEE op order (bit-exact with the oracle), slower
 
 
 def _c(t, dtype=torch.float32):
@@ -166,7 +167,8 @@ def marshal_render_args(vol: SDFVolume, rays: RaySet, cfg: RenderConfig, *, per_
     if cfg.bkgd_mode == abi.BKGD_PER_RAY:
         assert bkgd_rays is not None and tuple(bkgd_rays.shape) == (N, 3)
         a.bkgd_rays = ptr(_c(bkgd_rays))
-    a.flags = (abi.FLAG_DEPTH_DIV_NORM if cfg.depth_div_norm else 0) | (abi.FLAG_CLAMP_RGB if cfg.clamp_rgb else 0)
+    a.flags = (abi.FLAG_DEPTH_DIV_NORM if cfg.depth_div_norm else 0) | (abi.FLAG_CLAMP_RGB if cfg.clamp_rgb else 0) | \
+        (abi.FLAG_EXACT if cfg.exact else 0)
 
     f32 = dict(dtype=torch.float32, device=dev)
     out = outputs if outputs is not None else {}
