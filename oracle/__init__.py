@@ -90,3 +90,31 @@ def linspace01(j, n):
     fn = lib().oracle_linspace01
     fn.restype, fn.argtypes = C.c_float, [C.c_int, C.c_int]
     return fn(j, n)
+
+
+def msda_fwd(value, shapes, starts, loc, attw):
+    """C oracle of MSDA forward.  value (bs,nv,h,d) f32; shapes (L,2) int; loc (bs,nq,h,L,P,2)."""
+    import torch
+    bs, nv, heads, d = value.shape
+    _, nq, _, L, P, _ = loc.shape
+    out = torch.empty(bs, nq, heads * d)
+    sh = shapes.to(torch.int32).contiguous(); st = starts.to(torch.int32).contiguous()
+    fn = lib().oracle_msda_fwd
+    fn.restype, fn.argtypes = C.c_int, [C.c_void_p] * 6 + [C.c_int] * 7
+    fn(value.contiguous().data_ptr(), sh.data_ptr(), st.data_ptr(), loc.contiguous().data_ptr(),
+       attw.contiguous().data_ptr(), out.data_ptr(), bs, nv, nq, heads, d, L, P)
+    return out
+
+
+def msda_bwd(value, shapes, starts, loc, attw, g_out):
+    import torch
+    bs, nv, heads, d = value.shape
+    _, nq, _, L, P, _ = loc.shape
+    gv, gl, ga = torch.zeros_like(value), torch.empty_like(loc), torch.empty_like(attw)
+    sh = shapes.to(torch.int32).contiguous(); st = starts.to(torch.int32).contiguous()
+    fn = lib().oracle_msda_bwd
+    fn.restype, fn.argtypes = C.c_int, [C.c_void_p] * 9 + [C.c_int] * 7
+    fn(value.contiguous().data_ptr(), sh.data_ptr(), st.data_ptr(), loc.contiguous().data_ptr(),
+       attw.contiguous().data_ptr(), g_out.contiguous().data_ptr(), gv.data_ptr(), gl.data_ptr(), ga.data_ptr(),
+       bs, nv, nq, heads, d, L, P)
+    return gv, gl, ga

@@ -131,3 +131,28 @@ def _render_chunk(mapping, vol, n_rgb, n_sem, o, d, dn, cfg, t_rand, bkgd_rays, 
     if return_samples:
         out.update(weights=weights, ts=ts, deltas=dz, sdf=sdf, grad=grad)
     return out
+
+
+# ---------------------------------------------------------------------------------------
+# mmcv.ops.multi_scale_deform_attn.multi_scale_deformable_attn_pytorch — the function the
+# reference itself calls when value is not on CUDA
+# (model/encoder/bevformer/attention/image_cross_attention.py:344-345).  mmcv==2.0.1 is not
+# in /root/reference; restated from its published source.
+# ---------------------------------------------------------------------------------------
+def msda_port(value, spatial_shapes, sampling_locations, attention_weights):
+    bs, _, num_heads, embed_dims = value.shape
+    _, num_queries, num_heads, num_levels, num_points, _ = sampling_locations.shape
+    value_list = value.split([int(H_ * W_) for H_, W_ in spatial_shapes], dim=1)
+    sampling_grids = 2 * sampling_locations - 1
+    sampling_value_list = []
+    for level, (H_, W_) in enumerate(spatial_shapes):
+        value_l_ = value_list[level].flatten(2).transpose(1, 2).reshape(bs * num_heads, embed_dims, int(H_), int(W_))
+        sampling_grid_l_ = sampling_grids[:, :, :, level].transpose(1, 2).flatten(0, 1)
+        sampling_value_l_ = F.grid_sample(value_l_, sampling_grid_l_, mode='bilinear', padding_mode='zeros',
+                                          align_corners=False)
+        sampling_value_list.append(sampling_value_l_)
+    attention_weights = attention_weights.transpose(1, 2).reshape(bs * num_heads, 1, num_queries,
+                                                                  num_levels * num_points)
+    output = (torch.stack(sampling_value_list, dim=-2).flatten(-2) * attention_weights).sum(-1).view(
+        bs, num_heads * embed_dims, num_queries)
+    return output.transpose(1, 2).contiguous()

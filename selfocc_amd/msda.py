@@ -1,0 +1,72 @@
+"""Multi-scale deformable attention op — same name, signature and autograd contract as
+``mmcv.ops.multi_scale_deform_attn.MultiScaleDeformableAttnFunction`` (mmcv==2.0.1), the
+native op the reference calls at
+model/encoder/bevformer/attention/image_cross_attention.py:340-342 and
+model/encoder/tpvformer/attention/cross_view_hybrid_attention.py:111-113.
+The arithmetic is csrc/msda.hip behind selfocc_msda_fwd / selfocc_msda_bwd.
+"""
+import torch
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+
+from ._lib import lib, check, ptr, current_stream
+
+
+def _prep(value, spatial_shapes, level_start_index, sampling_locations, attention_weights):
+    if not value.is_cuda:
+        raise RuntimeError("MultiScaleDeformableAttnFunction needs CUDA(HIP) tensors: selfocc_amd has no CPU fallback")
+    bs, nv, heads, d = value.shape
+    _, nq, heads2, L, P, two = sampling_locations.shape
+    assert heads2 == heads and two == 2
+    assert tuple(attention_weights.shape) == (bs, nq, heads, L, P)
+    assert spatial_shapes.shape == (L, 2) and level_start_index.shape == (L,)
+    value = value.contiguous().float()
+    # mmcv casts locations / weights to value's dtype (amp switch = dtype of value)
+    loc = sampling_locations.contiguous().float()
+    aw = attention_weights.contiguous().float()
+    sh = spatial_shapes.to(device=value.device, dtype=torch.int32).contiguous()
+    st = level_start_index.to(device=value.device, dtype=torch.int32).contiguous()
+    return value, sh, st, loc, aw, (bs, nv, nq, heads, d, L, P)
+
+
+class MultiScaleDeformableAttnFunction(Function):
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                attention_weights, im2col_step=64):
+        """value (bs, num_keys, num_heads, embed_dims // num_heads); value_spatial_shapes
+        (num_levels, 2) [H, W]; sampling_locations (bs, num_queries, num_heads, num_levels,
+        num_points, 2) in [0, 1] (x, y); attention_weights (bs, num_queries, num_heads,
+        num_levels, num_points).  Returns (bs, num_queries, embed_dims).  ``im2col_step`` is
+        accepted for signature compatibility; the HIP kernel needs no batch chunking."""
+        value, sh, st, loc, aw, dims = _prep(value, value_spatial_shapes, value_level_start_index,
+                                             sampling_locations, attention_weights)
+        bs, nv, nq, heads, d, L, P = dims
+        out = torch.empty(bs, nq, heads * d, device=value.device, dtype=torch.float32)
+        check(lib().selfocc_msda_fwd(ptr(value), ptr(sh), ptr(st), ptr(loc), ptr(aw), ptr(out),
+                                     bs, nv, nq, heads, d, L, P, current_stream(value.device)),
+              "selfocc_msda_fwd")
+        ctx.save_for_backward(value, sh, st, loc, aw)
+        ctx.dims = dims
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, sh, st, loc, aw = ctx.saved_tensors
+        bs, nv, nq, heads, d, L, P = ctx.dims
+        g_out = grad_output.contiguous().float()
+        g_value = torch.zeros_like(value)
+        g_loc = torch.empty_like(loc)
+        g_aw = torch.empty_like(aw)
+        check(lib().selfocc_msda_bwd(ptr(value), ptr(sh), ptr(st), ptr(loc), ptr(aw), ptr(g_out),
+                                     ptr(g_value), ptr(g_loc), ptr(g_aw),
+                                     bs, nv, nq, heads, d, L, P, current_stream(value.device)),
+              "selfocc_msda_bwd")
+        return g_value, None, None, g_loc, g_aw, None
+
+
+def multi_scale_deformable_attn(value, spatial_shapes, level_start_index, sampling_locations,
+                                attention_weights):
+    return MultiScaleDeformableAttnFunction.apply(value, spatial_shapes, level_start_index,
+                                                  sampling_locations, attention_weights, 64)
