@@ -192,14 +192,30 @@ typedef struct so_query_args {
 
 int selfocc_field_query(const so_query_args *args, void *stream);
 
-/* Trilinear resample of a dense (H, W, D) scalar grid (+ optional (H, W, D, C) logits)
- * at normalised coordinates, threshold, border crop, argmax + LUT: eval_iou.py:211-250.
- *   coords (n, 3) in [0,1] along (H, W, D) of the source grid (align_corners=True)
- *   occ    (n) int32 = (sdf <= thresh)            sem (n) int32 = occ * lut[argmax]   */
-int selfocc_occ_resample(const float *grid, const float *logits, int32_t H, int32_t W,
-                         int32_t D, int32_t C, const float *coords, int32_t n,
-                         float thresh, const int32_t *lut, float *sampled,
-                         int32_t *occ, int32_t *sem, void *stream);
+/* Occ3D evaluation tail, eval_iou.py:211-250: trilinear resample (F.grid_sample,
+ * align_corners=True, zero padding — bit-exact with torch's CPU kernel) of the dense SDF
+ * grid (+ optional semantic logits) at the ego-frame Occ3D lattice, threshold, border crop,
+ * argmax + openseed2nuscenes LUT (utils/metric_util.py:37-64), occupancy * semantics.
+ *   grid    [H][W][D] float32           logits [H][W][D][C] float32 (NULL: no semantics)
+ *   coords  (n, 3) normalised [0,1] along (H, W, D) of `grid`; n = n0 * n1 * n2 lattice
+ *   crop    {lo0, hi0, lo1, hi1, lo2, hi2}: output index i_k outside [lo_k, n_k - hi_k) -> 0
+ *   density != 0 selects (value >= thresh) (eval_iou.py:205-206,227) instead of (<=). */
+typedef struct so_occ_args {
+    const float *grid;
+    const float *logits;
+    int32_t H, W, D, C;
+    const float *coords;
+    int32_t n0, n1, n2;
+    int32_t crop[6];
+    float thresh;
+    int32_t density;
+    const int32_t *lut; /* (C) class LUT applied to the argmax, NULL = identity */
+    float *sampled;     /* (n) resampled scalar, optional                        */
+    int32_t *occ;       /* (n) 0 / 1                                             */
+    int32_t *sem;       /* (n) occ * lut[argmax_c logits], optional              */
+} so_occ_args;
+
+int selfocc_occ_resample(const so_occ_args *args, void *stream);
 
 /* Integer confusion counts of MeanIoU._after_step (utils/metric_util.py:90-121):
  * counts (3, n_cls + 1) int64 rows = seen / correct / positive; last column = the

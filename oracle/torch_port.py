@@ -156,3 +156,65 @@ def msda_port(value, spatial_shapes, sampling_locations, attention_weights):
     output = (torch.stack(sampling_value_list, dim=-2).flatten(-2) * attention_weights).sum(-1).view(
         bs, num_heads * embed_dims, num_queries)
     return output.transpose(1, 2).contiguous()
+
+
+# ---------------------------------------------------------------------------------------
+# Occ3D evaluation tail — eval_iou.py:152-163 (lattice), :211-250 (resample, threshold,
+# crop, argmax, LUT) and utils/metric_util.py:37-64, 90-165 (LUT, MeanIoU), CPU torch ops.
+# ---------------------------------------------------------------------------------------
+def openseed2nuscenes(sem):
+    lut = torch.tensor([1, 2, 3, 4, 5, 5, 6, 7, 8, 9, 9, 10, 11, 12, 13, 14, 14, 15, 15, 16, 0],
+                       dtype=sem.dtype, device=sem.device)
+    return lut[sem.flatten()].reshape(*sem.shape)
+
+
+def occ3d_lattice():
+    xx = torch.linspace(-40.0, 40.0, 200)
+    yy = torch.linspace(-40.0, 40.0, 200)
+    zz = torch.linspace(-1.0, 5.4, 16)
+    return torch.stack([xx[:, None, None].expand(-1, 200, 16), yy[None, :, None].expand(200, -1, 16),
+                        zz[None, None, :].expand(200, 200, -1), torch.ones(200, 200, 16)], dim=-1)
+
+
+def occ_tail_port(sdf, logits, ego2lidar, point_cloud_range, expansion, thresh, xyz=None):
+    """sdf (H, W, D); logits (H, W, D, C) or None; returns pred_occ, pred_occ_miou, lidar_points."""
+    xyz = occ3d_lattice() if xyz is None else xyz
+    n0, n1, n2 = xyz.shape[:3]
+    ego2lidar = xyz.new_tensor(ego2lidar)
+    lidar_points = torch.matmul(ego2lidar.unsqueeze(0), xyz.reshape(-1, 4, 1)).squeeze(-1)[:, :3]
+    lidar_points[:, 0] = (lidar_points[:, 0] - point_cloud_range[0]) / expansion[0]
+    lidar_points[:, 1] = (lidar_points[:, 1] - point_cloud_range[1]) / expansion[1]
+    lidar_points[:, 2] = (lidar_points[:, 2] - point_cloud_range[2]) / expansion[2]
+    lidar_points = lidar_points.reshape(1, n0, n1, n2, 3)
+    sampled_sdf = F.grid_sample(sdf[None, None, ...], lidar_points[..., [2, 0, 1]] * 2 - 1, mode='bilinear',
+                                align_corners=True)
+    pred_occ = (sampled_sdf.squeeze(0).squeeze(0) <= thresh).to(torch.int)
+    pred_occ[..., 12:] = 0
+    pred_occ[:6, ...] = 0
+    pred_occ[-6:, ...] = 0
+    pred_occ[:, :6, :] = 0
+    pred_occ[:, -6:, :] = 0
+    pred_miou = None
+    if logits is not None:
+        sem = logits.permute(3, 0, 1, 2)
+        sampled_sem = F.grid_sample(sem[None, ...], lidar_points[..., [2, 0, 1]] * 2 - 1, mode='bilinear',
+                                    align_corners=True)
+        sampled_sem = torch.argmax(sampled_sem, dim=1).squeeze(0)
+        pred_miou = pred_occ * openseed2nuscenes(sampled_sem)
+    return pred_occ, pred_miou, lidar_points[0], sampled_sdf[0, 0]
+
+
+def mean_iou_counts_port(outputs, targets, class_indices, empty_label, mask=None):
+    """MeanIoU._after_step (utils/metric_util.py:108-121) -> (3, n_cls + 1) int64"""
+    if mask is not None:
+        outputs, targets = outputs[mask], targets[mask]
+    n = len(class_indices)
+    c = torch.zeros(3, n + 1, dtype=torch.int64)
+    for i, k in enumerate(class_indices):
+        c[0, i] = torch.sum(targets == k).item()
+        c[1, i] = torch.sum((targets == k) & (outputs == k)).item()
+        c[2, i] = torch.sum(outputs == k).item()
+    c[0, -1] = torch.sum(targets != empty_label).item()
+    c[1, -1] = torch.sum((targets != empty_label) & (outputs != empty_label)).item()
+    c[2, -1] = torch.sum(outputs != empty_label).item()
+    return c

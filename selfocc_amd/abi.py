@@ -69,6 +69,19 @@ class SoQueryArgs(C.Structure):
     ]
 
 
+class SoOccArgs(C.Structure):
+    _fields_ = [
+        ("grid", _p), ("logits", _p),
+        ("H", _i), ("W", _i), ("D", _i), ("C", _i),
+        ("coords", _p),
+        ("n0", _i), ("n1", _i), ("n2", _i),
+        ("crop", _i * 6),
+        ("thresh", _f), ("density", _i),
+        ("lut", _p),
+        ("sampled", _p), ("occ", _p), ("sem", _p),
+    ]
+
+
 class SoReprojArgs(C.Structure):
     _fields_ = [
         ("weights", _p), ("ts", _p), ("deltas", _p),
@@ -91,7 +104,7 @@ SYMBOLS = {
     "selfocc_msda_fwd": (C.c_int, [_p, _p, _p, _p, _p, _p] + [_i] * 7 + [_p]),
     "selfocc_msda_bwd": (C.c_int, [_p] * 9 + [_i] * 7 + [_p]),
     "selfocc_field_query": (C.c_int, [C.POINTER(SoQueryArgs), _p]),
-    "selfocc_occ_resample": (C.c_int, [_p, _p, _i, _i, _i, _i, _p, _i, _f, _p, _p, _p, _p, _p]),
+    "selfocc_occ_resample": (C.c_int, [C.POINTER(SoOccArgs), _p]),
     "selfocc_iou_counts": (C.c_int, [_p, _p, _p, C.c_int64, _p, _i, _i, _p, _p]),
     "selfocc_reproj_fwd": (C.c_int, [C.POINTER(SoReprojArgs), _p]),
     "selfocc_reproj_bwd": (C.c_int, [C.POINTER(SoReprojArgs), _p, _p, _p, _p]),

@@ -236,8 +236,8 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(const float *__restrict__
 
 int validate(const float *value, const int32_t *shapes, const int32_t *starts, const float *loc,
              const float *attw, int bs, int nv, int nq, int heads, int d, int L, int P) {
-    SO_REQUIRE(value && shapes && starts && loc && attw, "msda: NULL input pointer");
     SO_REQUIRE(bs >= 0 && nq >= 0 && nv >= 0, "msda: negative size");
+    SO_REQUIRE((bs == 0 || nq == 0) || (value && shapes && starts && loc && attw), "msda: NULL input pointer");
     SO_REQUIRE(heads >= 1 && L >= 1 && P >= 1, "msda: heads, L, P must be >= 1");
     SO_REQUIRE(d == 4 || d == 8 || d == 16 || d == 32, "msda: channels per head must be 4, 8, 16 or 32 (got %d)", d);
     SO_REQUIRE((long long)bs * nq * heads * L * P < (1LL << 40), "msda: problem too large");
@@ -251,9 +251,9 @@ extern "C" int selfocc_msda_fwd(const float *value, const int32_t *shapes, const
                                 int32_t nv, int32_t nq, int32_t heads, int32_t d, int32_t L,
                                 int32_t P, void *stream) {
     if (validate(value, shapes, starts, loc, attw, bs, nv, nq, heads, d, L, P)) return -1;
-    SO_REQUIRE(out != nullptr, "msda_fwd: out is NULL");
     const long long n_groups = (long long)bs * nq * heads;
     if (n_groups == 0) return 0;
+    SO_REQUIRE(out != nullptr, "msda_fwd: out is NULL");
     const int LP = L * P;
     int G = 1, logG = 0;
     while (G < LP && G < 64) { G <<= 1; ++logG; }
@@ -281,9 +281,9 @@ extern "C" int selfocc_msda_bwd(const float *value, const int32_t *shapes, const
                                 int32_t nv, int32_t nq, int32_t heads, int32_t d, int32_t L,
                                 int32_t P, void *stream) {
     if (validate(value, shapes, starts, loc, attw, bs, nv, nq, heads, d, L, P)) return -1;
-    SO_REQUIRE(g_out && g_value && g_loc && g_attw, "msda_bwd: NULL gradient pointer");
     const long long n_pts = (long long)bs * nq * heads * L * P;
     if (n_pts == 0) return 0;
+    SO_REQUIRE(g_out && g_value && g_loc && g_attw, "msda_bwd: NULL gradient pointer");
     const long long blocks = (n_pts + 255) / 256;
     SO_REQUIRE(blocks < (1LL << 31), "msda_bwd: grid too large");
     MsdaDims dm{bs, nv, nq, heads, L, P};

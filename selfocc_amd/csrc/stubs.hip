@@ -3,8 +3,5 @@
 #include "so_device.h"
 #define SO_STUB(name) so_set_error(#name " is not implemented in this build"); return -2;
 extern "C" int selfocc_render_bwd(const so_render_bwd_args *, void *) { SO_STUB(selfocc_render_bwd) }
-extern "C" int selfocc_field_query(const so_query_args *, void *) { SO_STUB(selfocc_field_query) }
-extern "C" int selfocc_occ_resample(const float *, const float *, int32_t, int32_t, int32_t, int32_t, const float *, int32_t, float, const int32_t *, float *, int32_t *, int32_t *, void *) { SO_STUB(selfocc_occ_resample) }
-extern "C" int selfocc_iou_counts(const int32_t *, const int32_t *, const uint8_t *, int64_t, const int32_t *, int32_t, int32_t, unsigned long long *, void *) { SO_STUB(selfocc_iou_counts) }
 extern "C" int selfocc_reproj_fwd(const so_reproj_args *, void *) { SO_STUB(selfocc_reproj_fwd) }
 extern "C" int selfocc_reproj_bwd(const so_reproj_args *, const float *, const float *, float *, void *) { SO_STUB(selfocc_reproj_bwd) }
