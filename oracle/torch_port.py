@@ -218,3 +218,89 @@ def mean_iou_counts_port(outputs, targets, class_indices, empty_label, mask=None
     c[1, -1] = torch.sum((targets != empty_label) & (outputs != empty_label)).item()
     c[2, -1] = torch.sum(outputs != empty_label).item()
     return c
+
+
+# ---------------------------------------------------------------------------------------
+# Differentiable restatement for the BACKWARD parity tests.  Stock PyTorch cannot
+# double-backward 3-D grid_sample (the reference needs the external cuda_gridsample_grad2
+# for that, docs/installation.md:30), so the lookup is written as an explicit 8-corner
+# trilinear (value identical to F.grid_sample(align_corners=True): tested) whose analytic
+# metre gradient is itself differentiable wrt the volume.  Run in float64.
+# ---------------------------------------------------------------------------------------
+def trilinear_explicit(mapping, vol_chw, xyz):
+    """vol_chw (C, H, W, D); xyz (n, 3) -> values (n, C), d value[:, 0] / d xyz (n, 3)."""
+    C, H, W, D = vol_chw.shape
+    g = mapping.meter2grid(xyz)                       # (n, 3) h, w, d (un-normalised)
+    with torch.no_grad():
+        eps = 1e-3
+        gp = mapping.meter2grid(xyz + eps)
+        slope = (gp - g) / eps                         # piece-wise constant d grid / d metre (y->h, x->w, z->d)
+        slope = torch.stack([slope[:, 1], slope[:, 0], slope[:, 2]], -1)   # metre order x, y, z
+    g0 = torch.floor(g)
+    fr = g - g0
+    i0 = g0.long()
+    vals = 0
+    dval = [0, 0, 0]
+    for kh in (0, 1):
+        for kw in (0, 1):
+            for kd in (0, 1):
+                h, w, d = i0[:, 0] + kh, i0[:, 1] + kw, i0[:, 2] + kd
+                inb = (h >= 0) & (h < H) & (w >= 0) & (w < W) & (d >= 0) & (d < D)
+                v = vol_chw[:, h.clamp(0, H - 1), w.clamp(0, W - 1), d.clamp(0, D - 1)].T * inb[:, None]
+                fh = fr[:, 0] if kh else 1 - fr[:, 0]
+                fw = fr[:, 1] if kw else 1 - fr[:, 1]
+                fd = fr[:, 2] if kd else 1 - fr[:, 2]
+                vals = vals + v * (fh * fw * fd)[:, None]
+                s = v[:, 0]
+                dval[0] = dval[0] + s * (1 if kw else -1) * fh * fd   # d / d grid w  (metre x)
+                dval[1] = dval[1] + s * (1 if kh else -1) * fw * fd   # d / d grid h  (metre y)
+                dval[2] = dval[2] + s * (1 if kd else -1) * fh * fw   # d / d grid d  (metre z)
+    grad = torch.stack(dval, -1) * torch.stack([slope[:, 0], slope[:, 1], slope[:, 2]], -1)
+    return vals, grad
+
+
+def render_port_differentiable(mapping, vol_chw, n_rgb, n_sem, o, d, dn, cfg, inv_s, t_rand=None, bkgd_rays=None):
+    """Same algorithm as _render_chunk, every op differentiable wrt vol_chw and inv_s."""
+    S = cfg.n_samples
+    nears, fars = aabb_collider(o, d, cfg.aabb, cfg.near_plane)
+    bins = torch.linspace(0.0, 1.0, S + 1, dtype=o.dtype)[None, :]
+    if t_rand is not None:
+        tr = t_rand[:, None] if t_rand.dim() == 1 else t_rand
+        centers = (bins[..., 1:] + bins[..., :-1]) / 2.0
+        upper = torch.cat([centers, bins[..., -1:]], -1)
+        lower = torch.cat([bins[..., :1], centers], -1)
+        bins = lower + (upper - lower) * tr
+    edges = bins * fars + (1 - bins) * nears
+    starts, ends = edges[:, :-1], edges[:, 1:]
+    deltas = ends - starts
+    mids = (starts + ends) / 2
+    pos = o[:, None, :] + d[:, None, :] * (starts if cfg.sample_pos == 0 else mids)[..., None]
+    h, grad = trilinear_explicit(mapping, vol_chw, pos.reshape(-1, 3))
+    sdf = h[:, 0].reshape(-1, S)
+    grad = grad.reshape(-1, S, 3)
+    true_cos = (d[:, None, :] * grad).sum(-1)
+    iter_cos = -F.relu(-true_cos)
+    prev_cdf = torch.sigmoid((sdf - iter_cos * deltas * 0.5) * inv_s)
+    next_cdf = torch.sigmoid((sdf + iter_cos * deltas * 0.5) * inv_s)
+    alpha = ((prev_cdf - next_cdf + 1e-5) / (prev_cdf + 1e-5)).clip(0.0, 1.0)
+    trans = torch.cumprod(torch.cat([torch.ones_like(alpha[:, :1]), 1.0 - alpha + 1e-7], 1), 1)
+    weights = alpha * trans[:, :-1]
+    acc = weights.sum(-1)
+    depth = (weights * mids).sum(-1) / (acc + 1e-10)
+    if cfg.depth_div_norm:
+        depth = depth / dn
+    out = dict(depth=depth, acc=acc, weights=weights, sdf=sdf, grad=grad)
+    if n_rgb:
+        col = sh0_color(h[:, 1:1 + n_rgb]).reshape(-1, S, 3)
+        rgb = (weights[..., None] * col).sum(-2)
+        if cfg.bkgd_mode == 1:
+            rgb = rgb + torch.tensor(cfg.bkgd, dtype=o.dtype) * (1.0 - acc[:, None])
+        elif cfg.bkgd_mode == 2:
+            rgb = rgb + bkgd_rays * (1.0 - acc[:, None])
+        if cfg.clamp_rgb:
+            rgb = rgb.clamp(0.0, 1.0)
+        out['rgb'] = rgb
+    if n_sem:
+        sm = torch.softmax(h[:, 1 + n_rgb:], dim=-1).reshape(-1, S, n_sem)
+        out['sem'] = (weights[..., None] * sm).sum(-2)
+    return out

@@ -202,3 +202,67 @@ def render_rays(vol: SDFVolume, rays: RaySet, cfg: RenderConfig, *, per_sample=F
                                         bkgd_rays=bkgd_rays, outputs=outputs)
     check(lib().selfocc_render_fwd(a, current_stream(vol.sdf.device)), "selfocc_render_fwd")
     return out
+
+
+class _RenderFunction(torch.autograd.Function):
+    """Differentiable wrt the SDF volume, the feature volume and inv_s (a 0-dim / 1-elem
+    tensor).  Ray geometry carries no gradient — the reference's rays come from constant
+    camera matrices (model/head/nerfacc_head/img2lidar.py:36-69)."""
+
+    @staticmethod
+    def forward(ctx, sdf_vol, feat_vol, inv_s, mapping, n_rgb, n_sem, rays, cfg, t_rand, bkgd_rays, want_grad_samples):
+        vol = SDFVolume(mapping, sdf_vol, feat_vol, n_rgb, n_sem)
+        cfg_run = RenderConfig(**{**cfg.__dict__, 'inv_s': float(inv_s.detach().reshape(-1)[0])})
+        out = render_rays(vol, rays, cfg_run, per_sample=True, want_grad_samples=want_grad_samples,
+                          t_rand=t_rand, bkgd_rays=bkgd_rays)
+        ctx.vol, ctx.rays, ctx.cfg, ctx.t_rand, ctx.bkgd_rays = vol, rays, cfg_run, t_rand, bkgd_rays
+        ctx.inv_s_shape = inv_s.shape
+        ctx.keys = ['depth', 'acc'] + (['rgb'] if n_rgb else []) + (['sem'] if n_sem else []) + ['weights'] + \
+            (['sdf', 'grad'] if want_grad_samples else [])
+        ctx.nondiff_keys = ['ts', 'deltas', 'max_depth', 'nears', 'fars']
+        nd = tuple(out[k] for k in ctx.nondiff_keys)
+        ctx.mark_non_differentiable(*nd)
+        return tuple(out[k] for k in ctx.keys) + nd
+
+    @staticmethod
+    def backward(ctx, *grads):
+        vol, rays, cfg = ctx.vol, ctx.rays, ctx.cfg
+        gmap = {k: g for k, g in zip(ctx.keys, grads)}
+        a, _out, _keep = marshal_render_args(vol, rays, cfg, per_sample=False, t_rand=ctx.t_rand,
+                                             bkgd_rays=ctx.bkgd_rays, outputs={})
+        ba = abi.SoRenderBwdArgs()
+        ba.fwd = a
+        hold = []
+        def gp(name):
+            g = gmap.get(name)
+            if g is None:
+                return None
+            g = g.contiguous().float()
+            hold.append(g)
+            return ptr(g)
+        ba.g_depth, ba.g_acc, ba.g_rgb, ba.g_sem = gp('depth'), gp('acc'), gp('rgb'), gp('sem')
+        ba.g_weights, ba.g_sdf, ba.g_grad = gp('weights'), gp('sdf'), gp('grad')
+        g_sdf_vol = torch.zeros_like(vol.sdf)
+        ba.g_sdf_vol = ptr(g_sdf_vol)
+        g_feat = None
+        if vol.feat is not None:
+            g_feat = torch.zeros(vol.feat.shape, dtype=torch.float32, device=vol.feat.device)
+            ba.g_feat_vol = ptr(g_feat)
+        g_inv_s = torch.zeros(1, device=vol.sdf.device)
+        ba.g_inv_s = ptr(g_inv_s)
+        check(lib().selfocc_render_bwd(ba, current_stream(vol.sdf.device)), "selfocc_render_bwd")
+        if g_feat is not None and vol.feat.dtype != torch.float32:
+            g_feat = g_feat.to(vol.feat.dtype)
+        return (g_sdf_vol, g_feat, g_inv_s.reshape(ctx.inv_s_shape), None, None, None, None, None, None, None, None)
+
+
+def render_rays_autograd(vol: SDFVolume, inv_s: torch.Tensor, rays: RaySet, cfg: RenderConfig, *,
+                         want_grad_samples=True, t_rand=None, bkgd_rays=None):
+    """Training-time render: returns the same dict as ``render_rays(per_sample=True)`` with
+    depth / acc / rgb / sem / weights / sdf / grad attached to the autograd graph of
+    ``vol.sdf``, ``vol.feat`` and ``inv_s``."""
+    res = _RenderFunction.apply(vol.sdf, vol.feat, inv_s, vol.mapping, vol.n_rgb, vol.n_sem, rays, cfg,
+                                t_rand, bkgd_rays, want_grad_samples)
+    keys = ['depth', 'acc'] + (['rgb'] if vol.n_rgb else []) + (['sem'] if vol.n_sem else []) + ['weights'] + \
+        (['sdf', 'grad'] if want_grad_samples else []) + ['ts', 'deltas', 'max_depth', 'nears', 'fars']
+    return dict(zip(keys, res))

@@ -109,3 +109,16 @@ def test_compositing_invariants():
     assert (o['depth'] * 1.0 >= 0).all()
     assert torch.allclose(o['weights'].sum(-1), o['acc'], rtol=1e-5, atol=1e-6)
     assert torch.allclose(o['sem'].sum(-1), o['acc'], rtol=1e-4, atol=1e-5)  # softmax sums to 1
+
+
+def test_differentiable_port_matches_grid_sample_port():
+    """trilinear_explicit (used for the backward parity tests) == F.grid_sample lookup."""
+    vol, rays = _port_inputs("cfg1", 3, 5)
+    ex = sy.explicit_rays(rays)
+    cfg = sy.make_render_config("cfg1", inv_s=15.0)
+    a = tp.render_port(vol.mapping, vol.to_reference_layout(), 3, 5, ex.origins, ex.dirs, ex.dir_norm, cfg,
+                       return_samples=True)
+    b = tp.render_port_differentiable(vol.mapping, vol.to_reference_layout()[0].double(), 3, 5, ex.origins.double(),
+                                      ex.dirs.double(), ex.dir_norm.double(), cfg, torch.tensor(15.0, dtype=torch.float64))
+    for k in ('sdf', 'grad', 'weights', 'acc', 'rgb', 'sem'):
+        assert torch.allclose(a[k].double(), b[k], rtol=2e-3, atol=2e-5), k

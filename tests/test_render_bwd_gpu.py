@@ -1,0 +1,88 @@
+"""GPU parity of selfocc_render_bwd: gradients wrt the SDF volume, the feature volume and
+inv_s against float64 autograd through the differentiable torch port of the same path."""
+import pytest
+import torch
+
+from oracle import torch_port as tp
+from selfocc_amd import abi, synthetic as sy
+from selfocc_amd.render import render_rays_autograd, RaySet, SDFVolume
+
+pytestmark = pytest.mark.gpu
+D0 = torch.device("cuda:0")
+
+
+def _rel_l2(a, b):
+    return ((a - b).norm() / (b.norm() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("n_rgb,n_sem,jitter,sample_pos,S", [
+    (0, 0, abi.JITTER_NONE, 0, 32), (3, 0, abi.JITTER_SINGLE, 1, 32), (3, 5, abi.JITTER_PER_BIN, 0, 32),
+    (3, 21, abi.JITTER_NONE, 0, 100), (3, 0, abi.JITTER_NONE, 0, 256)])
+def test_render_backward_vs_float64_autograd(hip, n_rgb, n_sem, jitter, sample_pos, S):
+    vol = sy.make_volume("cfg1", n_rgb=n_rgb, n_sem=n_sem, seed=11, noise=0.02)
+    ex = sy.explicit_rays(sy.make_rays("cfg1", seed=11))
+    cfg = sy.make_render_config("cfg1", inv_s=12.0, sample_pos=sample_pos, jitter_mode=jitter,
+                                bkgd_mode=abi.BKGD_PER_RAY if n_rgb else abi.BKGD_NONE)
+    cfg.n_samples = S
+    N = ex.n_rays
+    g = torch.Generator().manual_seed(3)
+    t_rand = None if jitter == abi.JITTER_NONE else torch.rand(*((N,) if jitter == abi.JITTER_SINGLE else (N, S + 1)), generator=g)
+    bk = torch.rand(N, 3, generator=g) if n_rgb else None
+    # random upstream gradients on every differentiable output
+    G = dict(depth=torch.randn(N, generator=g), acc=torch.randn(N, generator=g),
+             weights=torch.randn(N, S, generator=g), sdf=0.1 * torch.randn(N, S, generator=g),
+             grad=0.1 * torch.randn(N, S, 3, generator=g))
+    if n_rgb:
+        G['rgb'] = torch.randn(N, 3, generator=g)
+    if n_sem:
+        G['sem'] = torch.randn(N, n_sem, generator=g)
+
+    # ---- float64 reference -------------------------------------------------------------
+    dd = torch.float64
+    vol64 = vol.to_reference_layout()[0].to(dd).requires_grad_(True)      # (C, H, W, D)
+    inv_s64 = torch.tensor(cfg.inv_s, dtype=dd, requires_grad=True)
+    ref = tp.render_port_differentiable(vol.mapping, vol64, n_rgb, n_sem, ex.origins.to(dd), ex.dirs.to(dd),
+                                        ex.dir_norm.to(dd), cfg, inv_s64,
+                                        None if t_rand is None else t_rand.to(dd), None if bk is None else bk.to(dd))
+    L = sum((ref[k] * G[k].to(dd)).sum() for k in G)
+    L.backward()
+    ref_gsdf = vol64.grad[0]
+    ref_gfeat = vol64.grad[1:].permute(1, 2, 3, 0) if n_rgb + n_sem else None
+
+    # ---- HIP ---------------------------------------------------------------------------
+    v = vol.to(D0)
+    sdf_p = v.sdf.clone().requires_grad_(True)
+    feat_p = None if v.feat is None else v.feat.clone().requires_grad_(True)
+    inv_s = torch.tensor([cfg.inv_s], device=D0, requires_grad=True)
+    out = render_rays_autograd(SDFVolume(v.mapping, sdf_p, feat_p, n_rgb, n_sem), inv_s,
+                               RaySet(origins=ex.origins.to(D0), dirs=ex.dirs.to(D0), dir_norm=ex.dir_norm.to(D0)),
+                               cfg, want_grad_samples=True, t_rand=None if t_rand is None else t_rand.to(D0),
+                               bkgd_rays=None if bk is None else bk.to(D0))
+    # forward agrees with the float64 port
+    for k in G:
+        assert torch.allclose(out[k].detach().cpu().double(), ref[k].detach(), rtol=2e-3, atol=2e-4), k
+    Lh = sum((out[k] * G[k].to(D0)).sum() for k in G)
+    Lh.backward()
+    e_sdf = _rel_l2(sdf_p.grad.cpu().double(), ref_gsdf)
+    assert e_sdf < 2e-3, f"d/d sdf_vol rel L2 {e_sdf:.3e}"
+    assert (sdf_p.grad.cpu().double() - ref_gsdf).abs().max() < 2e-2 * ref_gsdf.abs().max()
+    if ref_gfeat is not None:
+        got = feat_p.grad.cpu().double()[..., :n_rgb + n_sem]
+        e_f = _rel_l2(got, ref_gfeat)
+        assert e_f < 2e-3, f"d/d feat_vol rel L2 {e_f:.3e}"
+        if feat_p.shape[-1] > n_rgb + n_sem:
+            assert feat_p.grad[..., n_rgb + n_sem:].abs().max() == 0
+    e_s = abs(inv_s.grad.item() - inv_s64.grad.item()) / (abs(inv_s64.grad.item()) + 1e-12)
+    assert e_s < 5e-3, f"d/d inv_s rel {e_s:.3e} ({inv_s.grad.item()} vs {inv_s64.grad.item()})"
+
+
+def test_render_backward_zero_upstream(hip):
+    vol = sy.make_volume("cfg1", n_rgb=3, n_sem=0, seed=1).to(D0)
+    ex = sy.explicit_rays(sy.make_rays("cfg1", seed=1))
+    sdf_p = vol.sdf.clone().requires_grad_(True)
+    inv_s = torch.tensor([20.0], device=D0, requires_grad=True)
+    out = render_rays_autograd(SDFVolume(vol.mapping, sdf_p, vol.feat, 3, 0), inv_s,
+                               RaySet(origins=ex.origins.to(D0), dirs=ex.dirs.to(D0), dir_norm=ex.dir_norm.to(D0)),
+                               sy.make_render_config("cfg1"))
+    (out['depth'].sum() * 0.0).backward()
+    assert sdf_p.grad.abs().max() == 0 and inv_s.grad.abs().max() == 0
