@@ -1,0 +1,41 @@
+import torch.nn as nn
+
+from ..registry import OPENOCC_LOSS
+
+
+class BaseLoss(nn.Module):
+    """weight * loss_func(**{arg: inputs[key]}) with ``input_dict`` = {arg: key} (loss/base_loss.py:9-39)."""
+
+    def __init__(self, weight=1.0, input_dict={'input': 'input'}, **kwargs):
+        super().__init__()
+        self.weight = weight
+        self.input_dict = input_dict
+        self.loss_func = lambda: 0
+        self.writer = None
+
+    def forward(self, inputs):
+        return self.weight * self.loss_func(**{arg: inputs[key] for arg, key in self.input_dict.items()})
+
+
+@OPENOCC_LOSS.register_module()
+class MultiLoss(nn.Module):
+    """Sum of the configured losses -> (total, {class name: float}) (loss/multi_loss.py:10-43).
+    ``sync_items=False`` keeps the per-loss values on the device (the reference
+    pays one ``.item()`` host sync per loss per iteration, multi_loss.py:33-41)."""
+
+    def __init__(self, loss_cfgs, sync_items=True):
+        super().__init__()
+        assert isinstance(loss_cfgs, list)
+        self.num_losses = len(loss_cfgs)
+        self.losses = nn.ModuleList([OPENOCC_LOSS.build(cfg) for cfg in loss_cfgs])
+        self.iter_counter = 0
+        self.sync_items = sync_items
+
+    def forward(self, inputs):
+        loss_dict, tot_loss = {}, 0.
+        for loss_func in self.losses:
+            loss = loss_func(inputs)
+            tot_loss = tot_loss + loss
+            loss_dict[loss_func.__class__.__name__] = loss.detach().item() if self.sync_items else loss.detach()
+        self.iter_counter += 1
+        return tot_loss, loss_dict

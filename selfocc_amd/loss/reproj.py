@@ -1,0 +1,153 @@
+"""Temporal reprojection photometric losses.
+
+ReprojLossMonoMultiNewCombine <- loss/reproj_loss_mono_multi_new_combine.py:41-247
+ReprojLossMonoMultiNew        <- loss/reproj_loss_mono_multi_new.py:41-287
+The per-sample chain (projection, bilinear fetch, masks, per-ray renormalised reductions)
+is ONE fused HIP launch per camera (reproj.py -> csrc/reproj.hip); SSIM, the auto-mask
+minimum and the means stay in torch on the (R, 3) lattice images.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..registry import OPENOCC_LOSS
+from ..reproj import ReprojSampleFunction
+from .base import BaseLoss
+
+
+class SSIM(nn.Module):
+    """(1 - SSIM) / 2 with 3x3 mean filters on reflection-padded inputs, clamped to [0, 1]."""
+    C1, C2 = 0.01 ** 2, 0.03 ** 2
+
+    def forward(self, x, y):
+        x, y = F.pad(x, (1, 1, 1, 1), mode='reflect'), F.pad(y, (1, 1, 1, 1), mode='reflect')
+        pool = lambda t: F.avg_pool2d(t, 3, 1)
+        mu_x, mu_y = pool(x), pool(y)
+        sigma_x = pool(x ** 2) - mu_x ** 2
+        sigma_y = pool(y ** 2) - mu_y ** 2
+        sigma_xy = pool(x * y) - mu_x * mu_y
+        n = (2 * mu_x * mu_y + self.C1) * (2 * sigma_xy + self.C2)
+        d = (mu_x ** 2 + mu_y ** 2 + self.C1) * (sigma_x + sigma_y + self.C2)
+        return torch.clamp((1 - n / d) / 2, 0, 1)
+
+
+# a transform that maps every point behind the camera: disables one temporal frame in the kernel
+_INVALID = torch.diag(torch.tensor([1.0, 1.0, -1.0, 1.0]))
+
+
+class _ReprojBase(BaseLoss):
+    def __init__(self, weight=1.0, input_dict=None, **kwargs):
+        super().__init__(weight)
+        self.input_dict = input_dict if input_dict is not None else {
+            'curr_imgs': 'curr_imgs', 'prev_imgs': 'prev_imgs', 'next_imgs': 'next_imgs',
+            'ray_indices': 'ray_indices', 'weights': 'weights', 'ts': 'ts', 'metas': 'metas', 'ms_rays': 'ms_rays'}
+        self.img_size = kwargs.get('img_size', [768, 1600])
+        self.ray_resize = kwargs.get('ray_resize', None)
+        self.no_automask = kwargs.get('no_automask', False)
+        self.dims = kwargs.get('dims', 3)
+        self.no_ssim = kwargs.get('no_ssim', False) or (self.ray_resize is None)
+        if not self.no_ssim:
+            self.ssim = SSIM()
+        self.loss_func = self.reproj_loss
+        self.iter_counter = 0
+
+    def _transforms(self, metas, key, like, num_cams):
+        vals = [m[key] for m in metas]
+        if isinstance(vals[0], (np.ndarray, list)):
+            t = like.new_tensor(np.asarray(vals))
+        else:
+            t = torch.stack(vals, dim=0).to(like)
+        return t.reshape(-1, num_cams, 4, 4).float()
+
+    def _sample_lattice(self, pix, img, padding_mode):
+        """bilinear sample of one camera image (3, H, W) at the ray pixels -> (R, 3)."""
+        g = pix.clone().reshape(1, 1, -1, 2)
+        g[..., 0] /= self.img_size[1]
+        g[..., 1] /= self.img_size[0]
+        out = F.grid_sample(img[None], 2 * g - 1, mode='bilinear', padding_mode=padding_mode, align_corners=True)
+        return out.reshape(img.shape[0], -1).transpose(0, 1)
+
+    def _photometric(self, pred, target):
+        """0.85 SSIM + 0.15 L1 per ray between two (R, 3) lattice images."""
+        l1 = torch.abs(target - pred).mean(-1)
+        if self.no_ssim:
+            return l1
+        im = lambda t: t.reshape(1, *self.ray_resize, self.dims).permute(0, 3, 1, 2)
+        return 0.85 * self.ssim(im(pred), im(target)).mean(1).flatten() + 0.15 * l1
+
+
+@OPENOCC_LOSS.register_module()
+class ReprojLossMonoMultiNewCombine(_ReprojBase):
+
+    def reproj_loss(self, curr_imgs, prev_imgs, next_imgs, ray_indices, weights, ts, metas, ms_rays, deltas=None):
+        bs, num_cams = curr_imgs.shape[:2]
+        num_rays = ms_rays.shape[0]
+        assert bs == 1
+        T_prev = self._transforms(metas, 'img2prevImg', ts[0], num_cams)[0]
+        T_next = self._transforms(metas, 'img2nextImg', ts[0], num_cams)[0]
+        pix = ms_rays.float().contiguous()
+        tot = 0.
+        for cam, (weight, t) in enumerate(zip(weights, ts)):
+            rgb_curr = self._sample_lattice(pix, curr_imgs[0, cam].float(), 'border')              # (R, 3)
+            l1, comb, any_valid = ReprojSampleFunction.apply(
+                weight.reshape(num_rays, -1), t.reshape(num_rays, -1),
+                None if deltas is None else deltas[cam].detach().reshape(num_rays, -1), pix, rgb_curr,
+                T_prev[cam], T_next[cam], prev_imgs[0, cam].float(), next_imgs[0, cam].float(),
+                self.img_size[0], self.img_size[1])
+            prev_next = l1
+            if not self.no_ssim:
+                im = lambda x: x.reshape(1, *self.ray_resize, self.dims).permute(0, 3, 1, 2)
+                prev_next = 0.15 * l1 + 0.85 * self.ssim(im(comb), im(rgb_curr)).mean(1).flatten()
+            if not self.no_automask:
+                target_prev = self._sample_lattice(pix, prev_imgs[0, cam].float(), 'border')
+                target_next = self._sample_lattice(pix, next_imgs[0, cam].float(), 'border')
+                prev_next = torch.where(any_valid > 0, prev_next, prev_next.new_full((), 1e3))
+                proj = torch.stack([prev_next, self._photometric(target_prev, rgb_curr),
+                                    self._photometric(target_next, rgb_curr)], dim=-1).min(dim=-1)[0]
+            else:
+                proj = prev_next
+            tot = tot + proj.mean()
+        self.iter_counter += 1
+        return tot / num_cams
+
+
+@OPENOCC_LOSS.register_module()
+class ReprojLossMonoMultiNew(_ReprojBase):
+    """Mono / KITTI variant: the two temporal frames are masked and renormalised separately and
+    enter the minimum as two candidates (reproj_loss_mono_multi_new.py:165-255)."""
+
+    def __init__(self, weight=1.0, input_dict=None, **kwargs):
+        super().__init__(weight, input_dict, **kwargs)
+        if kwargs.get('sdf_loss', False):
+            raise NotImplementedError("sdf_loss=True is not used by any shipped config")
+
+    def reproj_loss(self, curr_imgs, prev_imgs, next_imgs, ray_indices, weights, ts, metas, ms_rays, deltas=None,
+                    sample_sdfs=None):
+        bs, num_cams = curr_imgs.shape[:2]
+        num_rays = ms_rays.shape[0]
+        assert bs == 1
+        T_prev = self._transforms(metas, 'img2prevImg', ts[0], num_cams)[0]
+        T_next = self._transforms(metas, 'img2nextImg', ts[0], num_cams)[0]
+        pix = ms_rays.float().contiguous()
+        invalid = _INVALID.to(pix.device)
+        tot = 0.
+        for cam, (weight, t) in enumerate(zip(weights, ts)):
+            target_curr = self._sample_lattice(pix, curr_imgs[0, cam].float(), 'zeros')
+            w2, t2 = weight.reshape(num_rays, -1), t.reshape(num_rays, -1)
+            d2 = None if deltas is None else deltas[cam].detach().reshape(num_rays, -1)
+            cands = []
+            for T, img in ((T_prev[cam], prev_imgs[0, cam].float()), (T_next[cam], next_imgs[0, cam].float())):
+                l1, comb, any_valid = ReprojSampleFunction.apply(w2, t2, d2, pix, target_curr, T, invalid, img, img,
+                                                                 self.img_size[0], self.img_size[1])
+                loss = l1
+                if not self.no_ssim:
+                    im = lambda x: x.reshape(1, *self.ray_resize, self.dims).permute(0, 3, 1, 2)
+                    loss = 0.85 * self.ssim(im(comb), im(target_curr)).mean(1).flatten() + 0.15 * l1
+                cands.append(torch.where(any_valid > 0, loss, loss.new_full((), 1e3)))
+            if not self.no_automask:
+                for img in (prev_imgs[0, cam].float(), next_imgs[0, cam].float()):
+                    cands.append(self._photometric(self._sample_lattice(pix, img, 'zeros'), target_curr))
+            tot = tot + torch.stack(cands, dim=-1).min(dim=-1)[0].mean()
+        self.iter_counter += 1
+        return tot / num_cams

@@ -1,0 +1,186 @@
+"""Small building blocks the reference takes from mmengine / mmcv (absent here): BaseModule,
+ModuleList, init helpers, FFN, norm builder and the mmcv MultiScaleDeformableAttention base
+class whose parameters / state-dict keys CrossViewHybridAttention inherits
+(model/encoder/tpvformer/attention/cross_view_hybrid_attention.py:12)."""
+import math
+import warnings
+
+import torch
+import torch.nn as nn
+
+from ..registry import MODELS
+from ..msda import MultiScaleDeformableAttnFunction
+
+
+class BaseModule(nn.Module):
+    def __init__(self, init_cfg=None):
+        super().__init__()
+        self.init_cfg = init_cfg
+        self._is_init = False
+
+    def init_weights(self):
+        for m in self.children():
+            if hasattr(m, 'init_weights'):
+                m.init_weights()
+        self._is_init = True
+
+
+ModuleList = nn.ModuleList
+
+
+def xavier_init(module, gain=1, bias=0, distribution='normal'):
+    if getattr(module, 'weight', None) is not None:
+        (nn.init.xavier_uniform_ if distribution == 'uniform' else nn.init.xavier_normal_)(module.weight, gain=gain)
+    if getattr(module, 'bias', None) is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def constant_init(module, val, bias=0):
+    if getattr(module, 'weight', None) is not None:
+        nn.init.constant_(module.weight, val)
+    if getattr(module, 'bias', None) is not None:
+        nn.init.constant_(module.bias, bias)
+
+
+def build_norm_layer(cfg, num_features):
+    typ = cfg.get('type', 'LN')
+    if typ != 'LN':
+        raise NotImplementedError(f"norm {typ}: only LN is used on the SelfOcc hot path")
+    return 'ln', nn.LayerNorm(num_features, eps=cfg.get('eps', 1e-5))
+
+
+def build_activation_layer(cfg):
+    typ = cfg.get('type', 'ReLU')
+    if typ == 'ReLU':
+        return nn.ReLU(inplace=cfg.get('inplace', False))
+    if typ == 'GELU':
+        return nn.GELU()
+    raise NotImplementedError(typ)
+
+
+@MODELS.register_module()
+class FFN(BaseModule):
+    """mmcv.cnn.bricks.transformer.FFN: Linear -> act -> drop (x num_fcs-1) -> Linear -> drop,
+    returns identity + out."""
+
+    def __init__(self, embed_dims=256, feedforward_channels=1024, num_fcs=2,
+                 act_cfg=dict(type='ReLU', inplace=True), ffn_drop=0., dropout_layer=None,
+                 add_identity=True, init_cfg=None, **kwargs):
+        super().__init__(init_cfg)
+        assert num_fcs >= 2
+        self.embed_dims, self.feedforward_channels, self.num_fcs = embed_dims, feedforward_channels, num_fcs
+        layers, in_ch = [], embed_dims
+        for _ in range(num_fcs - 1):
+            layers.append(nn.Sequential(nn.Linear(in_ch, feedforward_channels), build_activation_layer(act_cfg),
+                                        nn.Dropout(ffn_drop)))
+            in_ch = feedforward_channels
+        layers.append(nn.Linear(feedforward_channels, embed_dims))
+        layers.append(nn.Dropout(ffn_drop))
+        self.layers = nn.Sequential(*layers)
+        self.dropout_layer = nn.Identity()
+        self.add_identity = add_identity
+
+    def forward(self, x, identity=None):
+        out = self.layers(x)
+        if not self.add_identity:
+            return self.dropout_layer(out)
+        if identity is None:
+            identity = x
+        return identity + self.dropout_layer(out)
+
+
+def deformable_sampling(module, query, value, reference_points, spatial_shapes, level_start_index,
+                        per_level_reference, key_padding_mask=None):
+    """Shared body of the three deformable attentions: value_proj, offset / weight linears,
+    softmax, sampling locations, MSDA (HIP).  ``per_level_reference``: reference points
+    carry their own (level, point) dims (CrossViewHybridAttention,
+    cross_view_hybrid_attention.py:96-99) instead of one anchor per point
+    (BEVDeformableAttention, bevformer/attention/image_cross_attention.py:323-328)."""
+    bs, num_query, _ = query.shape
+    _, num_value, _ = value.shape
+    assert int((spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum()) == num_value
+    value = module.value_proj(value)
+    if key_padding_mask is not None:
+        value = value.masked_fill(key_padding_mask[..., None], 0.0)
+    value = value.view(bs, num_value, module.num_heads, -1)
+    off = module.sampling_offsets(query).view(bs, num_query, module.num_heads, module.num_levels,
+                                              module.num_points, 2)
+    aw = module.attention_weights(query).view(bs, num_query, module.num_heads,
+                                              module.num_levels * module.num_points).softmax(-1)
+    aw = aw.view(bs, num_query, module.num_heads, module.num_levels, module.num_points)
+    if reference_points.shape[-1] != 2:
+        raise ValueError('Last dim of reference_points must be 2 on the SelfOcc path, '
+                         f'got {reference_points.shape[-1]}')
+    normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
+    if per_level_reference == 'level_point':      # (bs, nq, L, P, 2)
+        ref = reference_points[:, :, None, :, :, :]
+    elif per_level_reference == 'point':          # (bs, nq, P, 2): one anchor per point, all levels
+        ref = reference_points[:, :, None, None, :, :]
+    else:                                         # (bs, nq, L, 2): mmcv base class
+        ref = reference_points[:, :, None, :, None, :]
+    loc = ref + off / normalizer[None, None, None, :, None, :]
+    return MultiScaleDeformableAttnFunction.apply(value, spatial_shapes, level_start_index, loc, aw,
+                                                  module.im2col_step)
+
+
+@MODELS.register_module()
+class MultiScaleDeformableAttention(BaseModule):
+    """mmcv.ops.multi_scale_deform_attn.MultiScaleDeformableAttention (mmcv==2.0.1): same
+    constructor, parameters (sampling_offsets, attention_weights, value_proj, output_proj) and
+    forward contract; used as self-attention by config/nuscenes/nuscenes_occ_bev.py:222."""
+
+    def __init__(self, embed_dims=256, num_heads=8, num_levels=4, num_points=4, im2col_step=64,
+                 dropout=0.1, batch_first=False, norm_cfg=None, init_cfg=None, value_proj_ratio=1.0):
+        super().__init__(init_cfg)
+        if embed_dims % num_heads != 0:
+            raise ValueError(f'embed_dims must be divisible by num_heads, but got {embed_dims} and {num_heads}')
+        dim_per_head = embed_dims // num_heads
+        if dim_per_head & (dim_per_head - 1):
+            warnings.warn("the HIP MSDA kernel needs a power-of-two dim per head (4, 8, 16, 32)")
+        self.norm_cfg, self.batch_first = norm_cfg, batch_first
+        self.dropout = nn.Dropout(dropout)
+        self.im2col_step, self.embed_dims = im2col_step, embed_dims
+        self.num_levels, self.num_heads, self.num_points = num_levels, num_heads, num_points
+        self.sampling_offsets = nn.Linear(embed_dims, num_heads * num_levels * num_points * 2)
+        self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
+        value_proj_size = int(embed_dims * value_proj_ratio)
+        self.value_proj = nn.Linear(embed_dims, value_proj_size)
+        self.output_proj = nn.Linear(value_proj_size, embed_dims)
+        self.init_weights()
+
+    _scale_points = True  # mmcv scales the i-th point's offset bias by (i + 1)
+
+    def init_weights(self):
+        constant_init(self.sampling_offsets, 0.)
+        thetas = torch.arange(self.num_heads, dtype=torch.float32) * (2.0 * math.pi / self.num_heads)
+        grid_init = torch.stack([thetas.cos(), thetas.sin()], -1)
+        grid_init = (grid_init / grid_init.abs().max(-1, keepdim=True)[0]).view(
+            self.num_heads, 1, 1, 2).repeat(1, self.num_levels, self.num_points, 1)
+        if self._scale_points:
+            for i in range(self.num_points):
+                grid_init[:, :, i, :] *= i + 1
+        self.sampling_offsets.bias.data = grid_init.view(-1).to(self.sampling_offsets.bias.device)
+        constant_init(self.attention_weights, val=0., bias=0.)
+        xavier_init(self.value_proj, distribution='uniform', bias=0.)
+        if hasattr(self, 'output_proj'):
+            xavier_init(self.output_proj, distribution='uniform', bias=0.)
+        self._is_init = True
+
+    _reference_kind = 'level'
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
+                reference_points=None, spatial_shapes=None, level_start_index=None, **kwargs):
+        if value is None:
+            value = query
+        if identity is None:
+            identity = query
+        if query_pos is not None:
+            query = query + query_pos
+        if not self.batch_first:
+            query, value = query.permute(1, 0, 2), value.permute(1, 0, 2)
+        output = deformable_sampling(self, query, value, reference_points, spatial_shapes, level_start_index,
+                                     self._reference_kind, key_padding_mask)
+        output = self.output_proj(output)
+        if not self.batch_first:
+            output = output.permute(1, 0, 2)
+        return self.dropout(output) + identity

@@ -1,0 +1,164 @@
+"""Image cross-attention and cross-view hybrid attention of the TPV / BEV lifter — the
+MSDA call sites of the reference, behind the same registry names, constructor kwargs,
+parameter names (state-dict keys) and forward contracts:
+
+BEVDeformableAttention   <- model/encoder/bevformer/attention/image_cross_attention.py:149-351
+BEVCrossAttention        <- model/encoder/bevformer/attention/image_cross_attention.py:12-139
+TPVCrossAttention        <- model/encoder/tpvformer/attention/image_cross_attention.py:8-95
+CrossViewHybridAttention <- model/encoder/tpvformer/attention/cross_view_hybrid_attention.py:12-124
+The sampling itself is the HIP kernel behind MultiScaleDeformableAttnFunction (msda.py).
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from ...registry import MODELS, build_attention
+from ..bricks import (BaseModule, MultiScaleDeformableAttention, constant_init, xavier_init,
+                      deformable_sampling)
+
+
+@MODELS.register_module()
+class BEVDeformableAttention(BaseModule):
+    """Deformable attention with one reference anchor per sampling point
+    (num_points == points in the pillar); no output projection / residual — the caller
+    (BEVCrossAttention) owns those."""
+
+    def __init__(self, embed_dims=256, num_heads=8, num_levels=4, num_points=4, im2col_step=64,
+                 dropout=0.1, batch_first=False, norm_cfg=None, init_cfg=None, value_proj_ratio=1.0):
+        super().__init__(init_cfg)
+        if embed_dims % num_heads != 0:
+            raise ValueError(f'embed_dims must be divisible by num_heads, but got {embed_dims} and {num_heads}')
+        self.norm_cfg, self.batch_first = norm_cfg, batch_first
+        self.im2col_step, self.embed_dims = im2col_step, embed_dims
+        self.num_levels, self.num_heads, self.num_points = num_levels, num_heads, num_points
+        self.sampling_offsets = nn.Linear(embed_dims, num_heads * num_levels * num_points * 2)
+        self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
+        self.value_proj = nn.Linear(embed_dims, int(embed_dims * value_proj_ratio))
+        self.init_weights()
+
+    def init_weights(self):
+        constant_init(self.sampling_offsets, 0.)
+        thetas = torch.arange(self.num_heads, dtype=torch.float32) * (2.0 * math.pi / self.num_heads)
+        grid_init = torch.stack([thetas.cos(), thetas.sin()], -1)
+        grid_init = (grid_init / grid_init.abs().max(-1, keepdim=True)[0]).view(
+            self.num_heads, 1, 1, 2).repeat(1, self.num_levels, self.num_points, 1)
+        # (the reference deliberately drops mmcv's per-point (i + 1) scaling, :238-239)
+        self.sampling_offsets.bias.data = grid_init.view(-1).to(self.sampling_offsets.bias.device)
+        constant_init(self.attention_weights, val=0., bias=0.)
+        xavier_init(self.value_proj, distribution='uniform', bias=0.)
+        self._is_init = True
+
+    def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
+                reference_points=None, spatial_shapes=None, level_start_index=None, **kwargs):
+        if value is None:
+            value = query
+        if query_pos is not None:
+            query = query + query_pos
+        if not self.batch_first:
+            query, value = query.permute(1, 0, 2), value.permute(1, 0, 2)
+        output = deformable_sampling(self, query, value, reference_points, spatial_shapes, level_start_index,
+                                     'point', key_padding_mask)
+        if not self.batch_first:
+            output = output.permute(1, 0, 2)
+        return output
+
+
+@MODELS.register_module()
+class BEVCrossAttention(BaseModule):
+    """Every plane query attends to the cameras that see it: visible queries are re-batched
+    per camera, sampled by ``deformable_attention``, scattered back and averaged over the
+    cameras that hit (image_cross_attention.py:46-139).  The reference's python double loops
+    (:101-110, :129-131) are single index_select / index_add_ calls here."""
+
+    def __init__(self, embed_dims=256, num_cams=6, dropout=0.1, init_cfg=None, batch_first=True,
+                 deformable_attention=dict(type='MSDeformableAttention3D', embed_dims=256, num_levels=4),
+                 **kwargs):
+        super().__init__(init_cfg)
+        self.dropout = nn.Dropout(dropout)
+        self.deformable_attention = build_attention(deformable_attention)
+        self.embed_dims, self.num_cams = embed_dims, num_cams
+        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.batch_first = batch_first
+        self.init_weight()
+
+    def init_weight(self):
+        xavier_init(self.output_proj, distribution='uniform', bias=0.)
+
+    def forward(self, query, key, value, residual=None, spatial_shapes=None, reference_points_cams=None,
+                bev_masks=None, level_start_index=None, **kwargs):
+        if key is None:
+            key = query
+        if value is None:
+            value = key
+        if residual is None:
+            residual = query
+        bs, num_query, _ = query.size()
+        num_cams = self.num_cams
+        D = reference_points_cams.size(3)
+        # visible (camera, query) pairs; like the reference, visibility is taken from batch 0 (:92)
+        vis = bev_masks[:, 0].sum(-1) > 0                                  # (num_cams, Q)
+        lens = vis.sum(-1)
+        max_len = int(lens.max())                                          # the one host sync (:95)
+        cam_idx, q_idx = vis.nonzero(as_tuple=True)                        # sorted by camera, then query
+        starts = torch.cumsum(lens, 0) - lens
+        slot = torch.arange(cam_idx.numel(), device=query.device) - starts[cam_idx]
+        queries_rebatch = query.new_zeros([bs, num_cams, max_len, self.embed_dims])
+        ref_rebatch = reference_points_cams.new_zeros([bs, num_cams, max_len, D, 2])
+        queries_rebatch[:, cam_idx, slot] = query[:, q_idx]
+        ref_rebatch[:, cam_idx, slot] = reference_points_cams.permute(1, 0, 2, 3, 4)[:, cam_idx, q_idx]
+        queries_rebatch = queries_rebatch.flatten(0, 1)                    # (bs * num_cams, max_len, C)
+        ref_rebatch = ref_rebatch.flatten(0, 1)
+
+        _, l, _, _ = key.shape
+        key = key.permute(2, 0, 1, 3).reshape(num_cams * bs, l, self.embed_dims)
+        value = value.permute(2, 0, 1, 3).reshape(num_cams * bs, l, self.embed_dims)
+        sampled = self.deformable_attention(query=queries_rebatch, key=key, value=value,
+                                            reference_points=ref_rebatch, spatial_shapes=spatial_shapes,
+                                            level_start_index=level_start_index)
+        sampled = sampled.view(bs, num_cams, max_len, self.embed_dims)
+        slots = torch.zeros_like(query)
+        slots.index_add_(1, q_idx, sampled[:, cam_idx, slot])
+        count = bev_masks.sum(-1) > 0
+        count = count.permute(1, 2, 0).sum(-1)
+        count = torch.clamp(count, min=1.0)
+        slots = slots / count[..., None]
+        slots = self.output_proj(slots)
+        return self.dropout(slots) + residual
+
+
+@MODELS.register_module()
+class TPVCrossAttention(BaseModule):
+    """One BEVCrossAttention per TPV plane (hw, zh, wz) with num_points = [wz, zh, hw] pillar
+    sizes (tpvformer/attention/image_cross_attention.py:19-69)."""
+
+    def __init__(self, embed_dims=256, num_cams=6, dropout=0.1, init_cfg=None, batch_first=True,
+                 num_heads=16, num_levels=4, num_points=[64, 64, 8]):
+        super().__init__(init_cfg)
+
+        def plane(points):
+            return build_attention(dict(
+                type='BEVCrossAttention', embed_dims=embed_dims, num_cams=num_cams, dropout=dropout,
+                batch_first=batch_first,
+                deformable_attention=dict(type='BEVDeformableAttention', embed_dims=embed_dims,
+                                          num_heads=num_heads, num_levels=num_levels, num_points=points,
+                                          dropout=dropout, batch_first=batch_first)))
+        self.attn_hw = plane(num_points[2])
+        self.attn_zh = plane(num_points[1])
+        self.attn_wz = plane(num_points[0])
+        self.attns = [self.attn_hw, self.attn_zh, self.attn_wz]
+        self.embed_dims = embed_dims
+
+    def forward(self, query, key, value, residual=None, spatial_shapes=None, reference_points_cams=None,
+                tpv_masks=None, level_start_index=None, **kwargs):
+        return [self.attns[i](query[i], key, value, residual[i] if residual is not None else None,
+                              spatial_shapes=spatial_shapes, level_start_index=level_start_index,
+                              reference_points_cams=reference_points_cams[i], bev_masks=tpv_masks[i])
+                for i in range(3)]
+
+
+@MODELS.register_module()
+class CrossViewHybridAttention(MultiScaleDeformableAttention):
+    """Self-attention across the three TPV planes treated as 3 "levels"; reference points
+    carry their own (level, point) dims (cross_view_hybrid_attention.py:96-99)."""
+    _reference_kind = 'level_point'

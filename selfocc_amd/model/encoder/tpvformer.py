@@ -1,0 +1,335 @@
+"""TPVFormer / BEVFormer encoders: orchestration around the two MSDA call sites.
+
+TPVPositionalEncoding <- model/encoder/tpvformer/tpvformer_pos_embed.py:6-57
+BEVPositionalEncoding <- model/encoder/bevformer/bevformer_pos_embed.py:7-34
+TPVFormerLayer        <- model/encoder/tpvformer/tpvformer_encoder_layer.py:11-219
+BEVFormerLayer        <- model/encoder/bevformer/bevformer_encoder_layer.py:11-216
+TPVFormerEncoder      <- model/encoder/tpvformer/tpvformer_encoder.py:20-290
+BEVFormerEncoder      <- model/encoder/bevformer/bevformer_encoder.py:18-224
+Same registry names, constructor kwargs, buffers / parameter names and forward contracts.
+"""
+import copy
+
+import torch
+import torch.nn as nn
+
+from ...mapping import GridMeterMapping
+from ...registry import (MODELS, build_attention, build_feedforward_network, build_positional_encoding,
+                         build_transformer_layer)
+from ..bricks import BaseModule, ModuleList, MultiScaleDeformableAttention, build_norm_layer
+from .attention import BEVCrossAttention, BEVDeformableAttention, TPVCrossAttention, CrossViewHybridAttention
+from .utils import point_sampling, get_cross_view_ref_points
+
+
+def _fourier(num_freqs, meter):
+    """(…, 2) normalised metres -> (N, 4 * num_freqs) sin/cos features, pi * 2^k, k = -1 .. F-2."""
+    freqs = torch.pi * (2 ** torch.arange(-1, num_freqs - 1, dtype=torch.float))
+    mf = meter.unsqueeze(-1) * freqs[None, None, None, ...]
+    return torch.stack([torch.sin(mf), torch.cos(mf)], dim=-1).flatten(-3).flatten(0, 1)
+
+
+def _normalise(meter, lo0, hi0, lo1, hi1):
+    meter = meter.clone()
+    meter[..., 0] = (meter[..., 0] - lo0) / (hi0 - lo0)
+    meter[..., 1] = (meter[..., 1] - lo1) / (hi1 - lo1)
+    return meter
+
+
+@MODELS.register_module()
+class TPVPositionalEncoding(BaseModule):
+    def __init__(self, num_freqs, embed_dims, tpv_meters, tot_range, init_cfg=None):
+        super().__init__(init_cfg)
+        assert isinstance(tot_range, list) and len(tot_range) == 6
+        r = tot_range
+        hw, zh, wz = tpv_meters
+        self.register_buffer('hw_freq_feat', _fourier(num_freqs[0], _normalise(hw, r[0], r[3], r[1], r[4])), False)
+        self.register_buffer('zh_freq_feat', _fourier(num_freqs[1], _normalise(zh, r[1], r[4], r[2], r[5])), False)
+        self.register_buffer('wz_freq_feat', _fourier(num_freqs[2], _normalise(wz, r[0], r[3], r[2], r[5])), False)
+        self.position_layer_hw = nn.Linear(4 * num_freqs[0], embed_dims)
+        self.position_layer_zh = nn.Linear(4 * num_freqs[1], embed_dims)
+        self.position_layer_wz = nn.Linear(4 * num_freqs[2], embed_dims)
+
+    def forward(self):
+        return [self.position_layer_hw(self.hw_freq_feat), self.position_layer_zh(self.zh_freq_feat),
+                self.position_layer_wz(self.wz_freq_feat)]
+
+
+@MODELS.register_module()
+class BEVPositionalEncoding(BaseModule):
+    def __init__(self, num_freqs, embed_dims, bev_meter, tot_range, init_cfg=None):
+        super().__init__(init_cfg)
+        r = tot_range if isinstance(tot_range, list) else [-1.0 * tot_range, -1.0 * tot_range, 0., tot_range, tot_range, 0.]
+        self.register_buffer('freq_feat', _fourier(num_freqs, _normalise(bev_meter, r[0], r[3], r[1], r[4])), False)
+        self.position_layer = nn.Linear(4 * num_freqs, embed_dims)
+
+    def forward(self):
+        return self.position_layer(self.freq_feat)
+
+
+class _FormerLayerBase(BaseModule):
+    """attention / norm / ffn stack driven by ``operation_order`` (mmcv BaseTransformerLayer idiom)."""
+
+    def __init__(self, attn_cfgs=None,
+                 ffn_cfgs=dict(type='FFN', feedforward_channels=1024, num_fcs=2, ffn_drop=0.,
+                               act_cfg=dict(type='ReLU', inplace=True)),
+                 operation_order=None, norm_cfg=dict(type='LN'), init_cfg=None, batch_first=True, **kwargs):
+        ffn_cfgs = copy.deepcopy(ffn_cfgs)
+        for old, new in dict(feedforward_channels='feedforward_channels', ffn_dropout='ffn_drop',
+                             ffn_num_fcs='num_fcs').items():
+            if old in kwargs:
+                ffn_cfgs[new] = kwargs[old]
+        super().__init__(init_cfg)
+        self.batch_first = batch_first
+        num_attn = operation_order.count('self_attn') + operation_order.count('cross_attn')
+        if isinstance(attn_cfgs, dict):
+            attn_cfgs = [copy.deepcopy(attn_cfgs) for _ in range(num_attn)]
+        else:
+            attn_cfgs = [copy.deepcopy(c) for c in attn_cfgs]
+            assert num_attn == len(attn_cfgs)
+        self.num_attn, self.operation_order, self.norm_cfg = num_attn, operation_order, norm_cfg
+        self.pre_norm = operation_order[0] == 'norm'
+        self.attentions = ModuleList()
+        index = 0
+        for op in operation_order:
+            if op in ('self_attn', 'cross_attn'):
+                if 'batch_first' in attn_cfgs[index]:
+                    assert self.batch_first == attn_cfgs[index]['batch_first']
+                else:
+                    attn_cfgs[index]['batch_first'] = self.batch_first
+                attention = build_attention(attn_cfgs[index])
+                attention.operation_name = op
+                self.attentions.append(attention)
+                index += 1
+        self.embed_dims = self.attentions[0].embed_dims
+        self.ffns = ModuleList()
+        num_ffns = operation_order.count('ffn')
+        if isinstance(ffn_cfgs, dict):
+            ffn_cfgs = [copy.deepcopy(ffn_cfgs) for _ in range(num_ffns)]
+        assert len(ffn_cfgs) == num_ffns
+        for cfg in ffn_cfgs:
+            cfg.setdefault('embed_dims', self.embed_dims)
+            assert cfg['embed_dims'] == self.embed_dims
+            self.ffns.append(build_feedforward_network(cfg))
+        self.norms = ModuleList([build_norm_layer(norm_cfg, self.embed_dims)[1]
+                                 for _ in range(operation_order.count('norm'))])
+
+
+@MODELS.register_module()
+class TPVFormerLayer(_FormerLayerBase):
+    def __init__(self, *args, multi_plane_ffn_norm=False, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.multi_plane_ffn_norm = multi_plane_ffn_norm
+
+    def forward(self, query, key=None, value=None, tpv_pos=None, ref_2d=None, spatial_shapes=None,
+                level_start_index=None, reference_points_cams=None, tpv_masks=None, tpv_size=None, **kwargs):
+        H, W, Z = tpv_size
+        sizes = [H * W, Z * H, W * Z]
+        norm_i = attn_i = ffn_i = 0
+        identity = query
+        device = query[0].device
+        cat = lambda planes: planes if self.multi_plane_ffn_norm else torch.cat(planes, dim=1)
+        split = lambda t: t if self.multi_plane_ffn_norm else torch.split(t, sizes, 1)
+        for op in self.operation_order:
+            if op == 'self_attn':   # cross-view hybrid attention: the 3 planes are the 3 "levels"
+                ss = torch.tensor([[H, W], [Z, H], [W, Z]], device=device)
+                lsi = torch.tensor([0, H * W, H * W + Z * H], device=device)
+                q = torch.cat(query, dim=1)
+                q = self.attentions[attn_i](q, q, q, torch.cat(identity, dim=1) if self.pre_norm else None,
+                                            query_pos=torch.cat(tpv_pos, dim=1), reference_points=ref_2d,
+                                            spatial_shapes=ss, level_start_index=lsi, **kwargs)
+                query = torch.split(q, sizes, 1)
+                attn_i += 1
+                identity = query
+            elif op == 'norm':
+                query = split(self.norms[norm_i](cat(query)))
+                norm_i += 1
+            elif op == 'cross_attn':  # image cross-attention, per plane
+                query = self.attentions[attn_i](query, key, value, identity if self.pre_norm else None,
+                                                spatial_shapes=spatial_shapes, level_start_index=level_start_index,
+                                                reference_points_cams=reference_points_cams, tpv_masks=tpv_masks,
+                                                **kwargs)
+                attn_i += 1
+                identity = query
+            elif op == 'ffn':
+                query = split(self.ffns[ffn_i](cat(query), cat(identity) if self.pre_norm else None))
+                ffn_i += 1
+        return query
+
+
+@MODELS.register_module()
+class BEVFormerLayer(_FormerLayerBase):
+    def forward(self, query, key=None, value=None, bev_pos=None, ref_2d=None, spatial_shapes=None,
+                level_start_index=None, reference_points_cams=None, bev_masks=None, bev_size=None, **kwargs):
+        norm_i = attn_i = ffn_i = 0
+        identity = query
+        for op in self.operation_order:
+            if op == 'self_attn':
+                ss = torch.tensor([bev_size], device=query.device)
+                lsi = torch.tensor([0], device=query.device)
+                query = self.attentions[attn_i](query, query, query, identity if self.pre_norm else None,
+                                                query_pos=bev_pos, reference_points=ref_2d, spatial_shapes=ss,
+                                                level_start_index=lsi, **kwargs)
+                attn_i += 1
+                identity = query
+            elif op == 'norm':
+                query = self.norms[norm_i](query)
+                norm_i += 1
+            elif op == 'cross_attn':
+                query = self.attentions[attn_i](query, key, value, identity if self.pre_norm else None,
+                                                spatial_shapes=spatial_shapes, level_start_index=level_start_index,
+                                                reference_points_cams=reference_points_cams, bev_masks=bev_masks,
+                                                **kwargs)
+                attn_i += 1
+                identity = query
+            elif op == 'ffn':
+                query = self.ffns[ffn_i](query, identity if self.pre_norm else None)
+                ffn_i += 1
+        return query
+
+
+class _EncoderBase(BaseModule):
+    _attention_types = (BEVCrossAttention, MultiScaleDeformableAttention, BEVDeformableAttention,
+                        TPVCrossAttention, CrossViewHybridAttention)
+
+    def _build_layers(self, transformerlayers, num_layers):
+        if isinstance(transformerlayers, dict):
+            transformerlayers = [copy.deepcopy(transformerlayers) for _ in range(num_layers)]
+        else:
+            assert isinstance(transformerlayers, (list, tuple)) and len(transformerlayers) == num_layers
+        self.num_layers = num_layers
+        self.layers = ModuleList([build_transformer_layer(copy.deepcopy(c)) for c in transformerlayers])
+        self.pre_norm = self.layers[0].pre_norm
+        self.level_embeds = nn.Parameter(torch.randn(self.num_feature_levels, self.embed_dims))
+        self.cams_embeds = nn.Parameter(torch.randn(self.num_cams, self.embed_dims))
+
+    def init_weights(self):
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, self._attention_types):
+                (getattr(m, 'init_weight', None) or m.init_weights)()
+        nn.init.normal_(self.level_embeds)
+        nn.init.normal_(self.cams_embeds)
+
+    def _flatten_feats(self, img_feats):
+        """4 x (B, N, C, h, w) -> (N, sum hw, B, C) + cam / level embeddings, spatial shapes, level starts."""
+        device = img_feats[0].device
+        flat, shapes = [], []
+        for lvl, feat in enumerate(img_feats):
+            _, _, _, h, w = feat.shape
+            feat = feat.flatten(3).permute(1, 0, 3, 2)           # N, B, hw, C
+            feat = feat + self.cams_embeds[:, None, None, :].to(feat.dtype)
+            feat = feat + self.level_embeds[None, None, lvl:lvl + 1, :].to(feat.dtype)
+            shapes.append((h, w))
+            flat.append(feat)
+        flat = torch.cat(flat, 2).permute(0, 2, 1, 3)
+        spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=device)
+        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+        return flat, spatial_shapes, level_start_index
+
+
+@MODELS.register_module()
+class TPVFormerEncoder(_EncoderBase):
+    def __init__(self, mapping_args, embed_dims=128, num_cams=6, num_feature_levels=4, positional_encoding=None,
+                 num_points_cross=[64, 64, 8], num_points_self=[16, 16, 16], transformerlayers=None,
+                 num_layers=None, camera_aware=False, camera_aware_mid_channels=None, init_cfg=None):
+        super().__init__(init_cfg)
+        if camera_aware:
+            raise NotImplementedError("camera_aware=True (CameraAwareSE) is off in every shipped config")
+        self.embed_dims, self.num_feature_levels, self.num_cams = embed_dims, num_feature_levels, num_cams
+        self.camera_aware = camera_aware
+        self.mapping = GridMeterMapping(**mapping_args)
+        H, W, Z = self.mapping.size_h, self.mapping.size_w, self.mapping.size_d
+        ar = lambda n: torch.arange(n, dtype=torch.float)
+        hw_grid = torch.stack([ar(H)[:, None].expand(-1, W), ar(W)[None].expand(H, -1), torch.zeros(H, W)], -1)
+        zh_grid = torch.stack([ar(H)[None].expand(Z, -1), torch.zeros(Z, H), ar(Z)[:, None].expand(-1, H)], -1)
+        wz_grid = torch.stack([torch.zeros(W, Z), ar(W)[:, None].expand(-1, Z), ar(Z)[None].expand(W, -1)], -1)
+        g2m = self.mapping.grid2meter
+        positional_encoding = dict(positional_encoding)
+        positional_encoding['tpv_meters'] = [g2m(hw_grid)[..., [0, 1]], g2m(zh_grid)[..., [1, 2]], g2m(wz_grid)[..., [0, 2]]]
+        self.positional_encoding = build_positional_encoding(positional_encoding)
+        self.tpv_size = [H, W, Z]
+        self._build_layers(transformerlayers, num_layers)
+        self.num_points_cross, self.num_points_self = num_points_cross, num_points_self
+
+        # pillar reference points (metres) of the image cross-attention, one pillar per plane cell
+        Pz, Pw, Ph = num_points_cross[2], num_points_cross[1], num_points_cross[0]
+        hw3 = torch.cat([hw_grid[..., [0, 1]].unsqueeze(2).expand(-1, -1, Pz, -1),
+                         torch.linspace(0, Z - 1, Pz).reshape(1, 1, -1, 1).expand(H, W, -1, -1)], -1)
+        zh3 = torch.cat([zh_grid[..., :1].unsqueeze(2).expand(-1, -1, Pw, -1),
+                         torch.linspace(0, W - 1, Pw).reshape(1, 1, -1, 1).expand(Z, H, -1, -1),
+                         zh_grid[..., 2:].unsqueeze(2).expand(-1, -1, Pw, -1)], -1)
+        wz3 = torch.cat([torch.linspace(0, H - 1, Ph).reshape(1, 1, -1, 1).expand(W, Z, -1, -1),
+                         wz_grid[..., [1, 2]].unsqueeze(2).expand(-1, -1, Ph, -1)], -1)
+        for name, g in (('ref_3d_hw', hw3), ('ref_3d_zh', zh3), ('ref_3d_wz', wz3)):
+            self.register_buffer(name, g2m(g).flatten(0, 1).transpose(0, 1), False)
+        self.register_buffer('cross_view_ref_points', get_cross_view_ref_points(H, W, Z, num_points_self), False)
+
+    def forward_layers(self, tpv_query, key, value, tpv_pos=None, spatial_shapes=None, level_start_index=None,
+                       img_metas=None, **kwargs):
+        bs = tpv_query[0].shape[0]
+        reference_points_cams, tpv_masks = [], []
+        for ref_3d in (self.ref_3d_hw, self.ref_3d_zh, self.ref_3d_wz):
+            cam, mask = point_sampling(ref_3d.unsqueeze(0).repeat(bs, 1, 1, 1), img_metas)
+            reference_points_cams.append(cam)
+            tpv_masks.append(mask)
+        ref_cross_view = self.cross_view_ref_points.clone().unsqueeze(0).expand(bs, -1, -1, -1, -1)
+        for layer in self.layers:
+            tpv_query = layer(tpv_query, key, value, tpv_pos=tpv_pos, ref_2d=ref_cross_view,
+                              spatial_shapes=spatial_shapes, level_start_index=level_start_index,
+                              reference_points_cams=reference_points_cams, tpv_masks=tpv_masks,
+                              tpv_size=self.tpv_size, **kwargs)
+        return tpv_query
+
+    def forward(self, representation, ms_img_feats=None, metas=None, **kwargs):
+        bs = ms_img_feats[0].shape[0]
+        tpv_pos = [pos.unsqueeze(0).repeat(bs, 1, 1) for pos in self.positional_encoding()]
+        feat, spatial_shapes, level_start_index = self._flatten_feats(ms_img_feats)
+        tpv = self.forward_layers(representation, feat, feat, tpv_pos=tpv_pos, spatial_shapes=spatial_shapes,
+                                  level_start_index=level_start_index, img_metas=metas)
+        return {'representation': tpv}
+
+
+@MODELS.register_module()
+class BEVFormerEncoder(_EncoderBase):
+    def __init__(self, mapping_args, embed_dims=128, num_cams=6, num_feature_levels=4, positional_encoding=None,
+                 num_points_cross=32, num_points_self=16, transformerlayers=None, num_layers=None, init_cfg=None):
+        super().__init__(init_cfg)
+        self.embed_dims, self.num_feature_levels, self.num_cams = embed_dims, num_feature_levels, num_cams
+        self.mapping = GridMeterMapping(**mapping_args)
+        H, W, Z = self.mapping.size_h, self.mapping.size_w, self.mapping.size_d
+        ar = lambda n: torch.arange(n, dtype=torch.float)
+        bev_grid = torch.stack([ar(H)[:, None].expand(-1, W), ar(W)[None].expand(H, -1)], -1)
+        positional_encoding = dict(positional_encoding)
+        positional_encoding['bev_meter'] = self.mapping.grid2meter(bev_grid)
+        self.positional_encoding = build_positional_encoding(positional_encoding)
+        self.bev_size = [H, W]
+        self._build_layers(transformerlayers, num_layers)
+        self.num_points_cross, self.num_points_self = num_points_cross, num_points_self
+        g3 = torch.cat([bev_grid.unsqueeze(2).expand(-1, -1, num_points_cross, -1),
+                        torch.linspace(0, Z - 1, num_points_cross).reshape(1, 1, -1, 1).expand(H, W, -1, -1)], -1)
+        self.register_buffer('ref_3d', self.mapping.grid2meter(g3).flatten(0, 1).transpose(0, 1), False)
+        normed = bev_grid.clone()
+        normed[..., 0] = normed[..., 0] / (H - 1)
+        normed[..., 1] = normed[..., 1] / (W - 1)
+        self.register_buffer('ref_2d', normed, False)
+
+    def forward_layers(self, bev_query, key, value, bev_pos=None, spatial_shapes=None, level_start_index=None,
+                       img_metas=None, **kwargs):
+        bs = bev_query.shape[0]
+        cam, mask = point_sampling(self.ref_3d.unsqueeze(0).repeat(bs, 1, 1, 1), img_metas)
+        ref_2d = self.ref_2d.unsqueeze(0).repeat(bs, 1, 1, 1).reshape(bs, -1, 1, 2)
+        for layer in self.layers:
+            bev_query = layer(bev_query, key, value, bev_pos=bev_pos, ref_2d=ref_2d, spatial_shapes=spatial_shapes,
+                              level_start_index=level_start_index, reference_points_cams=cam, bev_masks=mask,
+                              bev_size=self.bev_size, **kwargs)
+        return bev_query
+
+    def forward(self, representation, ms_img_feats=None, metas=None, **kwargs):
+        bs = ms_img_feats[0].shape[0]
+        bev_pos = self.positional_encoding().unsqueeze(0).repeat(bs, 1, 1)
+        feat, spatial_shapes, level_start_index = self._flatten_feats(ms_img_feats)
+        bev = self.forward_layers(representation, feat, feat, bev_pos=bev_pos, spatial_shapes=spatial_shapes,
+                                  level_start_index=level_start_index, img_metas=metas)
+        return {'representation': bev}

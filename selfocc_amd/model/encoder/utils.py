@@ -1,0 +1,89 @@
+"""Geometry helpers of the lifter / encoder (host side, torch; computed once per forward).
+
+point_sampling          <- model/encoder/bevformer/utils.py:116-206
+get_cross_view_ref_points <- model/encoder/tpvformer/utils.py:5-71
+"""
+import numpy as np
+import torch
+
+
+def _stack_meta(img_metas, key, like):
+    vals = [m[key] for m in img_metas]
+    if isinstance(vals[0], (np.ndarray, list)):
+        return like.new_tensor(np.asarray(vals))
+    return torch.stack(vals, dim=0).to(like)
+
+
+@torch.autocast("cuda", enabled=False)
+def point_sampling(reference_points, img_metas):
+    """Project 3-D reference points (B, D, Q, 3) into every camera.
+    Returns reference_points_cam (N, B, Q, D, 2) in [0,1] image coordinates and the
+    visibility mask (N, B, Q, D).  Always float32 (bevformer/utils.py:114-117)."""
+    reference_points = reference_points.float()
+    lidar2img = _stack_meta(img_metas, 'lidar2img', reference_points).float()   # (B, N, 4, 4)
+    pts = torch.cat((reference_points, torch.ones_like(reference_points[..., :1])), -1)
+    pts = pts.permute(1, 0, 2, 3)                                               # (D, B, Q, 4)
+    D, B, Q = pts.shape[:3]
+    N = lidar2img.size(1)
+    cam = torch.matmul(lidar2img.view(1, B, N, 1, 4, 4), pts.view(D, B, 1, Q, 4, 1)).squeeze(-1)
+    eps = 1e-5
+    aug = img_metas[0].get('img_augmentation') if isinstance(img_metas[0], dict) else None
+    if aug is not None and 'post_rots' in aug and 'post_trans' in aug:
+        post_rots = reference_points.new_tensor(np.asarray([m['img_augmentation']['post_rots'].numpy() for m in img_metas]))
+        post_trans = reference_points.new_tensor(np.asarray([m['img_augmentation']['post_trans'].numpy() for m in img_metas]))
+        cam[..., :2] = cam[..., :2] / torch.maximum(cam[..., 2:3], torch.ones_like(cam[..., 2:3]) * eps)
+        cam = torch.matmul(post_rots.view(1, B, N, 1, 3, 3), cam[..., :3].unsqueeze(-1)).squeeze(-1)
+        cam = cam + post_trans.view(1, B, N, 1, 3)
+        mask = cam[..., 2:3] > eps
+        cam = cam[..., :2]
+    else:
+        mask = cam[..., 2:3] > eps
+        cam = cam[..., 0:2] / torch.maximum(cam[..., 2:3], torch.ones_like(cam[..., 2:3]) * eps)
+    cam[..., 0] /= img_metas[0]['img_shape'][1]
+    cam[..., 1] /= img_metas[0]['img_shape'][0]
+    mask = (mask & (cam[..., 1:2] > 0.0) & (cam[..., 1:2] < 1.0) & (cam[..., 0:1] < 1.0) & (cam[..., 0:1] > 0.0))
+    mask = torch.nan_to_num(mask)
+    cam = cam.permute(2, 1, 3, 0, 4)                      # (N, B, Q, D, 2)
+    mask = mask.permute(2, 1, 3, 0, 4).squeeze(-1)
+    if 'focal_ratios_x' in img_metas[0]:
+        sx = reference_points.new_tensor(np.asarray(img_metas[0]['focal_ratios_x'])).view(-1, 1, 1, 1, 1)
+        sy = reference_points.new_tensor(np.asarray(img_metas[0]['focal_ratios_y'])).view(-1, 1, 1, 1, 1)
+        cam[..., :1] = cam[..., :1] * sx
+        cam[..., 1:] = cam[..., 1:] * sy
+    return cam, mask
+
+
+def _axis(n, count=None, offset=0):
+    return torch.linspace(offset, n - 1 + offset, n if count is None else count) / n
+
+
+def get_cross_view_ref_points(tpv_h, tpv_w, tpv_z, num_points_in_pillar, offset=0):
+    """Reference points of the cross-view hybrid self-attention: for every query of the
+    three planes (hw, zh, wz) and every "level" (= plane) P points in that plane's
+    normalised (x = column, y = row) coordinates.  Returns (hw + zh + wz, 3, P, 2)."""
+    H, W, Z = tpv_h, tpv_w, tpv_z
+    P_hw, P_zh, P_wz = num_points_in_pillar[2], num_points_in_pillar[1], num_points_in_pillar[0]
+    h, w, z = _axis(H, offset=offset), _axis(W, offset=offset), _axis(Z, offset=offset)
+
+    def grid(rows, cols, P):
+        return rows.numel(), cols.numel(), P
+
+    # ---- queries on the hw plane (row = h, col = w); pillar runs along z ----
+    hh = h.view(H, 1, 1).expand(H, W, P_hw)
+    ww = w.view(1, W, 1).expand(H, W, P_hw)
+    zz = _axis(Z, P_hw, offset).view(1, 1, P_hw).expand(H, W, P_hw)
+    hw_hw = torch.stack([ww, hh], -1)          # plane hw: (x, y) = (w, h)
+    hw_zh = torch.stack([hh, zz], -1)          # plane zh: (x, y) = (h, z)
+    hw_wz = torch.stack([zz, ww], -1)          # plane wz: (x, y) = (z, w)
+    q_hw = torch.stack([hw_hw, hw_zh, hw_wz], 2).flatten(0, 1)
+    # ---- queries on the zh plane (row = z, col = h); pillar runs along w ----
+    zz = z.view(Z, 1, 1).expand(Z, H, P_zh)
+    hh = h.view(1, H, 1).expand(Z, H, P_zh)
+    ww = _axis(W, P_zh, offset).view(1, 1, P_zh).expand(Z, H, P_zh)
+    q_zh = torch.stack([torch.stack([ww, hh], -1), torch.stack([hh, zz], -1), torch.stack([zz, ww], -1)], 2).flatten(0, 1)
+    # ---- queries on the wz plane (row = w, col = z); pillar runs along h ----
+    ww = w.view(W, 1, 1).expand(W, Z, P_wz)
+    zz = z.view(1, Z, 1).expand(W, Z, P_wz)
+    hh = _axis(H, P_wz, offset).view(1, 1, P_wz).expand(W, Z, P_wz)
+    q_wz = torch.stack([torch.stack([ww, hh], -1), torch.stack([hh, zz], -1), torch.stack([zz, ww], -1)], 2).flatten(0, 1)
+    return torch.cat([q_hw, q_zh, q_wz], 0)

@@ -1,0 +1,399 @@
+"""NeuSHead — the SDF volume-rendering head behind the reference's registry name and dict
+protocol (model/head/neus_head/neus_head.py:22-720).
+
+The reference drives an un-pinned sdfstudio fork (``NeuSCustomModel`` / ``SDFCustomField``,
+absent from the tree) through ~40 torch ops and a chunked ray loop.  Here the same contract
+is served by three native entry points:
+    selfocc_render_fwd / selfocc_render_bwd  (csrc/render_fwd.hip, render_bwd.hip)
+    selfocc_field_query                      (csrc/occ.hip)
+Ray generation (RaySampler + Img2LiDAR, model/head/nerfacc_head/ray_sampler.py:5-68,
+img2lidar.py:6-70) is folded into the render kernel for lattice ray modes.
+
+Restated-from-upstream semantics (the fork is unavailable; DESIGN.md §7 lists them as
+declared deviation risks): field evaluated at frustum START positions, single jitter per
+ray in training, ``inv_s = exp(10 * variance)``, eik_grad = metre gradient at every sample,
+second_grad = compact second differences of the SDF volume.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from ... import abi
+from ...mapping import GridMeterMapping
+from ...occ import field_query, uniform_lattice
+from ...registry import HEADS
+from ...render import SDFVolume, RaySet, RenderConfig, render_rays, render_rays_autograd
+from ..bricks import BaseModule
+
+
+def get_rm(angle, axis, deg=False):
+    """Rotation matrix about a coordinate axis (dataset/utils.get_rm, used for novel views)."""
+    if deg:
+        angle = np.deg2rad(angle)
+    c, s = np.cos(angle), np.sin(angle)
+    rm = np.eye(3)
+    i, j = {'x': (1, 2), 'y': (2, 0), 'z': (0, 1)}[axis]
+    rm[i, i], rm[i, j], rm[j, i], rm[j, j] = c, -s, s, c
+    return rm
+
+
+class RaySampler(nn.Module):
+    """Pixel lattice of the rays: 'fixed' (arange * stride), 'cellular' (random stride + offset,
+    4 np.random.uniform() draws in the reference's order) or 'random'."""
+
+    def __init__(self, ray_sample_mode='fixed', ray_number=[192, 400], ray_img_size=[768, 1600],
+                 ray_upper_crop=0, ray_x_dsr_max=None, ray_y_dsr_max=None):
+        super().__init__()
+        assert ray_sample_mode in ['fixed', 'cellular', 'random']
+        self.ray_sample_mode = ray_sample_mode
+        self.ray_number = ray_number[0] * ray_number[1]
+        self.ray_resize, self.ray_img_size = ray_number, ray_img_size
+        self.ray_upper_crop = ray_upper_crop
+        self.ray_x_dsr_max = 1.0 * ray_img_size[1] / ray_number[1] if ray_x_dsr_max is None else ray_x_dsr_max
+        self.ray_y_dsr_max = 1.0 * (ray_img_size[0] - ray_upper_crop) / ray_number[0] if ray_y_dsr_max is None else ray_y_dsr_max
+        if ray_sample_mode == 'cellular':
+            assert self.ray_x_dsr_max > 1 and self.ray_y_dsr_max > 1
+        self.register_buffer('_dev', torch.zeros(1), False)
+
+    def lattice(self):
+        """(sx, sy, ox, oy): pixel (u, v) = (ix * sx + ox, iy * sy + oy); None for 'random'."""
+        ny, nx = self.ray_resize
+        if self.ray_sample_mode == 'fixed':
+            return 1.0 * self.ray_img_size[1] / nx, 1.0 * self.ray_img_size[0] / ny, 0.0, 0.0
+        if self.ray_sample_mode == 'cellular':
+            sx = np.random.uniform() * (self.ray_x_dsr_max - 1) + 1
+            sy = np.random.uniform() * (self.ray_y_dsr_max - 1) + 1
+            ox = np.random.uniform() * (self.ray_img_size[1] - nx * sx)
+            oy = np.random.uniform() * (self.ray_img_size[0] - self.ray_upper_crop - ny * sy)
+            return sx, sy, ox, oy + self.ray_upper_crop
+        return None
+
+    @staticmethod
+    def pixels(ny, nx, sx, sy, ox, oy, device):
+        xs = torch.arange(nx, dtype=torch.float, device=device) * sx + ox
+        ys = torch.arange(ny, dtype=torch.float, device=device) * sy + oy
+        return torch.stack([xs[None].expand(ny, -1), ys[:, None].expand(-1, nx)], -1).flatten(0, 1)
+
+    def forward(self):
+        lat = self.lattice()
+        if lat is None:
+            rays = torch.rand(self.ray_number, 2, device=self._dev.device)
+            rays[:, 0] *= self.ray_img_size[1]
+            rays[:, 1] *= self.ray_img_size[0]
+            return rays
+        return self.pixels(*self.ray_resize, *lat, self._dev.device)
+
+
+class Img2LiDAR(nn.Module):
+    """(B, N, 4, 4) pixel*depth -> world matrices from the metas (img2lidar.py:25-57)."""
+
+    def __init__(self, trans_kw, trans_kw_eval=None, novel_view=None):
+        super().__init__()
+        if not isinstance(trans_kw, list):
+            trans_kw, self.two_split = [trans_kw], False
+        else:
+            assert trans_kw == ['img2lidar', 'temImg2lidar']
+            self.two_split = True
+        self.trans_kw = trans_kw
+        self.trans_kw_eval = trans_kw if trans_kw_eval is None else trans_kw_eval
+        if not isinstance(self.trans_kw_eval, list):
+            self.trans_kw_eval = [self.trans_kw_eval]
+        self.novel_view = novel_view
+
+    def matrices(self, metas, device):
+        keys = self.trans_kw_eval if os.environ.get('eval', 'false') == 'true' else self.trans_kw
+        mats = []
+        for meta in metas:
+            temp = []
+            for key in keys:
+                temp.extend(meta[key])
+            if isinstance(temp[0], (np.ndarray, list)):
+                mats.append(torch.as_tensor(np.asarray(temp), dtype=torch.float32))
+            else:
+                mats.append(torch.stack(temp, dim=0).float().cpu())
+        M = torch.stack(mats, 0).to(device)                       # B, N, 4, 4
+        if self.novel_view is not None:
+            rot = M.new_tensor(get_rm(self.novel_view[3], 'z', True))
+            M = M.clone()
+            M[..., :3, :3] = rot[None, None] @ M[..., :3, :3]
+            M[..., 0, 3] += self.novel_view[0]
+            M[..., 1, 3] += self.novel_view[1]
+            M[..., 2, 3] += self.novel_view[2]
+        return M
+
+    def forward(self, metas, rays):
+        M = self.matrices(metas, rays.device)
+        pad = torch.cat([rays.float(), torch.ones_like(rays[..., :1])], -1).reshape(1, 1, -1, 3)
+        direction = torch.matmul(M[..., :3, :3].unsqueeze(2), pad.unsqueeze(-1)).squeeze(-1)
+        return M[..., :3, 3], direction
+
+
+class SDFField(BaseModule):
+    """Tri-plane / BEV -> dense SDF + colour + semantic volume, written directly in the
+    layout the kernels read.  In-repo analogue: BEVNeRF (nerfacc_head/bev_nerf.py:8-95):
+    [Softplus, Linear(C, C)] x (density_layers - 1) + [Softplus, Linear(C, 1 + color_dims)]."""
+
+    def __init__(self, mapping_args, embed_dims=128, color_dims=0, density_layers=2, sh_deg=2, sh_act='relu',
+                 tpv=False, beta_init=0.1, beta_learnable=True, return_sem=False, feat_dtype=torch.float32):
+        super().__init__()
+        self.mapping = GridMeterMapping(**mapping_args)
+        self.embed_dims, self.color_dims, self.tpv = embed_dims, color_dims, tpv
+        self.size_h, self.size_w, self.size_d = self.mapping.size_h, self.mapping.size_w, self.mapping.size_d
+        if color_dims > 0 and (sh_deg != 0 or sh_act != 'relu'):
+            raise NotImplementedError("the render kernel implements SH degree 0 with relu (every shipped config)")
+        self.n_rgb = 3 if color_dims >= 3 else 0
+        self.n_sem = color_dims - self.n_rgb if color_dims > 3 else 0
+        out = 1 + color_dims
+        layers = []
+        for _ in range(density_layers - 1):
+            layers += [nn.Softplus(), nn.Linear(embed_dims, embed_dims)]
+        layers += [nn.Softplus(), nn.Linear(embed_dims, out if tpv else out * self.size_d)]
+        self.density_net = nn.Sequential(*layers)
+        self.variance = nn.Parameter(beta_init * torch.ones(1), requires_grad=beta_learnable)
+        self.feat_dtype = feat_dtype
+        self.volume = None
+
+    def inv_s(self):
+        return torch.exp(self.variance * 10.0).clip(1e-6, 1e6)
+
+    def pre_compute_density_color(self, representation):
+        H, W, D, C = self.size_h, self.size_w, self.size_d, self.embed_dims
+        with torch.autocast("cuda", enabled=False):
+            if self.tpv:
+                hw, zh, wz = (t.float() for t in representation)
+                assert hw.shape[0] == 1, 'only support bs = 1 currently'
+                feat = hw.reshape(H, W, 1, C) + zh.reshape(D, H, 1, C).permute(1, 2, 0, 3) + \
+                    wz.reshape(W, D, 1, C).permute(2, 0, 1, 3)                       # H, W, D, C
+                out = self.density_net(feat)                                         # H, W, D, 1 + color
+            else:
+                bev = representation.float()
+                assert bev.shape[0] == 1, 'only support bs = 1 currently'
+                out = self.density_net(bev.reshape(H, W, C)).reshape(H, W, D, -1)
+            sdf = out[..., 0].contiguous()
+            feat_vol = None
+            if self.color_dims > 0:
+                F = SDFVolume.feat_width(self.n_rgb, self.n_sem)
+                if F == out.shape[-1] - 1:
+                    feat_vol = out[..., 1:].contiguous()
+                else:
+                    feat_vol = torch.cat([out[..., 1:], out.new_zeros(H, W, D, F - (out.shape[-1] - 1))], -1).contiguous()
+                if self.feat_dtype != torch.float32:
+                    feat_vol = feat_vol.to(self.feat_dtype)
+        self.volume = SDFVolume(self.mapping, sdf, feat_vol, self.n_rgb, self.n_sem)
+        return self.volume
+
+    def forward_geonetwork(self, xyz):
+        """(n, 3) metres -> (n, 1 + color_dims): [sdf, raw rgb, semantic logits] (neus_head.py:284-288)."""
+        v = self.volume
+        vol = SDFVolume(v.mapping, v.sdf.detach(), None if v.feat is None else v.feat.detach(), v.n_rgb, v.n_sem)
+        q = field_query(vol, xyz.reshape(-1, 3), want_sdf=True, want_logits=v.n_sem > 0)
+        cols = [q['sdf'][:, None]]
+        if v.n_rgb:
+            cols.append(torch.zeros(q['sdf'].shape[0], 3, device=xyz.device))  # raw rgb is not consumed by any caller
+        if v.n_sem:
+            cols.append(q['logits'])
+        return torch.cat(cols, -1)
+
+    def forward_sdfnetwork(self, xyz):
+        v = self.volume
+        return field_query(SDFVolume(v.mapping, v.sdf.detach(), None, 0, 0), xyz.reshape(-1, 3))['sdf']
+
+    def second_grad(self):
+        """Compact second differences of the SDF volume along h, w, d (declared restatement)."""
+        s = self.volume.sdf
+        return torch.cat([(s[2:] - 2 * s[1:-1] + s[:-2]).flatten(), (s[:, 2:] - 2 * s[:, 1:-1] + s[:, :-2]).flatten(),
+                          (s[:, :, 2:] - 2 * s[:, :, 1:-1] + s[:, :, :-2]).flatten()])
+
+
+class _NeuSModel(nn.Module):
+    """Namespace so that parameters live under ``head.model.field.*`` like the reference's."""
+
+    def __init__(self, field):
+        super().__init__()
+        self.field = field
+
+
+@HEADS.register_module()
+class NeuSHead(BaseModule):
+
+    def __init__(self, roi_aabb, resolution=0.4, near_plane=0.0, far_plane=1e10, num_samples=64,
+                 num_samples_importance=64, num_up_sample_steps=4, base_variance=64, beta_init=0.1,
+                 beta_max=0.195, total_iters=3516 * 11, use_numerical_gradients=True,
+                 numerical_gradients_delta=0.01, use_uniform_gradient=False, nbr_gradient_points=128 * 128 * 16,
+                 calculate_online=False, sample_gradient=False, use_compact_2nd_grad=False, beta_hand_tune=False,
+                 return_uniform_sdf=False, estimate_flow=False, return_max_depth=False, return_surface_sdf=False,
+                 return_second_grad=False, return_sample_sdf=False, return_sem=False, disp_sampler=False,
+                 anneal_aabb=False, aabb_every_iters=3516, aabb_min_near=10., aabb_min_far_frac=0.25,
+                 ray_sample_mode='fixed', ray_number=[192, 400], ray_img_size=[768, 1600], ray_upper_crop=0,
+                 ray_x_dsr_max=None, ray_y_dsr_max=None, trans_kw='img2lidar', trans_kw_eval=None, novel_view=None,
+                 render_bkgd='white',
+                 mapping_args=dict(nonlinear_mode="linear_upscale", h_size=[128, 32], h_range=[51.2, 28.8],
+                                   h_half=False, w_size=[128, 32], w_range=[51.2, 28.8], w_half=False,
+                                   d_size=[20, 10], d_range=[-4.0, 4.0, 12.0]),
+                 embed_dims=128, color_dims=0, density_layers=2, sh_deg=2, sh_act="relu", init_cfg=None,
+                 print_freq=50, two_split=True, tpv=False, using_2d_img_feats=False,
+                 sample_pos='start', single_jitter=True, feat_dtype=torch.float32, exact_render=False, **kwargs):
+        super().__init__(init_cfg)
+        for name, on in dict(num_samples_importance=num_samples_importance > 0, num_up_sample_steps=num_up_sample_steps > 0,
+                             use_numerical_gradients=use_numerical_gradients, estimate_flow=estimate_flow,
+                             anneal_aabb=anneal_aabb, disp_sampler=disp_sampler, using_2d_img_feats=using_2d_img_feats,
+                             beta_hand_tune=beta_hand_tune, return_surface_sdf=return_surface_sdf).items():
+            if on:
+                raise NotImplementedError(f"NeuSHead({name}=...) is off in every shipped SelfOcc config and not built")
+        self.ray_sampler = RaySampler(ray_sample_mode, ray_number, ray_img_size, ray_upper_crop, ray_x_dsr_max, ray_y_dsr_max)
+        self.ray_sampler_eval = RaySampler('fixed', ray_number, ray_img_size, ray_upper_crop)
+        self.img2lidar = Img2LiDAR(trans_kw, trans_kw_eval, novel_view)
+        field = SDFField(mapping_args, embed_dims, color_dims, density_layers, sh_deg, sh_act, tpv, beta_init,
+                         not beta_hand_tune, return_sem, feat_dtype)
+        self.model = _NeuSModel(field)
+        self.num_samples, self.near_plane = num_samples, near_plane
+        self.render_bkgd = render_bkgd
+        self.print_freq, self.resolution, self.aabb = print_freq, resolution, roi_aabb
+        self.return_uniform_sdf, self.return_max_depth = return_uniform_sdf, return_max_depth
+        self.return_second_grad, self.return_sample_sdf, self.return_sem = return_second_grad, return_sample_sdf, return_sem
+        self.z_size = field.size_d
+        self.bev_size = [field.size_h, field.size_w]
+        self.two_split = two_split
+        self.sample_pos = abi.SAMPLE_AT_START if sample_pos == 'start' else abi.SAMPLE_AT_MID
+        self.single_jitter = single_jitter
+        self.exact_render = exact_render
+        self.last_inv_s = None
+
+    # ---- helpers -----------------------------------------------------------------------
+    def _render_cfg(self, training):
+        bk = {'white': (abi.BKGD_CONST, (1., 1., 1.)), 'black': (abi.BKGD_CONST, (0., 0., 0.)),
+              'random': (abi.BKGD_PER_RAY, (0., 0., 0.)), None: (abi.BKGD_NONE, (0., 0., 0.))}[self.render_bkgd]
+        jit = abi.JITTER_NONE if not training else (abi.JITTER_SINGLE if self.single_jitter else abi.JITTER_PER_BIN)
+        return RenderConfig(aabb=tuple(self.aabb), n_samples=self.num_samples, near_plane=self.near_plane if training else 0.0,
+                            sample_pos=self.sample_pos, jitter_mode=jit, bkgd_mode=bk[0], bkgd=bk[1],
+                            depth_div_norm=True, clamp_rgb=not training, exact=self.exact_render)
+
+    def _rays(self, metas, device):
+        sampler = self.ray_sampler_eval if os.environ.get('eval', 'false') == 'true' else self.ray_sampler
+        M = self.img2lidar.matrices(metas, device)
+        bs, num_cams = M.shape[:2]
+        assert bs == 1, 'only support bs = 1 currently'
+        lat = sampler.lattice()
+        ny, nx = sampler.ray_resize
+        if lat is not None:
+            pix = sampler.pixels(ny, nx, *lat, device)
+            rs = RaySet(img2lidar=M[0].contiguous(), nx=nx, ny=ny, sx=float(np.float32(lat[0])), sy=float(np.float32(lat[1])),
+                        ox=float(np.float32(lat[2])), oy=float(np.float32(lat[3])))
+        else:
+            pix = sampler().to(device)
+            origin, direction = self.img2lidar(metas, pix)
+            direction = direction.flatten(0, 2)
+            dn = torch.norm(direction, dim=-1)
+            rs = RaySet(origins=origin.unsqueeze(2).repeat(1, 1, pix.shape[0], 1).flatten(0, 2).contiguous(),
+                        dirs=(direction / dn[:, None]).contiguous(), dir_norm=dn.contiguous())
+        return rs, pix, num_cams, pix.shape[0]
+
+    # ---- reference API -----------------------------------------------------------------
+    def prepare(self, representation, metas=None, **kwargs):
+        self.model.field.pre_compute_density_color(representation)
+        return {}
+
+    def get_uniform_sdf(self, aabb, resolution, device, shift=False):
+        xyz = uniform_lattice(aabb, resolution, device, shift)
+        H, W, D = xyz.shape[:3]
+        if self.return_sem:
+            h = self.model.field.forward_geonetwork(xyz.reshape(-1, 3))
+            sem_logits = h[..., 4:].reshape(H, W, D, -1)
+            return h[..., 0].reshape(H, W, D), torch.argmax(sem_logits, dim=-1), sem_logits, xyz
+        return self.model.field.forward_sdfnetwork(xyz.reshape(-1, 3)).reshape(H, W, D), xyz
+
+    def forward_occ(self, representation, metas=None, **kwargs):
+        device = representation[0].device if isinstance(representation, (tuple, list)) else representation.device
+        self.model.field.pre_compute_density_color(representation)
+        aabb = kwargs.get('aabb', self.aabb)
+        reso = kwargs.get('resolution', self.resolution)
+        if self.return_sem:
+            sdf, sem, sem_logits, xyz = self.get_uniform_sdf(aabb, reso, device)
+            return {'sdf': sdf, 'rep': representation, 'sem': sem, 'logits': sem_logits, 'xyz': xyz}
+        sdf, xyz = self.get_uniform_sdf(aabb, reso, device)
+        return {'sdf': sdf, 'rep': representation, 'xyz': xyz}
+
+    @torch.no_grad()
+    def render(self, metas=None, batch=0, **kwargs):
+        """Full-lattice render in ONE launch: ``batch`` (the reference's memory-driven chunk size,
+        neus_head.py:329-385) is accepted and ignored — no per-sample tensor is materialised."""
+        vol = self.model.field.volume
+        assert vol is not None, "call prepare() (or forward) before render()"
+        device = vol.sdf.device
+        rays, pix, num_cams, num_rays = self._rays(metas, device)
+        cfg = self._render_cfg(False)
+        cfg.inv_s = float(self.model.field.inv_s())
+        vol = SDFVolume(vol.mapping, vol.sdf.detach(), None if vol.feat is None else vol.feat.detach(), vol.n_rgb, vol.n_sem)
+        bk = torch.rand(rays.n_rays, 3, device=device) if cfg.bkgd_mode == abi.BKGD_PER_RAY else None
+        out = render_rays(vol, rays, cfg, bkgd_rays=bk)
+        shp = (1, num_cams, num_rays)
+        rgb = out['rgb'].reshape(*shp, 3) if 'rgb' in out else torch.empty(*shp, 0, device=device)
+        outputs = {'ms_depths': [out['depth'].reshape(shp)], 'ms_colors': [rgb],
+                   'vis_normal': [torch.zeros(*shp, 3, device=device)], 'ms_accs': [out['acc'].reshape(shp)],
+                   'ms_rays': pix}
+        if self.return_max_depth:
+            outputs['ms_max_depths'] = [out['max_depth'].reshape(shp)]
+        if self.return_sem and 'sem' in out:
+            outputs['sem'] = [out['sem'].reshape(*shp, -1)]
+        return outputs
+
+    def forward(self, representation, metas=None, **kwargs):
+        field = self.model.field
+        vol = field.pre_compute_density_color(representation)
+        device = vol.sdf.device
+        global_iter = kwargs.get('global_iter', None)
+        rays, pix, num_cams, num_rays = self._rays(metas, device)
+        cfg = self._render_cfg(self.training)
+        N, S = rays.n_rays, self.num_samples
+        t_rand = None
+        if cfg.jitter_mode != abi.JITTER_NONE:
+            t_rand = torch.rand((N,) if cfg.jitter_mode == abi.JITTER_SINGLE else (N, S + 1), device=device)
+        bk = torch.rand(N, 3, device=device) if cfg.bkgd_mode == abi.BKGD_PER_RAY else None
+        inv_s = field.inv_s()
+        out = render_rays_autograd(vol, inv_s, rays, cfg, want_grad_samples=True, t_rand=t_rand, bkgd_rays=bk)
+        self.last_inv_s = float(inv_s.detach())
+
+        shp = (1, num_cams, num_rays)
+        depth, acc, fars = out['depth'].reshape(shp), out['acc'].reshape(shp), out['fars'].reshape(shp)
+        rgb = out['rgb'].reshape(*shp, 3) if 'rgb' in out else depth.new_empty(*shp, 0)
+        weights, ts, deltas = out['weights'], out['ts'], out['deltas']       # (N, S)
+        per_cam = lambda t: [c.reshape(-1) for c in t.reshape(num_cams, -1).chunk(num_cams, 0)]
+        ray_idx = [torch.arange(num_rays, device=device).unsqueeze(-1).repeat(1, S).flatten()] * num_cams
+        if rays.pixel_grid:
+            origin, direction = self.img2lidar(metas, pix)
+            direction = direction.flatten(0, 2)
+            direction_norm = torch.norm(direction, dim=-1, keepdim=True)
+            direction = direction / direction_norm
+            origin = origin.unsqueeze(2).repeat(1, 1, num_rays, 1).flatten(0, 2)
+        else:
+            origin, direction, direction_norm = rays.origins, rays.dirs, rays.dir_norm[:, None]
+        outputs = {'ms_depths': [depth], 'ms_colors': [rgb], 'ms_accs': [acc], 'ms_fars': [fars], 'ms_rays': pix,
+                   'origin': origin, 'direction': direction, 'direction_norm': direction_norm,
+                   'ray_indices': ray_idx, 'weights': per_cam(weights), 'ts': per_cam(ts), 'deltas': per_cam(deltas),
+                   'eik_grad': out['grad'].reshape(-1, 3), 'uniform_sdf': None}
+        if self.return_uniform_sdf:
+            outputs['uniform_sdf'] = self.get_uniform_sdf(self.aabb, self.resolution, device, True)[0]
+        if self.return_max_depth:
+            outputs['ms_max_depths'] = [out['max_depth'].reshape(shp)]
+        if self.return_second_grad:
+            outputs['second_grad'] = field.second_grad()
+        if self.return_sample_sdf:
+            outputs['sample_sdf'] = per_cam(out['sdf'])
+        if self.return_sem and 'sem' in out:
+            outputs['sem'] = [out['sem'].reshape(*shp, -1)]
+        if self.two_split and self.img2lidar.two_split:
+            h = num_cams // 2
+            for k in ('ms_depths', 'ms_accs', 'ms_fars', 'ms_max_depths'):
+                if k in outputs:
+                    outputs[k] = [outputs[k][0][:, :h]]
+            outputs['ms_colors'] = [rgb[:, h:]]
+            for k in ('ray_indices', 'weights', 'ts', 'deltas', 'sample_sdf'):
+                if k in outputs:
+                    outputs[k] = outputs[k][:h]
+            if 'sem' in outputs:
+                outputs['sem'] = [outputs['sem'][0][:, h:]]
+        return outputs

@@ -1,0 +1,388 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.npz by running the REAL reference code (/root/reference, read
+only) on seeded inputs, on CPU.
+
+The reference cannot be imported as a package here (mmengine / mmcv / mmseg / nerfstudio are
+absent), so this script
+  * installs tiny stand-ins for the third-party symbols the reference files import
+    (registries, BaseModule, init helpers, FFN / LayerNorm builders, MMLogger) — vendor
+    plumbing, none of it hot-path arithmetic;
+  * provides the one absent hot-path dependency, mmcv's ``multi_scale_deformable_attn_pytorch``
+    (the function the reference itself calls on CPU, image_cross_attention.py:344), from
+    oracle/torch_port.py;
+  * exposes the reference's directories as namespace packages WITHOUT executing their
+    ``__init__.py`` (which would pull in mmseg backbones), then imports single files.
+Nothing from /root/reference is copied: only numeric inputs / outputs / state dicts are saved.
+The sdfstudio-fork renderer (NeuSCustomModel) is absent from the reference tree, so no golden
+vector exists for it ("parity unpinned", see oracle/oracle_render.c).
+
+Run:  python tests/golden/make_golden.py        (needs /root/reference; ~10 s)
+"""
+import importlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = os.environ.get("SELFOCC_REFERENCE", "/root/reference")
+sys.path.insert(0, ROOT)
+
+
+# --------------------------------------------------------------------------------------------
+# third-party stand-ins
+# --------------------------------------------------------------------------------------------
+class _Registry:
+    def __init__(self, name='ref'):
+        self.name, self._d = name, {}
+
+    def register_module(self, name=None, force=False, module=None):
+        def reg(cls):
+            self._d[name or cls.__name__] = cls
+            return cls
+        return reg(module) if module is not None else reg
+
+    def build(self, cfg, **kw):
+        cfg = dict(cfg)
+        return self._d[cfg.pop('type')](**cfg, **kw)
+
+
+class _BaseModule(nn.Module):
+    def __init__(self, init_cfg=None):
+        super().__init__()
+        self.init_cfg = init_cfg
+
+    def init_weights(self):  # mmengine.model.BaseModule: recurse into children that define init_weights
+        for m in self.children():
+            if hasattr(m, 'init_weights'):
+                m.init_weights()
+
+
+def _xavier_init(m, gain=1, bias=0, distribution='normal'):
+    (nn.init.xavier_uniform_ if distribution == 'uniform' else nn.init.xavier_normal_)(m.weight, gain=gain)
+    if m.bias is not None:
+        nn.init.constant_(m.bias, bias)
+
+
+def _constant_init(m, val, bias=0):
+    nn.init.constant_(m.weight, val)
+    if m.bias is not None:
+        nn.init.constant_(m.bias, bias)
+
+
+class _Logger:
+    _instance_dict = {}
+
+    @classmethod
+    def get_instance(cls, name, **kw):
+        return cls()
+
+    def info(self, *a, **k):
+        pass
+
+
+def _mod(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def install_stubs():
+    from oracle.torch_port import msda_port
+    from selfocc_amd.model import bricks          # vendor-equivalent FFN / LN (mmcv bricks are absent)
+    REG = _Registry('reference_models')
+    LOSS_REG = _Registry('reference_losses')
+    REG.register_module(module=bricks.FFN)
+
+    class MSDABase(_BaseModule):
+        """parameter layout of mmcv MultiScaleDeformableAttention (forward is overridden by the
+        reference's CrossViewHybridAttention)."""
+        def __init__(self, embed_dims=256, num_heads=8, num_levels=4, num_points=4, im2col_step=64, dropout=0.1,
+                     batch_first=False, norm_cfg=None, init_cfg=None, value_proj_ratio=1.0):
+            super().__init__(init_cfg)
+            self.batch_first, self.im2col_step, self.embed_dims = batch_first, im2col_step, embed_dims
+            self.num_levels, self.num_heads, self.num_points = num_levels, num_heads, num_points
+            self.dropout = nn.Dropout(dropout)
+            self.sampling_offsets = nn.Linear(embed_dims, num_heads * num_levels * num_points * 2)
+            self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
+            self.value_proj = nn.Linear(embed_dims, int(embed_dims * value_proj_ratio))
+            self.output_proj = nn.Linear(int(embed_dims * value_proj_ratio), embed_dims)
+
+        def init_weights(self):
+            pass
+
+    def deprecated_api_warning(*a, **k):
+        return lambda f: f
+
+    build = lambda cfg, *a, **k: REG.build(cfg)
+    _mod('mmengine', ConfigDict=dict)
+    _mod('mmengine.model', BaseModule=_BaseModule, ModuleList=nn.ModuleList, xavier_init=_xavier_init,
+         constant_init=_constant_init)
+    _mod('mmengine.registry', MODELS=REG, Registry=lambda *a, **k: LOSS_REG)
+    _mod('mmengine.logging', MMLogger=_Logger)
+    _mod('mmengine.utils', deprecated_api_warning=deprecated_api_warning)
+    _mod('mmcv')
+    _mod('mmcv.cnn', build_norm_layer=lambda cfg, n: ('ln', nn.LayerNorm(n)))
+    _mod('mmcv.cnn.bricks')
+    _mod('mmcv.cnn.bricks.transformer', build_attention=build, build_feedforward_network=build,
+         build_positional_encoding=build, build_transformer_layer=build)
+    _mod('mmcv.ops')
+    _mod('mmcv.ops.multi_scale_deform_attn', MultiScaleDeformableAttention=MSDABase,
+         MultiScaleDeformableAttnFunction=None, multi_scale_deformable_attn_pytorch=msda_port)
+    _mod('mmcv.utils', IS_CUDA_AVAILABLE=False, IS_MLU_AVAILABLE=False)
+    _mod('mmseg')
+    _mod('mmseg.registry', MODELS=REG)
+    _mod('mmseg.models', HEADS=REG)
+    tb = _mod('utils.tb_wrapper', WrappedTBWriter=_Logger)
+    pkg = types.ModuleType('utils'); pkg.__path__ = []; pkg.tb_wrapper = tb
+    sys.modules['utils'] = pkg
+    return REG, LOSS_REG
+
+
+def namespace(pkg):
+    """Expose a reference directory as a package without running its __init__.py."""
+    m = types.ModuleType(pkg)
+    m.__path__ = [os.path.join(REF, *pkg.split('.'))]
+    m.__package__ = pkg
+    sys.modules[pkg] = m
+    return m
+
+
+def ref_import(name):
+    return importlib.import_module(name)
+
+
+def to_np(sd):
+    return {k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **arrs)
+    print(f"wrote {path}: {os.path.getsize(path) / 1024:.1f} KiB, keys={len(arrs)}")
+
+
+# --------------------------------------------------------------------------------------------
+def golden_geometry():
+    mp = ref_import('model.encoder.bevformer.mappings')
+    out = {}
+    g = torch.Generator().manual_seed(0)
+    cfgs = {
+        'occ': dict(nonlinear_mode='linear', h_size=[128, 0], h_range=[40.0, 0], h_half=False, w_size=[128, 0],
+                    w_range=[40.0, 0], w_half=False, d_size=[24, 0], d_range=[-1.0, 5.4, 5.4]),
+        'kitti': dict(nonlinear_mode='linear', h_size=[256, 0], h_range=[51.2, 0], h_half=True, w_size=[128, 0],
+                      w_range=[25.6, 0], w_half=False, d_size=[32, 0], d_range=[-2.0, 4.4, 4.4]),
+        'twoseg': dict(nonlinear_mode='linear', h_size=[128, 32], h_range=[51.2, 28.8], h_half=False,
+                       w_size=[128, 32], w_range=[51.2, 28.8], w_half=False, d_size=[20, 10], d_range=[-4.0, 4.0, 12.0]),
+        'upscale': dict(nonlinear_mode='linear_upscale', h_size=[128, 32], h_range=[51.2, 28.8], h_half=False,
+                        w_size=[128, 32], w_range=[51.2, 28.8], w_half=False, d_size=[20, 10], d_range=[-4.0, 4.0, 12.0]),
+    }
+    for name, kw in cfgs.items():
+        m = mp.GridMeterMapping(**kw)
+        lo = torch.tensor([-75.0, -75.0, -3.5]) if name != 'kitti' else torch.tensor([-25.0, 0.5, -1.9])
+        hi = torch.tensor([75.0, 75.0, 11.0]) if name != 'kitti' else torch.tensor([25.0, 51.0, 4.3])
+        xyz = lo + (hi - lo) * torch.rand(400, 3, generator=g)
+        grid = torch.rand(400, 3, generator=g) * torch.tensor([m.size_h - 1.0, m.size_w - 1.0, m.size_d - 1.0])
+        out[f'{name}.xyz'] = xyz.numpy(); out[f'{name}.grid'] = grid.numpy()
+        out[f'{name}.m2g'] = m.meter2grid(xyz.clone()).numpy()
+        out[f'{name}.m2g_norm'] = m.meter2grid(xyz.clone(), True).numpy()
+        out[f'{name}.g2m'] = m.grid2meter(grid.clone()).numpy()
+        out[f'{name}.sizes'] = np.array([m.size_h, m.size_w, m.size_d])
+    # the reference's only in-tree KAT (mappings.py:312-318): grid -> metre -> grid round trip
+    m = mp.GridMeterMapping(**cfgs['twoseg'])
+    kat = torch.tensor([[0, 0, 0], [128, 128, 10], [160, 160, 20], [192, 192, 25], [320, 320, 30], [64, 256, 5]], dtype=torch.float)
+    out['kat.grid'] = kat.numpy(); out['kat.meter'] = m.grid2meter(kat).numpy()
+    out['kat.back'] = m.meter2grid(m.grid2meter(kat)).numpy()
+
+    rs = ref_import('model.head.nerfacc_head.ray_sampler')
+    s = rs.RaySampler('fixed', [5, 8], [90, 160])
+    out['rays.fixed'] = s().numpy()
+    np.random.seed(123)
+    s = rs.RaySampler('cellular', [6, 10], [96, 200], ray_upper_crop=8)
+    out['rays.cellular'] = np.stack([s().numpy() for _ in range(3)])
+
+    bu = ref_import('model.encoder.bevformer.utils')
+    tu = ref_import('model.encoder.tpvformer.utils')
+    out['cvref'] = tu.get_cross_view_ref_points(5, 4, 3, [4, 4, 4]).numpy()
+    ref3d = torch.rand(1, 3, 50, 3, generator=g) * torch.tensor([60.0, 60.0, 6.0]) - torch.tensor([30.0, 30.0, 1.0])
+    l2i = []
+    for i in range(3):
+        yaw = 2.1 * i
+        R = np.array([[np.sin(yaw), -np.cos(yaw), 0, 0.3], [0, 0, -1, 1.5], [np.cos(yaw), np.sin(yaw), 0, 0.1], [0, 0, 0, 1]])
+        K = np.array([[300.0, 0, 200, 0], [0, 300.0, 112, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+        l2i.append(K @ R)
+    metas = [dict(lidar2img=np.stack(l2i), img_shape=(224, 400))]
+    cam, mask = bu.point_sampling(ref3d.clone(), metas)
+    out['ps.ref3d'] = ref3d.numpy(); out['ps.lidar2img'] = np.stack(l2i); out['ps.cam'] = cam.numpy(); out['ps.mask'] = mask.numpy()
+    metas[0].update(focal_ratios_x=[1.0, 1.1, 0.9], focal_ratios_y=[1.0, 0.95, 1.05])
+    cam2, mask2 = bu.point_sampling(ref3d.clone(), metas)
+    out['ps.cam_focal'] = cam2.numpy()
+
+    sh = ref_import('model.head.utils.sh_render')
+    feats = torch.randn(64, 3, generator=g)
+    out['sh.feat'] = feats.numpy()
+    out['sh.rgb'] = sh.SHRender(None, torch.randn(64, 3, generator=g), feats, 0, 'relu').numpy()
+    save('geometry.npz', **out)
+
+
+def loss_case(g, R_hw=(6, 10), S=12, Hi=48, Wi=100, num_cams=2):
+    R = R_hw[0] * R_hw[1]
+    K = np.array([[0.8 * Wi, 0, Wi / 2, 0], [0, 0.8 * Wi, Hi / 2, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    def motion(yaw, tx, tz):
+        y = np.deg2rad(yaw)
+        Rm = np.array([[np.cos(y), 0, np.sin(y), tx], [0, 1, 0, 0.02], [-np.sin(y), 0, np.cos(y), tz], [0, 0, 0, 1]])
+        return K @ Rm @ np.linalg.inv(K)
+    metas = [dict(img2prevImg=np.stack([motion(2.0 + c, 0.3, -0.6) for c in range(num_cams)]),
+                  img2nextImg=np.stack([motion(-2.5 - c, -0.2, 0.7) for c in range(num_cams)]))]
+    imgs = {k: torch.rand(1, num_cams, 3, Hi, Wi, generator=g) for k in ('curr', 'prev', 'next')}
+    xs = torch.arange(R_hw[1], dtype=torch.float) * (Wi / R_hw[1]) + 1.7
+    ys = torch.arange(R_hw[0], dtype=torch.float) * (Hi / R_hw[0]) + 0.9
+    rays = torch.stack([xs[None].expand(R_hw[0], -1), ys[:, None].expand(-1, R_hw[1])], -1).flatten(0, 1)
+    weights, ts, deltas = [], [], []
+    for c in range(num_cams):
+        near = torch.rand(R, 1, generator=g) * 0.5
+        far = 2.0 + torch.rand(R, 1, generator=g) * 40.0
+        edges = near + (far - near) * torch.linspace(0, 1, S + 1)[None]
+        ts.append(((edges[:, :-1] + edges[:, 1:]) / 2).flatten())
+        deltas.append((edges[:, 1:] - edges[:, :-1]).flatten())
+        weights.append((torch.softmax(torch.randn(R, S, generator=g) * 3, -1) * torch.rand(R, 1, generator=g)).flatten())
+    ray_idx = [torch.arange(R).unsqueeze(-1).repeat(1, S).flatten()] * num_cams
+    return metas, imgs, rays, weights, ts, deltas, ray_idx, (R, S, Hi, Wi)
+
+
+def golden_losses(LOSS_REG):
+    namespace('loss')
+    base = ref_import('loss.base_loss')
+    sys.modules['loss'].OPENOCC_LOSS = LOSS_REG
+    combine = ref_import('loss.reproj_loss_mono_multi_new_combine')
+    mono = ref_import('loss.reproj_loss_mono_multi_new')
+    rgbms = ref_import('loss.rgb_loss_ms')
+    edge = ref_import('loss.edge_loss_3d_ms')
+    g = torch.Generator().manual_seed(7)
+    metas, imgs, rays, weights, ts, deltas, ray_idx, (R, S, Hi, Wi) = loss_case(g)
+    out = dict(rays=rays.numpy(), img2prevImg=metas[0]['img2prevImg'], img2nextImg=metas[0]['img2nextImg'],
+               curr=imgs['curr'].numpy(), prev=imgs['prev'].numpy(), next=imgs['next'].numpy(),
+               weights=torch.stack(weights).numpy(), ts=torch.stack(ts).numpy(), deltas=torch.stack(deltas).numpy(),
+               dims=np.array([R, S, Hi, Wi, 6, 10]))
+    variants = {
+        'combine_ssim': (combine.ReprojLossMonoMultiNewCombine, dict(img_size=[Hi, Wi], ray_resize=[6, 10]), False),
+        'combine_nossim_deltas': (combine.ReprojLossMonoMultiNewCombine, dict(img_size=[Hi, Wi], no_ssim=True), True),
+        'combine_noautomask': (combine.ReprojLossMonoMultiNewCombine, dict(img_size=[Hi, Wi], ray_resize=[6, 10], no_automask=True), False),
+        'mono_ssim': (mono.ReprojLossMonoMultiNew, dict(img_size=[Hi, Wi], ray_resize=[6, 10]), False),
+        'mono_nossim_deltas': (mono.ReprojLossMonoMultiNew, dict(img_size=[Hi, Wi], no_ssim=True), True),
+    }
+    keys = dict(curr_imgs='curr_imgs', prev_imgs='prev_imgs', next_imgs='next_imgs', ray_indices='ray_indices',
+                weights='weights', ts='ts', metas='metas', ms_rays='ms_rays')
+    for name, (cls, kw, use_d) in variants.items():
+        idict = dict(keys, deltas='deltas') if use_d else keys
+        lossf = cls(weight=1.0, input_dict=idict, **kw)
+        lossf.writer = None
+        w = [x.clone().requires_grad_(True) for x in weights]
+        inp = dict(curr_imgs=imgs['curr'], prev_imgs=imgs['prev'], next_imgs=imgs['next'], ray_indices=ray_idx,
+                   weights=w, ts=ts, metas=metas, ms_rays=rays, deltas=deltas)
+        val = lossf(inp)
+        val.backward()
+        out[f'{name}.loss'] = val.detach().numpy()
+        out[f'{name}.gw'] = torch.stack([x.grad for x in w]).numpy()
+    # the small per-ray losses
+    colors = torch.rand(1, 2, R, 3, generator=g)
+    out['colors'] = colors.numpy()
+    out['rgb_l1.loss'] = rgbms.RGBLossMS(1.0, [Hi, Wi], True, None)(dict(ms_colors=[colors], ms_rays=rays, gt_imgs=imgs['curr'])).numpy()
+    out['rgb_ssim.loss'] = rgbms.RGBLossMS(1.0, [Hi, Wi], False, [6, 10])(dict(ms_colors=[colors], ms_rays=rays, gt_imgs=imgs['curr'])).numpy()
+    sem = torch.softmax(torch.randn(1, 2, R, 5, generator=g), -1)
+    semgt = torch.randint(0, 5, (2, Hi, Wi), generator=g)
+    out['sem'] = sem.numpy(); out['semgt'] = semgt.numpy()
+    smeta = [dict(sem=semgt)]
+    out['semce.loss'] = rgbms.SemCELossMS(1.0, [Hi, Wi], [6, 10])(dict(sem=[sem], metas=smeta, ms_rays=rays)).numpy()
+    out['sembce.loss'] = rgbms.SemLossMS(1.0, [Hi, Wi], [6, 10])(dict(sem=[sem], metas=smeta, ms_rays=rays)).numpy()
+    depth = torch.rand(1, 2, R, generator=g) * 30 + 1
+    out['depth'] = depth.numpy()
+    out['edge.loss'] = edge.EdgeLoss3DMS(1.0, None, img_size=[Hi, Wi], ray_resize=[6, 10])(
+        dict(curr_imgs=imgs['curr'], ms_depths=[depth], ms_rays=rays)).numpy()
+    save('losses.npz', **out)
+
+
+def golden_encoder(REG):
+    for p in ('model', 'model.encoder', 'model.encoder.bevformer', 'model.encoder.bevformer.attention',
+              'model.encoder.tpvformer', 'model.encoder.tpvformer.attention', 'model.encoder.tpvformer.modules',
+              'model.lifter'):
+        if p not in sys.modules:
+            namespace(p)
+    ica = ref_import('model.encoder.bevformer.attention.image_cross_attention')
+    sys.modules['model.encoder.bevformer.attention'].BEVCrossAttention = ica.BEVCrossAttention
+    sys.modules['model.encoder.bevformer.attention'].BEVDeformableAttention = ica.BEVDeformableAttention
+    cv = ref_import('model.encoder.tpvformer.attention.cross_view_hybrid_attention')
+    tca = ref_import('model.encoder.tpvformer.attention.image_cross_attention')
+    sys.modules['model.encoder.tpvformer.attention'].TPVCrossAttention = tca.TPVCrossAttention
+    sys.modules['model.encoder.tpvformer.attention'].CrossViewHybridAttention = cv.CrossViewHybridAttention
+    sys.modules['model.encoder.tpvformer.modules'].CameraAwareSE = object
+    ref_import('model.encoder.tpvformer.tpvformer_pos_embed')
+    ref_import('model.encoder.tpvformer.tpvformer_encoder_layer')
+    enc_mod = ref_import('model.encoder.tpvformer.tpvformer_encoder')
+    lift = ref_import('model.lifter.tpv_query_lifter')
+
+    torch.manual_seed(0)
+    dim, heads = 32, 2
+    mapping_args = dict(nonlinear_mode='linear', h_size=[4, 0], h_range=[8.0, 0], h_half=False, w_size=[3, 0],
+                        w_range=[6.0, 0], w_half=False, d_size=[2, 0], d_range=[-1.0, 3.0, 3.0])
+    H, W, Z = 9, 7, 3
+    layer = dict(type='TPVFormerLayer',
+                 attn_cfgs=[dict(type='CrossViewHybridAttention', embed_dims=dim, num_heads=heads, num_levels=3,
+                                 num_points=4, dropout=0.1, batch_first=True),
+                            dict(type='TPVCrossAttention', embed_dims=dim, num_cams=2, dropout=0.1, batch_first=True,
+                                 num_heads=heads, num_levels=2, num_points=[3, 3, 2])],
+                 feedforward_channels=2 * dim, ffn_dropout=0.1,
+                 operation_order=('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm'))
+    cfg = dict(mapping_args=mapping_args, embed_dims=dim, num_cams=2, num_feature_levels=2,
+               positional_encoding=dict(type='TPVPositionalEncoding', num_freqs=[3] * 3, embed_dims=dim,
+                                        tot_range=[-6.0, -8.0, -1.0, 6.0, 8.0, 3.0]),
+               num_points_cross=[3, 3, 2], num_points_self=[4] * 3, transformerlayers=[layer, layer], num_layers=2)
+    import copy
+    enc = enc_mod.TPVFormerEncoder(**copy.deepcopy(cfg))
+    enc.init_weights()
+    # make the offset / weight linears non-trivial (init zeroes them)
+    g = torch.Generator().manual_seed(1)
+    for n, p in enc.named_parameters():
+        if 'sampling_offsets.weight' in n or 'attention_weights' in n:
+            p.data = 0.2 * torch.randn(p.shape, generator=g)
+    enc.eval()
+    lifter = lift.TPVQueryLifter(H, W, Z, dim)
+    feats = [torch.randn(1, 2, dim, 6, 10, generator=g), torch.randn(1, 2, dim, 3, 5, generator=g)]
+    l2i = []
+    for i in range(2):
+        yaw = 1.3 + 3.1 * i
+        R = np.array([[np.sin(yaw), -np.cos(yaw), 0, 0.1], [0, 0, -1, 1.2], [np.cos(yaw), np.sin(yaw), 0, 0.4], [0, 0, 0, 1]])
+        K = np.array([[40.0, 0, 40, 0], [0, 40.0, 24, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+        l2i.append(K @ R)
+    metas = [dict(lidar2img=np.stack(l2i), img_shape=(48, 80))]
+    rep = lifter(feats)['representation']
+    with torch.no_grad():
+        out = enc(rep, ms_img_feats=feats, metas=metas)['representation']
+        # standalone attention outputs of layer 0 for finer-grained pinning
+        lay = enc.layers[0]
+    arrs = {f'enc.{k}': v for k, v in to_np(enc.state_dict()).items()}
+    arrs.update({f'lift.{k}': v for k, v in to_np(lifter.state_dict()).items()})
+    arrs.update(feat0=feats[0].numpy(), feat1=feats[1].numpy(), lidar2img=np.stack(l2i),
+                out_hw=out[0].numpy(), out_zh=out[1].numpy(), out_wz=out[2].numpy(),
+                ref_3d_hw=enc.ref_3d_hw.numpy(), cross_view_ref_points=enc.cross_view_ref_points.numpy())
+    save('encoder.npz', **arrs)
+    import json
+    with open(os.path.join(HERE, 'encoder_cfg.json'), 'w') as f:
+        json.dump(dict(encoder=cfg, lifter=dict(tpv_h=H, tpv_w=W, tpv_z=Z, dim=dim), img_shape=[48, 80]), f, indent=1)
+
+
+if __name__ == '__main__':
+    assert os.path.isdir(REF), f"{REF} not found: golden vectors can only be regenerated where the reference is mounted"
+    sys.path.insert(0, REF)
+    REG, LOSS_REG = install_stubs()
+    for p in ('model', 'model.encoder', 'model.encoder.bevformer', 'model.encoder.tpvformer', 'model.head',
+              'model.head.nerfacc_head', 'model.head.utils'):
+        namespace(p)
+    golden_geometry()
+    golden_losses(LOSS_REG)
+    golden_encoder(REG)
