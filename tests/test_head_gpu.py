@@ -1,0 +1,126 @@
+"""GPU: NeuSHead end to end — dict protocol of the reference, train step through the HIP
+render forward/backward + fused reprojection loss, eval render vs the oracle, forward_occ."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from oracle import torch_port as tp
+from selfocc_amd import abi, synthetic as sy
+from selfocc_amd.registry import MODELS, OPENOCC_LOSS
+from selfocc_amd.render import RaySet, RenderConfig
+import selfocc_amd.model, selfocc_amd.loss  # noqa: F401
+
+pytestmark = pytest.mark.gpu
+D0 = torch.device("cuda:0")
+MAP = sy.CONFIGS["cfg1"]["mapping"]
+AABB = list(sy.CONFIGS["cfg1"]["aabb"])
+
+
+def make_head(color_dims=8, return_sem=True, **kw):
+    cfg = dict(type='NeuSHead', roi_aabb=AABB, resolution=0.4, near_plane=0.0, far_plane=1e10, num_samples=32,
+               num_samples_importance=0, num_up_sample_steps=0, base_variance=4, beta_init=0.25, beta_hand_tune=False,
+               use_numerical_gradients=False, sample_gradient=True, return_uniform_sdf=False, return_second_grad=True,
+               return_sem=return_sem, ray_sample_mode='cellular', ray_number=[6, 10], ray_img_size=[64, 64],
+               trans_kw='temImg2lidar', render_bkgd='random', mapping_args=MAP, embed_dims=32, color_dims=color_dims,
+               density_layers=2, sh_deg=0, sh_act='relu', two_split=False, tpv=True, return_max_depth=True)
+    cfg.update(kw)
+    torch.manual_seed(0)
+    head = MODELS.build(cfg).to(D0)
+    # bias the last layer so that the synthetic field has surfaces (sdf changes sign inside the box)
+    with torch.no_grad():
+        head.model.field.density_net[-1].bias[0] = 0.5
+    return head
+
+
+def make_inputs(n_cams=2, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    H, W, Z, C = 32, 32, 4, 32
+    rep = [torch.randn(1, H * W, C, generator=g).to(D0).requires_grad_(True),
+           torch.randn(1, Z * H, C, generator=g).to(D0).requires_grad_(True),
+           torch.randn(1, W * Z, C, generator=g).to(D0).requires_grad_(True)]
+    cams = sy.make_cameras("cfg1", seed).repeat(n_cams, 1, 1).clone()
+    cams[1:, :3, 3] += torch.tensor([0.5, -0.3, 0.0])
+    K = np.array([[60.0, 0, 32, 0], [0, 60.0, 32, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+    def motion(yaw, tx, tz):
+        y = np.deg2rad(yaw)
+        Rm = np.array([[np.cos(y), 0, np.sin(y), tx], [0, 1, 0, 0.0], [-np.sin(y), 0, np.cos(y), tz], [0, 0, 0, 1]])
+        return K @ Rm @ np.linalg.inv(K)
+    metas = [dict(temImg2lidar=cams.numpy(), img2lidar=cams.numpy(),
+                  img2prevImg=np.stack([motion(2, 0.1, -0.3)] * n_cams), img2nextImg=np.stack([motion(-2, -0.1, 0.3)] * n_cams),
+                  img_shape=(64, 64))]
+    imgs = {k: torch.rand(1, n_cams, 3, 64, 64, generator=g).to(D0) for k in ('curr_imgs', 'prev_imgs', 'next_imgs')}
+    return rep, metas, imgs
+
+
+def test_head_train_step(hip):
+    os.environ['eval'] = 'false'
+    head = make_head().train()
+    rep, metas, imgs = make_inputs()
+    np.random.seed(0)
+    out = head(rep, metas, global_iter=0)
+    R, S, N = 60, 32, 2
+    assert out['ms_depths'][0].shape == (1, N, R) and out['ms_colors'][0].shape == (1, N, R, 3)
+    assert out['sem'][0].shape == (1, N, R, 5) and out['ms_rays'].shape == (R, 2)
+    assert len(out['weights']) == N and out['weights'][0].shape == (R * S,)
+    assert out['ray_indices'][0].shape == (R * S,) and out['ray_indices'][0].dtype == torch.int64
+    assert out['eik_grad'].shape == (N * R * S, 3) and out['origin'].shape == (N * R, 3)
+    assert out['ms_max_depths'][0].shape == (1, N, R) and out['ms_fars'][0].shape == (1, N, R)
+    loss_fn = OPENOCC_LOSS.build(dict(type='MultiLoss', loss_cfgs=[
+        dict(type='ReprojLossMonoMultiNewCombine', weight=1.0, no_ssim=False, img_size=[64, 64], ray_resize=[6, 10],
+             input_dict={'curr_imgs': 'curr_imgs', 'prev_imgs': 'prev_imgs', 'next_imgs': 'next_imgs',
+                         'ray_indices': 'ray_indices', 'weights': 'weights', 'ts': 'ts', 'metas': 'metas', 'ms_rays': 'ms_rays'}),
+        dict(type='RGBLossMS', weight=0.1, img_size=[64, 64], no_ssim=False, ray_resize=[6, 10],
+             input_dict={'ms_colors': 'ms_colors', 'ms_rays': 'ms_rays', 'gt_imgs': 'curr_imgs'}),
+        dict(type='EikonalLoss', weight=0.1), dict(type='SecondGradLoss', weight=0.01),
+        dict(type='EdgeLoss3DMS', weight=0.01, img_size=[64, 64], ray_resize=[6, 10])]))
+    inputs = dict(out, metas=metas, **imgs)
+    total, parts = loss_fn(inputs)
+    assert set(parts) == {'ReprojLossMonoMultiNewCombine', 'RGBLossMS', 'EikonalLoss', 'SecondGradLoss', 'EdgeLoss3DMS'}
+    total.backward()
+    for r in rep:
+        assert r.grad is not None and torch.isfinite(r.grad).all() and r.grad.abs().sum() > 0
+    for n, p in head.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), n
+    assert head.model.field.variance.grad.abs().item() > 0
+
+
+def test_head_eval_render_vs_oracle(hip):
+    os.environ['eval'] = 'true'
+    try:
+        head = make_head(render_bkgd='white').eval()
+        rep, metas, _ = make_inputs()
+        with torch.no_grad():
+            head.prepare(rep, metas)
+            out = head.render(metas, batch=90000)
+        vol = head.model.field.volume
+        cfg = RenderConfig(aabb=tuple(AABB), n_samples=32, inv_s=float(head.model.field.inv_s()),
+                           bkgd_mode=abi.BKGD_CONST, bkgd=(1., 1., 1.), clamp_rgb=True)
+        cams = torch.tensor(metas[0]['img2lidar'], dtype=torch.float32)
+        rays = RaySet(img2lidar=cams, nx=10, ny=6, sx=6.4, sy=64 / 6)
+        from selfocc_amd.render import SDFVolume
+        ref = oracle.render_fwd(SDFVolume(vol.mapping, vol.sdf.detach().cpu(), vol.feat.detach().cpu(), vol.n_rgb, vol.n_sem), rays, cfg)
+        ok = ref['acc'] > 0.05
+        assert torch.allclose(out['ms_depths'][0].flatten().cpu()[ok], ref['depth'][ok], rtol=1e-4, atol=1e-5)
+        assert torch.allclose(out['ms_accs'][0].flatten().cpu(), ref['acc'], rtol=1e-4, atol=1e-4)
+        assert torch.allclose(out['ms_colors'][0].reshape(-1, 3).cpu(), ref['rgb'], rtol=1e-4, atol=1e-4)
+        assert torch.allclose(out['sem'][0].reshape(-1, 5).cpu(), ref['sem'], rtol=1e-4, atol=1e-4)
+        assert out['ms_max_depths'][0].shape == (1, 2, 60)
+    finally:
+        os.environ['eval'] = 'false'
+
+
+def test_head_forward_occ_matches_grid_sample(hip):
+    head = make_head().eval()
+    rep, metas, _ = make_inputs()
+    with torch.no_grad():
+        res = head.forward_occ(rep, metas, aabb=AABB, resolution=0.4)
+    assert res['sdf'].shape == (32, 32, 7) and res['logits'].shape == (32, 32, 7, 5) and res['sem'].shape == (32, 32, 7)
+    vol = head.model.field.volume
+    dc = torch.cat([vol.sdf[None], vol.feat.permute(3, 0, 1, 2)], 0)[None].detach().cpu()
+    h = tp.field_lookup(vol.mapping, dc, res['xyz'].reshape(-1, 3).cpu())
+    assert torch.equal(res['sdf'].flatten().cpu(), h[:, 0])
+    assert torch.equal(res['logits'].reshape(-1, 5).cpu(), h[:, 4:])
+    assert torch.equal(res['sem'].flatten().cpu(), torch.argmax(h[:, 4:], -1))
