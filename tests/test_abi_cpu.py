@@ -1,0 +1,51 @@
+"""CPU: the C-ABI library loads (no GPU needed) and exports every symbol include/selfocc_hip.h
+declares; the ctypes mirror matches the header; the product never touches the oracle."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+from selfocc_amd import abi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = open(os.path.join(ROOT, "include", "selfocc_hip.h")).read()
+
+
+def test_every_declared_symbol_is_exported_and_mirrored():
+    declared = set(re.findall(r"^\s*(?:int|const char \*)\s*\*?\s*(selfocc_\w+)\s*\(", HEADER, re.M))
+    assert declared == set(abi.SYMBOLS), declared ^ set(abi.SYMBOLS)
+    from selfocc_amd._lib import lib
+    l = lib()                       # raises if the .so is missing or a symbol is absent
+    assert l.selfocc_abi_version() == abi.ABI_VERSION
+    m = re.search(r"#define SELFOCC_ABI_VERSION (\d+)", HEADER)
+    assert int(m.group(1)) == abi.ABI_VERSION
+
+
+def test_struct_layouts_match_header(tmp_path):
+    """compile a tiny C program against the header and compare sizeof / offsetof with ctypes"""
+    src = tmp_path / "sz.c"
+    fields = [("so_axis", "tot_len", abi.SoAxis), ("so_mapping", "d", abi.SoMapping),
+              ("so_render_args", "grad", abi.SoRenderArgs), ("so_render_args", "inv_s", abi.SoRenderArgs),
+              ("so_render_args", "t_rand", abi.SoRenderArgs), ("so_render_bwd_args", "g_inv_s", abi.SoRenderBwdArgs),
+              ("so_query_args", "sem_argmax", abi.SoQueryArgs), ("so_occ_args", "sem", abi.SoOccArgs),
+              ("so_occ_args", "thresh", abi.SoOccArgs), ("so_reproj_args", "wnorm", abi.SoReprojArgs),
+              ("so_reproj_args", "img_h", abi.SoReprojArgs)]
+    body = "\n".join(f'printf("%zu %zu\\n", sizeof({s}), offsetof({s}, {f}));' for s, f, _ in fields)
+    src.write_text(f'#include <stdio.h>\n#include <stddef.h>\n#include "{ROOT}/include/selfocc_hip.h"\n'
+                   f'int main(void) {{ {body} return 0; }}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", str(src), "-o", str(exe)])
+    lines = subprocess.check_output([str(exe)]).decode().split("\n")
+    for (s, f, cls), line in zip(fields, lines):
+        size, off = map(int, line.split())
+        assert C.sizeof(cls) == size, (s, C.sizeof(cls), size)
+        assert getattr(cls, f).offset == off, (s, f, getattr(cls, f).offset, off)
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "selfocc_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".sh")):
+                txt = open(os.path.join(dirpath, fn)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), os.path.join(dirpath, fn)
+                assert 'liboracle' not in txt and 'oracle_render_fwd' not in txt, os.path.join(dirpath, fn)
