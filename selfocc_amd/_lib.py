@@ -8,7 +8,7 @@ import os
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libselfocc_hip.so")
+LIB_PATH = os.environ.get("SELFOCC_HIP_LIB", os.path.join(_HERE, "libselfocc_hip.so"))  # env: kernel A/B builds
 _lib = None
 
 

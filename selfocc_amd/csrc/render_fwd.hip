@@ -15,6 +15,13 @@
 // render_train.hip, where the per-sample outputs must be written coalesced).
 #include "so_device.h"
 
+#ifdef SO_STAGE_STATS
+__device__ unsigned long long g_stage_stats[2];
+extern "C" int selfocc_debug_stage_stats(unsigned long long *out) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stage_stats), sizeof(unsigned long long) * 2);
+}
+#endif
+
 namespace {
 
 struct RayGeom {
@@ -96,6 +103,58 @@ SO_DEVFN void so_gather_feat(const void *__restrict__ vol, int H, int W, int D, 
 #pragma unroll
             for (int q = 0; q < NF / 4; ++q) {
                 uint2 t = p[q];
+                f[4 * q + 0] = fmaf(__uint_as_float(t.x << 16), wgt, f[4 * q + 0]);
+                f[4 * q + 1] = fmaf(__uint_as_float(t.x & 0xffff0000u), wgt, f[4 * q + 1]);
+                f[4 * q + 2] = fmaf(__uint_as_float(t.y << 16), wgt, f[4 * q + 2]);
+                f[4 * q + 3] = fmaf(__uint_as_float(t.y & 0xffff0000u), wgt, f[4 * q + 3]);
+            }
+        }
+    }
+}
+
+
+// ---- buffer-resource loads: one 32-bit lane offset + a uniform (SGPR) corner offset ----------
+typedef float so_f2v __attribute__((ext_vector_type(2)));
+typedef float so_f4v __attribute__((ext_vector_type(4)));
+typedef unsigned so_u2v __attribute__((ext_vector_type(2)));
+SO_DEVFN __amdgpu_buffer_rsrc_t so_make_rsrc(const void *p, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)p, 0, (int)(bytes > 0xfffffffcull ? 0xfffffffcull : bytes), 0x00020000);
+}
+SO_DEVFN so_f2v so_bload2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(so_f2v, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+SO_DEVFN so_f4v so_bload4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(so_f4v, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+SO_DEVFN so_u2v so_bload2u(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(so_u2v, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+}
+
+// all 8 corners in range (wave-uniform precondition): 8 uniform corner bases + one lane offset
+template <int NF, bool BF16>
+SO_DEVFN void so_gather_feat_interior(__amdgpu_buffer_rsrc_t rf, int W, int D, unsigned cell,
+                                      const float wk[8], float f[NF > 0 ? NF : 1]) {
+#pragma unroll
+    for (int k = 0; k < NF; ++k) f[k] = 0.0f;
+    constexpr unsigned VB = BF16 ? NF * 2u : NF * 4u;   // bytes per voxel
+    const unsigned off = cell * VB;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        const unsigned corner = ((unsigned)(kk >> 2) * W * D + (unsigned)((kk >> 1) & 1) * D + (kk & 1)) * VB;  // uniform
+        const float wgt = wk[kk];
+        if constexpr (!BF16) {
+#pragma unroll
+            for (int q = 0; q < NF / 4; ++q) {
+                const so_f4v t = so_bload4(rf, off + q * 16u, corner);
+                f[4 * q + 0] = fmaf(t.x, wgt, f[4 * q + 0]);
+                f[4 * q + 1] = fmaf(t.y, wgt, f[4 * q + 1]);
+                f[4 * q + 2] = fmaf(t.z, wgt, f[4 * q + 2]);
+                f[4 * q + 3] = fmaf(t.w, wgt, f[4 * q + 3]);
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < NF / 4; ++q) {
+                const so_u2v t = so_bload2u(rf, off + q * 8u, corner);
                 f[4 * q + 0] = fmaf(__uint_as_float(t.x << 16), wgt, f[4 * q + 0]);
                 f[4 * q + 1] = fmaf(__uint_as_float(t.x & 0xffff0000u), wgt, f[4 * q + 1]);
                 f[4 * q + 2] = fmaf(__uint_as_float(t.y << 16), wgt, f[4 * q + 2]);
@@ -243,8 +302,121 @@ SO_DEVFN AxisK so_axis_affine(const so_axis &A) {
 SO_DEVFN float so_fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 SO_DEVFN float so_fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-template <int NF, bool BF16, bool PER_SAMPLE>
-SO_DEVFN void so_march_fast(const so_render_args &a, int ray, const RayGeom &g) {
+
+// ---- LDS staging of the wavefront's voxel neighbourhood -----------------------------------
+// At one march step the 64 rays of an 8x8 pixel tile sit within ~1 voxel of each other, so
+// their 64 x 8 corner fetches hit the same <= 4x4x4 voxels: through the vector L1 that is
+// 64 x 8 x NF*4 B of traffic per step (the measured limiter: 86 % of the 64 B/clk/CU L1
+// rate at NF = 24).  Instead the wave loads the 4x4x4 block once (lane l <-> voxel l, NF/4
+// coalesced 16-B loads), parks it in LDS (row stride NF+4 dwords: 16 conflict-free 16-B
+// slots) and every lane reads its 8 corners with ds_read_b128 (256 B/clk/CU).
+// A wave whose cells span more than 3 along an axis takes the direct path (wave-uniform).
+SO_DEVFN unsigned so_wave_or(unsigned v) {
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);  // row_shr:1
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);  // row_shr:2
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);  // row_shr:4
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);  // row_shr:8
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);  // row_bcast:15
+    v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);  // row_bcast:31
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+template <int NF>
+struct StageGeom {
+    // dwords per staged voxel: an ODD multiple of 4 => 16-B aligned rows landing on all 16 16-B bank slots
+    static constexpr int kStride = ((NF / 4) & 1) ? NF : NF + 4;
+    static constexpr int kWaveDwords = 64 * kStride;
+};
+
+// returns true (wave-uniform) and fills hmin/wmin/dmin when the wave's clamped low corners
+// span <= 2 cells per axis, i.e. all corners live in the 4x4x4 block at (hmin, wmin, dmin)
+SO_DEVFN bool so_stage_box(int h0, int w0, int d0, int H, int W, int D, int &hmin, int &wmin, int &dmin) {
+    const int lh = min(max(h0, 0), H - 1), lw = min(max(w0, 0), W - 1), ld = min(max(d0, 0), D - 1);
+    const int bh = __builtin_amdgcn_readfirstlane(lh), bw = __builtin_amdgcn_readfirstlane(lw),
+              bd = __builtin_amdgcn_readfirstlane(ld);
+    const int oh = lh - bh + 4, ow = lw - bw + 4, od = ld - bd + 4;      // expected in [0, 9]
+    const bool bad = ((unsigned)oh > 9u) || ((unsigned)ow > 9u) || ((unsigned)od > 9u);
+    const unsigned m = bad ? 0x80000000u : ((1u << oh) | (1u << (10 + ow)) | (1u << (20 + od)));
+    const unsigned u = so_wave_or(m);
+    if (u & 0x80000000u) return false;
+    const unsigned fh = u & 0x3ffu, fw = (u >> 10) & 0x3ffu, fd = (u >> 20) & 0x3ffu;
+    const int lo_h = __builtin_ctz(fh), lo_w = __builtin_ctz(fw), lo_d = __builtin_ctz(fd);
+    const int hi_h = 31 - __builtin_clz(fh), hi_w = 31 - __builtin_clz(fw), hi_d = 31 - __builtin_clz(fd);
+    if (hi_h - lo_h > 2 || hi_w - lo_w > 2 || hi_d - lo_d > 2) return false;
+    hmin = bh - 4 + lo_h; wmin = bw - 4 + lo_w; dmin = bd - 4 + lo_d;
+    return true;
+}
+
+template <int NF, bool BF16>
+SO_DEVFN void so_gather_feat_staged(__amdgpu_buffer_rsrc_t rf, const void *__restrict__ vol, int H, int W, int D,
+                                    int h0, int w0, int d0, int hmin, int wmin, int dmin, const float wk[8],
+                                    float *lds, int lane, unsigned lane_vox, bool all_interior, float f[NF]) {
+    static_assert(!BF16, "staged path: float32 feature volume");
+    constexpr int ST = StageGeom<NF>::kStride;
+    {   // lane <-> voxel (i, j, k) of the block
+        float4 *dst = (float4 *)(lds + lane * ST);
+        so_f4v t[NF / 4];
+        if (hmin + 3 < H && wmin + 3 < W && dmin + 3 < D) {   // whole block inside the volume (uniform)
+            const unsigned vo = ((unsigned)((hmin * W + wmin) * D + dmin) + lane_vox) * (NF * 4u);
+#pragma unroll
+            for (int q = 0; q < NF / 4; ++q) t[q] = so_bload4(rf, vo + q * 16u, 0u);
+        } else {                                               // clamp at the edge (duplicates are harmless)
+            const int vh = min(hmin + (lane >> 4), H - 1), vw = min(wmin + ((lane >> 2) & 3), W - 1),
+                      vd = min(dmin + (lane & 3), D - 1);
+            const so_f4v *src = (const so_f4v *)((const float *)vol + ((size_t)(vh * W + vw) * D + vd) * NF);
+#pragma unroll
+            for (int q = 0; q < NF / 4; ++q) t[q] = src[q];
+        }
+#pragma unroll
+        for (int q = 0; q < NF / 4; ++q) dst[q] = make_float4(t[q].x, t[q].y, t[q].z, t[q].w);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int k = 0; k < NF; ++k) f[k] = 0.0f;
+    if (all_interior) {
+        // no padding anywhere: the 8 corners sit at compile-time offsets from ONE lane address
+        const float *p0 = lds + (((h0 - hmin) * 4 + (w0 - wmin)) * 4 + (d0 - dmin)) * ST;
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const float4 *p = (const float4 *)(p0 + ((kk >> 2) * 16 + ((kk >> 1) & 1) * 4 + (kk & 1)) * ST);
+            const float wgt = wk[kk];
+#pragma unroll
+            for (int q = 0; q < NF / 4; ++q) {
+                const float4 t = p[q];
+                f[4 * q + 0] = fmaf(t.x, wgt, f[4 * q + 0]);
+                f[4 * q + 1] = fmaf(t.y, wgt, f[4 * q + 1]);
+                f[4 * q + 2] = fmaf(t.z, wgt, f[4 * q + 2]);
+                f[4 * q + 3] = fmaf(t.w, wgt, f[4 * q + 3]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) {
+            const int h = h0 + (kk >> 2), w = w0 + ((kk >> 1) & 1), d = d0 + (kk & 1);
+            const bool in = ((unsigned)h < (unsigned)H) && ((unsigned)w < (unsigned)W) && ((unsigned)d < (unsigned)D);
+            const int li = ((min(max(h, 0), H - 1) - hmin) * 4 + (min(max(w, 0), W - 1) - wmin)) * 4 +
+                           (min(max(d, 0), D - 1) - dmin);
+            const float wgt = in ? wk[kk] : 0.0f;
+            const float4 *p = (const float4 *)(lds + li * ST);
+#pragma unroll
+            for (int q = 0; q < NF / 4; ++q) {
+                const float4 t = p[q];
+                f[4 * q + 0] = fmaf(t.x, wgt, f[4 * q + 0]);
+                f[4 * q + 1] = fmaf(t.y, wgt, f[4 * q + 1]);
+                f[4 * q + 2] = fmaf(t.z, wgt, f[4 * q + 2]);
+                f[4 * q + 3] = fmaf(t.w, wgt, f[4 * q + 3]);
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();   // the next step's stores must not overtake these reads
+}
+
+template <int NF, bool BF16, bool PER_SAMPLE, bool STAGED = false>
+SO_DEVFN void so_march_fast(const so_render_args &a, int ray, const RayGeom &g, bool store = true,
+                             float *lds = nullptr, int lane = 0) {
     constexpr int NSEM = NF > 4 ? NF - 3 : 0;
     const int H = a.map.h.tot_len, W = a.map.w.tot_len, D = a.map.d.tot_len;
     const int S = a.n_samples;
@@ -270,28 +442,48 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, const RayGeom &g) 
     for (int k = 0; k < NSEM; ++k) sem[k] = 0.0f;
     float best_w = -1.0f, best_t = 0.0f;
     const float *__restrict__ vol = a.sdf_vol;
+    const __amdgpu_buffer_rsrc_t rs = so_make_rsrc(vol, (size_t)H * W * D * 4);
+    const unsigned sD = (unsigned)D * 4u, sWD = (unsigned)W * D * 4u;
+    const unsigned lane_vox = (unsigned)(((lane >> 4) * W + ((lane >> 2) & 3)) * D + (lane & 3));  // block voxel of this lane
+    const __amdgpu_buffer_rsrc_t rf = so_make_rsrc(a.feat_vol, NF > 0 ? (size_t)H * W * D * NF * (BF16 ? 2 : 4) : 0);
 
-    for (int i = 0; i < S; ++i) {
+    // one march step; invalid (i >= S) steps of the last unrolled group run with alpha = 0
+    auto body = [&](const int i) __attribute__((always_inline)) {
+        const bool valid_step = i < S;
         const float fi = (float)i;
         const float step = fi * dt;
         const float gh = fmaf(Gdh, step, G0h), gw = fmaf(Gdw, step, G0w), gd = fmaf(Gdd, step, G0d);
         const float flh = floorf(gh), flw = floorf(gw), fld = floorf(gd);
         const float fh = gh - flh, fw = gw - flw, fd = gd - fld;
         const int h0 = (int)flh, w0 = (int)flw, d0 = (int)fld;
-        // zero padding: clamp the address, zero the value
-        const int d0c = min(max(d0, 0), D - 2);
-        const bool dlo_in = (unsigned)d0 < (unsigned)D, dhi_in = (unsigned)(d0 + 1) < (unsigned)D;
-        const bool lo_first = (d0 == d0c), hi_first = (d0 + 1 == d0c);
+        // a wave whose 64 cells are all strictly inside the volume (the common case) needs no
+        // clamps / padding selects and addresses its 4 (h, w) columns as 4 uniform bases + ONE
+        // 32-bit lane offset; otherwise zero padding: clamp the address, zero the value
+        const bool interior = ((unsigned)h0 < (unsigned)(H - 1)) & ((unsigned)w0 < (unsigned)(W - 1)) &
+                              ((unsigned)d0 < (unsigned)(D - 1));
+        const bool all_interior = __all(interior);
+        const unsigned cell = (unsigned)((h0 * W + w0) * D + d0);
         float v[8];
+        if (all_interior) {
+            const unsigned vo = cell * 4u;
+            const so_f2v p00 = so_bload2(rs, vo, 0u), p01 = so_bload2(rs, vo, sD);
+            const so_f2v p10 = so_bload2(rs, vo, sWD), p11 = so_bload2(rs, vo, sWD + sD);
+            v[0] = p00.x; v[1] = p00.y; v[2] = p01.x; v[3] = p01.y;
+            v[4] = p10.x; v[5] = p10.y; v[6] = p11.x; v[7] = p11.y;
+        } else {
+            const int d0c = min(max(d0, 0), D - 2);
+            const bool dlo_in = (unsigned)d0 < (unsigned)D, dhi_in = (unsigned)(d0 + 1) < (unsigned)D;
+            const bool lo_first = (d0 == d0c), hi_first = (d0 + 1 == d0c);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int h = h0 + (q >> 1), w = w0 + (q & 1);
-            const bool in = ((unsigned)h < (unsigned)H) && ((unsigned)w < (unsigned)W);
-            const int hc = min(max(h, 0), H - 1), wc = min(max(w, 0), W - 1);
-            const so_f2u pr = *(const so_f2u *)(vol + ((hc * W + wc) * D + d0c));
-            const float lo = lo_first ? pr.x : pr.y, hi = hi_first ? pr.x : pr.y;
-            v[2 * q] = (in && dlo_in) ? lo : 0.0f;
-            v[2 * q + 1] = (in && dhi_in) ? hi : 0.0f;
+            for (int q = 0; q < 4; ++q) {
+                const int h = h0 + (q >> 1), w = w0 + (q & 1);
+                const bool in = ((unsigned)h < (unsigned)H) && ((unsigned)w < (unsigned)W);
+                const int hc = min(max(h, 0), H - 1), wc = min(max(w, 0), W - 1);
+                const so_f2u pr = *(const so_f2u *)(vol + ((hc * W + wc) * D + d0c));
+                const float lo = lo_first ? pr.x : pr.y, hi = hi_first ? pr.x : pr.y;
+                v[2 * q] = (in && dlo_in) ? lo : 0.0f;
+                v[2 * q + 1] = (in && dhi_in) ? hi : 0.0f;
+            }
         }
         // nested lerps: d, then w, then h; gradients in voxel units reuse the differences
         const float dd0 = v[1] - v[0], dd1 = v[3] - v[2], dd2 = v[5] - v[4], dd3 = v[7] - v[6];
@@ -313,9 +505,9 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, const RayGeom &g) 
         const float eb = so_fast_exp2(-(sdf + half) * s2);  // exp(-(sdf + half) s)
         const float prev_cdf = so_fast_rcp(1.0f + ea), next_cdf = so_fast_rcp(1.0f + eb);
         float alpha = ((prev_cdf - next_cdf) + 1e-5f) * so_fast_rcp(prev_cdf + 1e-5f);
-        alpha = fminf(fmaxf(alpha, 0.0f), 1.0f);
+        alpha = valid_step ? fminf(fmaxf(alpha, 0.0f), 1.0f) : 0.0f;
         const float w = alpha * T;
-        T = T * ((1.0f - alpha) + 1e-7f);
+        T = valid_step ? T * ((1.0f - alpha) + 1e-7f) : T;
 
         const float t_mid = fmaf(fi, dt, tnear + hdt);
         acc = acc + w;
@@ -331,7 +523,22 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, const RayGeom &g) 
             wk[0] = fd0 * ww0; wk[1] = fd * ww0; wk[2] = fd0 * ww1; wk[3] = fd * ww1;
             wk[4] = fd0 * ww2; wk[5] = fd * ww2; wk[6] = fd0 * ww3; wk[7] = fd * ww3;
             float f[NF];
-            so_gather_feat<NF, BF16>(a.feat_vol, H, W, D, c, wk, f);
+            bool done = false;
+            if constexpr (STAGED) {
+                int hmin, wmin, dmin;
+                const bool boxed = so_stage_box(h0, w0, d0, H, W, D, hmin, wmin, dmin);
+#ifdef SO_STAGE_STATS
+                if (lane == 0) atomicAdd(&g_stage_stats[boxed ? 0 : 1], 1ull);
+#endif
+                if (boxed) {
+                    so_gather_feat_staged<NF, BF16>(rf, a.feat_vol, H, W, D, h0, w0, d0, hmin, wmin, dmin, wk, lds, lane, lane_vox, all_interior, f);
+                    done = true;
+                }
+            }
+            if (!done) {
+                if (all_interior) so_gather_feat_interior<NF, BF16>(rf, W, D, cell, wk, f);
+                else so_gather_feat<NF, BF16>(a.feat_vol, H, W, D, c, wk, f);
+            }
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 float col = fmaxf(fmaf(0.28209479177387814f, f[k], 0.5f), 0.0f);
@@ -353,21 +560,32 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, const RayGeom &g) 
             }
         }
         if constexpr (PER_SAMPLE) {
-            size_t o = (size_t)ray * S + i;
-            if (a.weights) a.weights[o] = w;
-            if (a.ts) a.ts[o] = t_mid * inv_dn;
-            if (a.deltas) a.deltas[o] = dt * inv_dn;
-            if (a.sdf) a.sdf[o] = sdf;
-            if (a.grad) {
-                a.grad[3 * o] = gvw * kw.k1; a.grad[3 * o + 1] = gvh * kh.k1; a.grad[3 * o + 2] = gvd * kd.k1;
+            if (valid_step) {
+                size_t o = (size_t)ray * S + i;
+                if (a.weights) a.weights[o] = w;
+                if (a.ts) a.ts[o] = t_mid * inv_dn;
+                if (a.deltas) a.deltas[o] = dt * inv_dn;
+                if (a.sdf) a.sdf[o] = sdf;
+                if (a.grad) {
+                    a.grad[3 * o] = gvw * kw.k1; a.grad[3 * o + 1] = gvh * kh.k1; a.grad[3 * o + 2] = gvd * kd.k1;
+                }
             }
-        } else {
+        }
+    };
+    // two steps per trip: the two independent gathers overlap (the compiler does not software-
+    // pipeline the loop on its own); the early-exit vote is taken once per trip
+    constexpr int U = 1;  // (2-step trips measured no faster: the loop is VALU-issue bound, not latency bound)
+    for (int i = 0; i < S; i += U) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) body(i + u);
+        if constexpr (!PER_SAMPLE) {
             if (__all(T < 1e-10f)) break;
         }
     }
 
     const float eps32 = 1.1920928955078125e-07f;
     if (dt * inv_dn < eps32) best_t = tnear + hdt;  // degenerate ray: all w/delta == 0 -> index 0
+    if (!store) return;
     float depth = dsum * so_fast_rcp(acc + 1e-10f);
     if (a.flags & SO_FLAG_DEPTH_DIV_NORM) depth = depth * inv_dn;
     if (a.depth) a.depth[ray] = depth;
@@ -404,8 +622,11 @@ SO_DEVFN void so_march(const so_render_args &a, int ray, const RayGeom &g) {
 }
 
 // explicit rays: one ray per thread, linear order
+#ifndef SO_WAVES_FEAT
+#define SO_WAVES_FEAT 2   // min waves / SIMD requested for the feature-carrying kernels (A/B knob)
+#endif
 template <int NF, bool BF16, bool PER_SAMPLE, bool FAST>
-__global__ __launch_bounds__(256) void render_fwd_explicit(so_render_args a) {
+__global__ __launch_bounds__(256, (NF >= 8 ? SO_WAVES_FEAT : 1)) void render_fwd_explicit(so_render_args a) {
     int ray = blockIdx.x * blockDim.x + threadIdx.x;
     if (ray >= a.n_rays) return;
     RayGeom g;
@@ -419,7 +640,7 @@ __global__ __launch_bounds__(256) void render_fwd_explicit(so_render_args a) {
 
 // pixel-grid rays: block = 16x16 pixel tile of one camera, each wave an 8x8 sub-tile
 template <int NF, bool BF16, bool PER_SAMPLE, bool FAST>
-__global__ __launch_bounds__(256) void render_fwd_pixgrid(so_render_args a, int tiles_x,
+__global__ __launch_bounds__(256, (NF >= 8 ? SO_WAVES_FEAT : 1)) void render_fwd_pixgrid(so_render_args a, int tiles_x,
                                                            int tiles_y) {
     int b = blockIdx.x;
     int cam = b / (tiles_x * tiles_y);
@@ -428,10 +649,22 @@ __global__ __launch_bounds__(256) void render_fwd_pixgrid(so_render_args a, int 
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int ix = tx * 16 + (wave & 1) * 8 + (lane & 7);
     int iy = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
-    if (ix >= a.nx || iy >= a.ny) return;
-    int ray = (cam * a.ny + iy) * a.nx + ix;
-    RayGeom g = so_pixel_ray(a, cam, ix, iy);
-    so_march<NF, BF16, PER_SAMPLE, FAST>(a, ray, g);
+    constexpr bool STAGED = FAST && !PER_SAMPLE && !BF16 && NF >= 4;
+    if constexpr (STAGED) {
+        // every lane keeps marching (the LDS staging is a whole-wave operation): lanes beyond the
+        // lattice edge shadow the nearest real pixel and only skip the final store
+        __shared__ __attribute__((aligned(16))) float s_stage[4 * StageGeom<NF>::kWaveDwords];
+        const bool real = (ix < a.nx) && (iy < a.ny);
+        ix = min(ix, a.nx - 1); iy = min(iy, a.ny - 1);
+        int ray = (cam * a.ny + iy) * a.nx + ix;
+        RayGeom g = so_pixel_ray(a, cam, ix, iy);
+        so_march_fast<NF, BF16, PER_SAMPLE, true>(a, ray, g, real, s_stage + wave * StageGeom<NF>::kWaveDwords, lane);
+    } else {
+        if (ix >= a.nx || iy >= a.ny) return;
+        int ray = (cam * a.ny + iy) * a.nx + ix;
+        RayGeom g = so_pixel_ray(a, cam, ix, iy);
+        so_march<NF, BF16, PER_SAMPLE, FAST>(a, ray, g);
+    }
 }
 
 template <int NF, bool BF16, bool PER_SAMPLE, bool FAST>
