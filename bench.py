@@ -44,8 +44,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--channels", type=int, default=25, choices=[1, 4, 25],
-                    help="volume channels: 1 sdf | 4 sdf+rgb | 25 sdf+rgb+21 sem (nuscenes_occ)")
+    ap.add_argument("--channels", type=int, default=1, choices=[1, 4, 25],
+                    help="volume channels: 1 = sdf only (config/nuscenes/nuscenes_depth.py, color_dims=0: the "
+                         "eval_depth.py path the reference's README quotes) | 4 sdf+rgb | 25 sdf+rgb+21 sem (nuscenes_occ)")
     ap.add_argument("--feat-dtype", default="f32", choices=["f32", "bf16"])
     ap.add_argument("--exact", action="store_true", help="canonical IEEE path (bit-exact with the oracle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -119,7 +120,7 @@ def main():
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     touch_bytes = n_rays * cfg.n_samples * 8 * (4 + (0 if vol.feat is None else (n_rgb + n_sem) * vol.feat.element_size()))
     roofline = {
-        "bound": "hbm", "kernel": "render_fwd_pixgrid", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+        "bound": "hbm", "kernel": f"render_fwd_pixgrid<NF={vol.feat.shape[3] if vol.feat is not None else 0}>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
         "traffic": None,  # rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE per launch: see profiles/ (filled by hand per round)
         "kernel_ms": round(kern_ms, 4), "algorithmic_bytes": alg_bytes,
@@ -127,9 +128,21 @@ def main():
                  "(volume <= 64 MB sits in L2 / Infinity Cache), touched bytes through L1 per launch = %d" % touch_bytes),
         "touch_GBps": round(touch_bytes / (kern_ms * 1e-3) / 1e9, 1),
     }
-    trf = os.environ.get("SELFOCC_BENCH_TRAFFIC_BYTES")
-    if trf:
-        roofline["traffic"] = float(trf)
+    # HBM-side bytes per launch measured with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes,
+    # scripts/pmc.sh); committed per round under profiles/ because PMC collection cannot run inside bench.py
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_file):
+        key = f"c{args.channels}_{args.feat_dtype}_{'exact' if args.exact else 'fast'}"
+        rec = json.load(open(pmc_file)).get(key)
+        if rec:
+            roofline["traffic"] = rec["traffic_bytes"]
+            roofline["traffic_note"] = rec["note"]
+            if "valu_wave_insts" in rec:   # secondary, compute-side view of the same kernel
+                peak = 256 * 4 * 32 * 2.4e9 / 1e12          # fp32 vector lane-ops / s (157.3 TFLOP/s = 2 flop x this)
+                ach = rec["valu_wave_insts"] * 64 / (kern_ms * 1e-3) / 1e12
+                roofline["valu"] = {"achieved_Tlaneops": round(ach, 2), "peak_Tlaneops": round(peak, 2),
+                                    "frac": round(ach / peak, 3),
+                                    "note": "SQ_INSTS_VALU x 64 lanes / kernel time vs 256 CU x 4 SIMD x 32 lanes x 2.4 GHz"}
 
     extras = {}
     if rank == 0 and world == 1 and not args.no_extras:
@@ -148,6 +161,7 @@ def main():
             return round(n_rays / (a.elapsed_time(b) / k * 1e-3), 1)
         extras = {
             "rays_per_s_c1_f32": time_variant(1, torch.float32, False),
+            "rays_per_s_c1_f32_exact": time_variant(1, torch.float32, True, k=3),
             "rays_per_s_c4_f32": time_variant(4, torch.float32, False),
             "rays_per_s_c25_f32": time_variant(25, torch.float32, False),
             "rays_per_s_c25_bf16": time_variant(25, torch.bfloat16, False),
@@ -156,22 +170,24 @@ def main():
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # the reference's CPU render path (torch grid_sample + compositing), one README-sized
-        # chunk of 90 000 rays of the same frame; oracle/ is used here ONLY as the timed baseline
+        # the reference's CPU render path (torch F.grid_sample + NeuS compositing) on the same frame, in
+        # README-sized chunks of 90 000 rays (neus_head.py:329-385) until ~12 s of CPU work are spent;
+        # oracle/ is used here ONLY as the timed baseline
         from oracle import torch_port as tp
         ex = sy.explicit_rays(rays_cpu)
-        n_s = 90_000 if args.channels < 25 else 30_000
-        sl = slice(1_000_000, 1_000_000 + n_s)
         dc = vol_cpu.to_reference_layout()
         cores = torch.get_num_threads()
         tp.render_port(vol_cpu.mapping, dc, n_rgb, n_sem, ex.origins[:2000], ex.dirs[:2000], ex.dir_norm[:2000], cfg)
-        c0 = time.perf_counter()
-        tp.render_port(vol_cpu.mapping, dc, n_rgb, n_sem, ex.origins[sl], ex.dirs[sl], ex.dir_norm[sl], cfg,
-                       chunk=90_000)
-        c1 = time.perf_counter()
-        cpu_baseline = {"value": round(n_s / (c1 - c0), 1), "unit": "rays/s", "cores": cores, "kind": "port",
-                        "sample": f"{n_s} rays (one chunk) of the same cfg2 frame, C={args.channels}, "
-                                  f"torch CPU F.grid_sample + NeuS compositing, {c1 - c0:.1f} s"}
+        chunk, done, spent = 90_000, 0, 0.0
+        while done < n_rays and spent < 12.0:
+            sl = slice(done, min(n_rays, done + chunk))
+            c0 = time.perf_counter()
+            tp.render_port(vol_cpu.mapping, dc, n_rgb, n_sem, ex.origins[sl], ex.dirs[sl], ex.dir_norm[sl], cfg, chunk=chunk)
+            spent += time.perf_counter() - c0
+            done = sl.stop
+        cpu_baseline = {"value": round(done / spent, 1), "unit": "rays/s", "cores": cores, "kind": "port",
+                        "sample": f"first {done} rays of the same cfg2 frame (chunks of 90000), C={args.channels}, "
+                                  f"torch CPU F.grid_sample + NeuS compositing, {spent:.1f} s"}
 
     if rank == 0:
         line = {
