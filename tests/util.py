@@ -2,7 +2,7 @@
 import torch
 
 
-def cell_margin(mapping, rays, cfg, nears, fars, chunk=200_000):
+def cell_margin(mapping, rays, cfg, nears, fars, chunk=200_000, skip_first=False):
     """Per ray: the smallest distance (in voxels) between any of its sample positions and a
     voxel face, in float64.  The SDF is trilinear, so its gradient — which feeds NeuS's
     alpha through cos = d . grad — is DISCONTINUOUS across voxel faces: a sample within
@@ -22,5 +22,7 @@ def cell_margin(mapping, rays, cfg, nears, fars, chunk=200_000):
         pos = o[:, None, :] + d[:, None, :] * t[..., None]
         g = mapping.meter2grid(pos)
         fr = g - torch.floor(g)
+        if skip_first:
+            fr = fr[:, 1:]
         out.append(torch.minimum(fr, 1 - fr).amin(dim=(1, 2)))
     return torch.cat(out)
