@@ -350,17 +350,22 @@ SO_DEVFN bool so_stage_box(int h0, int w0, int d0, int H, int W, int D, int &hmi
 template <int NF, bool BF16>
 SO_DEVFN void so_gather_feat_staged(__amdgpu_buffer_rsrc_t rf, const void *__restrict__ vol, int H, int W, int D,
                                     int h0, int w0, int d0, int hmin, int wmin, int dmin, const float wk[8],
-                                    float *lds, int lane, unsigned lane_vox, bool all_interior, float f[NF]) {
+                                    float *lds, int lane, unsigned lane_vox, bool pref, const so_f4v blk[NF / 4],
+                                    bool all_interior, float f[NF]) {
     static_assert(!BF16, "staged path: float32 feature volume");
     constexpr int ST = StageGeom<NF>::kStride;
-    {   // lane <-> voxel (i, j, k) of the block
+    {   // lane <-> voxel (i, j, k) of the block: registers prefetched a step ahead, or (block touching the
+        // volume edge) loaded here with clamped coordinates (duplicates are harmless)
         float4 *dst = (float4 *)(lds + lane * ST);
         so_f4v t[NF / 4];
-        if (hmin + 3 < H && wmin + 3 < W && dmin + 3 < D) {   // whole block inside the volume (uniform)
+        if (pref) {
+#pragma unroll
+            for (int q = 0; q < NF / 4; ++q) t[q] = blk[q];
+        } else if (hmin + 3 < H && wmin + 3 < W && dmin + 3 < D) {   // whole block inside the volume (uniform)
             const unsigned vo = ((unsigned)((hmin * W + wmin) * D + dmin) + lane_vox) * (NF * 4u);
 #pragma unroll
             for (int q = 0; q < NF / 4; ++q) t[q] = so_bload4(rf, vo + q * 16u, 0u);
-        } else {                                               // clamp at the edge (duplicates are harmless)
+        } else {
             const int vh = min(hmin + (lane >> 4), H - 1), vw = min(wmin + ((lane >> 2) & 3), W - 1),
                       vd = min(dmin + (lane & 3), D - 1);
             const so_f4v *src = (const so_f4v *)((const float *)vol + ((size_t)(vh * W + vw) * D + vd) * NF);
@@ -390,6 +395,11 @@ SO_DEVFN void so_gather_feat_staged(__amdgpu_buffer_rsrc_t rf, const void *__res
                 f[4 * q + 2] = fmaf(t.z, wgt, f[4 * q + 2]);
                 f[4 * q + 3] = fmaf(t.w, wgt, f[4 * q + 3]);
             }
+#ifdef SO_STAGE_SCHED
+            // keep at most SO_STAGE_SCHED corners' reads in flight: without this the scheduler hoists
+            // all 48 ds_read_b128 (192 VGPRs) and the kernel drops to 2 waves / SIMD
+            if constexpr (NF >= 16) { if ((kk % SO_STAGE_SCHED) == SO_STAGE_SCHED - 1) __builtin_amdgcn_sched_barrier(0); }
+#endif
         }
     } else {
 #pragma unroll
@@ -413,6 +423,19 @@ SO_DEVFN void so_gather_feat_staged(__amdgpu_buffer_rsrc_t rf, const void *__res
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();   // the next step's stores must not overtake these reads
 }
+
+// what `fetch` leaves in registers for one march step
+template <int NF>
+struct FastStep {
+    float fh, fw, fd, fi;         // fractional grid coordinates, step index as float
+    int h0, w0, d0;               // cell
+    unsigned cell;                // linear index of the low corner
+    bool all_interior;            // wave-uniform: no lane needs padding at this step
+    float v[8];                   // SDF corners (d fastest)
+    bool boxed, pref;             // wave-uniform: LDS staging applies / block already loaded
+    int hmin, wmin, dmin;         // staged block origin
+    so_f4v blk[NF >= 4 ? NF / 4 : 1];
+};
 
 template <int NF, bool BF16, bool PER_SAMPLE, bool STAGED = false>
 SO_DEVFN void so_march_fast(const so_render_args &a, int ray, const RayGeom &g, bool store = true,
@@ -447,29 +470,29 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, const RayGeom &g, 
     const unsigned lane_vox = (unsigned)(((lane >> 4) * W + ((lane >> 2) & 3)) * D + (lane & 3));  // block voxel of this lane
     const __amdgpu_buffer_rsrc_t rf = so_make_rsrc(a.feat_vol, NF > 0 ? (size_t)H * W * D * NF * (BF16 ? 2 : 4) : 0);
 
-    // one march step; invalid (i >= S) steps of the last unrolled group run with alpha = 0
-    auto body = [&](const int i) __attribute__((always_inline)) {
-        const bool valid_step = i < S;
-        const float fi = (float)i;
-        const float step = fi * dt;
+    constexpr bool PIPE = NF < 8;   // see the loop below
+    // ---- stage 1: geometry of step i + every global load it needs, issued one step ahead ------
+    auto fetch = [&](const int i, FastStep<NF> &st) __attribute__((always_inline)) {
+        st.fi = (float)i;
+        const float step = st.fi * dt;
         const float gh = fmaf(Gdh, step, G0h), gw = fmaf(Gdw, step, G0w), gd = fmaf(Gdd, step, G0d);
         const float flh = floorf(gh), flw = floorf(gw), fld = floorf(gd);
-        const float fh = gh - flh, fw = gw - flw, fd = gd - fld;
+        st.fh = gh - flh; st.fw = gw - flw; st.fd = gd - fld;
         const int h0 = (int)flh, w0 = (int)flw, d0 = (int)fld;
+        st.h0 = h0; st.w0 = w0; st.d0 = d0;
         // a wave whose 64 cells are all strictly inside the volume (the common case) needs no
-        // clamps / padding selects and addresses its 4 (h, w) columns as 4 uniform bases + ONE
-        // 32-bit lane offset; otherwise zero padding: clamp the address, zero the value
+        // clamps / padding selects and addresses its 4 (h, w) columns as ONE 32-bit lane offset +
+        // 4 uniform (SGPR) offsets of a buffer resource; otherwise zero padding: clamp + select
         const bool interior = ((unsigned)h0 < (unsigned)(H - 1)) & ((unsigned)w0 < (unsigned)(W - 1)) &
                               ((unsigned)d0 < (unsigned)(D - 1));
-        const bool all_interior = __all(interior);
-        const unsigned cell = (unsigned)((h0 * W + w0) * D + d0);
-        float v[8];
-        if (all_interior) {
-            const unsigned vo = cell * 4u;
+        st.all_interior = __all(interior);
+        st.cell = (unsigned)((h0 * W + w0) * D + d0);
+        if (st.all_interior) {
+            const unsigned vo = st.cell * 4u;
             const so_f2v p00 = so_bload2(rs, vo, 0u), p01 = so_bload2(rs, vo, sD);
             const so_f2v p10 = so_bload2(rs, vo, sWD), p11 = so_bload2(rs, vo, sWD + sD);
-            v[0] = p00.x; v[1] = p00.y; v[2] = p01.x; v[3] = p01.y;
-            v[4] = p10.x; v[5] = p10.y; v[6] = p11.x; v[7] = p11.y;
+            st.v[0] = p00.x; st.v[1] = p00.y; st.v[2] = p01.x; st.v[3] = p01.y;
+            st.v[4] = p10.x; st.v[5] = p10.y; st.v[6] = p11.x; st.v[7] = p11.y;
         } else {
             const int d0c = min(max(d0, 0), D - 2);
             const bool dlo_in = (unsigned)d0 < (unsigned)D, dhi_in = (unsigned)(d0 + 1) < (unsigned)D;
@@ -481,10 +504,29 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, const RayGeom &g, 
                 const int hc = min(max(h, 0), H - 1), wc = min(max(w, 0), W - 1);
                 const so_f2u pr = *(const so_f2u *)(vol + ((hc * W + wc) * D + d0c));
                 const float lo = lo_first ? pr.x : pr.y, hi = hi_first ? pr.x : pr.y;
-                v[2 * q] = (in && dlo_in) ? lo : 0.0f;
-                v[2 * q + 1] = (in && dhi_in) ? hi : 0.0f;
+                st.v[2 * q] = (in && dlo_in) ? lo : 0.0f;
+                st.v[2 * q + 1] = (in && dhi_in) ? hi : 0.0f;
             }
         }
+        st.boxed = false; st.pref = false;
+        if constexpr (STAGED) {
+            st.boxed = so_stage_box(h0, w0, d0, H, W, D, st.hmin, st.wmin, st.dmin);
+#ifdef SO_STAGE_STATS
+            if (lane == 0) atomicAdd(&g_stage_stats[st.boxed ? 0 : 1], 1ull);
+#endif
+            if (PIPE && st.boxed && st.hmin + 3 < H && st.wmin + 3 < W && st.dmin + 3 < D) {   // block inside the volume
+                const unsigned vo = ((unsigned)((st.hmin * W + st.wmin) * D + st.dmin) + lane_vox) * (NF * 4u);
+#pragma unroll
+                for (int q = 0; q < NF / 4; ++q) st.blk[q] = so_bload4(rf, vo + q * 16u, 0u);
+                st.pref = true;
+            }
+        }
+    };
+
+    // ---- stage 2: interpolation, NeuS alpha, compositing of step i ----------------------------
+    auto consume = [&](const int i, FastStep<NF> &st) __attribute__((always_inline)) {
+        const float fh = st.fh, fw = st.fw, fd = st.fd, fi = st.fi;
+        const float *v = st.v;
         // nested lerps: d, then w, then h; gradients in voxel units reuse the differences
         const float dd0 = v[1] - v[0], dd1 = v[3] - v[2], dd2 = v[5] - v[4], dd3 = v[7] - v[6];
         const float c0 = fmaf(fd, dd0, v[0]), c1 = fmaf(fd, dd1, v[2]);
@@ -505,9 +547,9 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, const RayGeom &g, 
         const float eb = so_fast_exp2(-(sdf + half) * s2);  // exp(-(sdf + half) s)
         const float prev_cdf = so_fast_rcp(1.0f + ea), next_cdf = so_fast_rcp(1.0f + eb);
         float alpha = ((prev_cdf - next_cdf) + 1e-5f) * so_fast_rcp(prev_cdf + 1e-5f);
-        alpha = valid_step ? fminf(fmaxf(alpha, 0.0f), 1.0f) : 0.0f;
+        alpha = fminf(fmaxf(alpha, 0.0f), 1.0f);
         const float w = alpha * T;
-        T = valid_step ? T * ((1.0f - alpha) + 1e-7f) : T;
+        T = T * ((1.0f - alpha) + 1e-7f);
 
         const float t_mid = fmaf(fi, dt, tnear + hdt);
         acc = acc + w;
@@ -516,7 +558,7 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, const RayGeom &g, 
 
         if constexpr (NF > 0) {
             so_cell c;
-            c.h0 = h0; c.w0 = w0; c.d0 = d0;
+            c.h0 = st.h0; c.w0 = st.w0; c.d0 = st.d0;
             float wk[8];
             const float fh0 = 1.0f - fh, fw0 = 1.0f - fw, fd0 = 1.0f - fd;
             const float ww0 = fw0 * fh0, ww1 = fw * fh0, ww2 = fw0 * fh, ww3 = fw * fh;
@@ -525,18 +567,15 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, const RayGeom &g, 
             float f[NF];
             bool done = false;
             if constexpr (STAGED) {
-                int hmin, wmin, dmin;
-                const bool boxed = so_stage_box(h0, w0, d0, H, W, D, hmin, wmin, dmin);
-#ifdef SO_STAGE_STATS
-                if (lane == 0) atomicAdd(&g_stage_stats[boxed ? 0 : 1], 1ull);
-#endif
-                if (boxed) {
-                    so_gather_feat_staged<NF, BF16>(rf, a.feat_vol, H, W, D, h0, w0, d0, hmin, wmin, dmin, wk, lds, lane, lane_vox, all_interior, f);
+                if (st.boxed) {
+                    so_gather_feat_staged<NF, BF16>(rf, a.feat_vol, H, W, D, st.h0, st.w0, st.d0, st.hmin, st.wmin,
+                                                    st.dmin, wk, lds, lane, lane_vox, st.pref, st.blk,
+                                                    st.all_interior, f);
                     done = true;
                 }
             }
             if (!done) {
-                if (all_interior) so_gather_feat_interior<NF, BF16>(rf, W, D, cell, wk, f);
+                if (st.all_interior) so_gather_feat_interior<NF, BF16>(rf, W, D, st.cell, wk, f);
                 else so_gather_feat<NF, BF16>(a.feat_vol, H, W, D, c, wk, f);
             }
 #pragma unroll
@@ -560,26 +599,40 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, const RayGeom &g, 
             }
         }
         if constexpr (PER_SAMPLE) {
-            if (valid_step) {
-                size_t o = (size_t)ray * S + i;
-                if (a.weights) a.weights[o] = w;
-                if (a.ts) a.ts[o] = t_mid * inv_dn;
-                if (a.deltas) a.deltas[o] = dt * inv_dn;
-                if (a.sdf) a.sdf[o] = sdf;
-                if (a.grad) {
-                    a.grad[3 * o] = gvw * kw.k1; a.grad[3 * o + 1] = gvh * kh.k1; a.grad[3 * o + 2] = gvd * kd.k1;
-                }
+            size_t o = (size_t)ray * S + i;
+            if (a.weights) a.weights[o] = w;
+            if (a.ts) a.ts[o] = t_mid * inv_dn;
+            if (a.deltas) a.deltas[o] = dt * inv_dn;
+            if (a.sdf) a.sdf[o] = sdf;
+            if (a.grad) {
+                a.grad[3 * o] = gvw * kw.k1; a.grad[3 * o + 1] = gvh * kh.k1; a.grad[3 * o + 2] = gvd * kd.k1;
             }
         }
     };
-    // two steps per trip: the two independent gathers overlap (the compiler does not software-
-    // pipeline the loop on its own); the early-exit vote is taken once per trip
-    constexpr int U = 1;  // (2-step trips measured no faster: the loop is VALU-issue bound, not latency bound)
-    for (int i = 0; i < S; i += U) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) body(i + u);
-        if constexpr (!PER_SAMPLE) {
-            if (__all(T < 1e-10f)) break;
+
+    // Light kernels (NF < 8) run a two-stage software pipeline with ping-pong register sets: the
+    // global loads of step i + 1 are in flight while step i is interpolated and composited.  With
+    // 24 feature channels the second register set spills (measured 12.5 ms vs 4.4 ms), so the
+    // heavy kernels fetch and consume the same step.
+    if constexpr (PIPE) {
+        FastStep<NF> A, B;
+        fetch(0, A);
+        for (int i = 0;;) {
+            if (i + 1 < S) fetch(i + 1, B);
+            consume(i, A);
+            if (++i >= S) break;
+            if constexpr (!PER_SAMPLE) { if (__all(T < 1e-10f)) break; }
+            if (i + 1 < S) fetch(i + 1, A);
+            consume(i, B);
+            if (++i >= S) break;
+            if constexpr (!PER_SAMPLE) { if (__all(T < 1e-10f)) break; }
+        }
+    } else {
+        for (int i = 0; i < S; ++i) {
+            FastStep<NF> A;
+            fetch(i, A);
+            consume(i, A);
+            if constexpr (!PER_SAMPLE) { if (__all(T < 1e-10f)) break; }
         }
     }
 
