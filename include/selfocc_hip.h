@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SELFOCC_ABI_VERSION 3
+#define SELFOCC_ABI_VERSION 4
 
 int selfocc_abi_version(void);
 const char *selfocc_last_error(void);
@@ -123,6 +123,11 @@ typedef struct so_render_args {
     float *deltas;    /* (n_rays, n_samples)  (end - start) / dir_norm                 */
     float *sdf;       /* (n_rays, n_samples)                                           */
     float *grad;      /* (n_rays, n_samples, 3)  d sdf / d (x, y, z) in metres         */
+    /* --- optional workspace --------------------------------------------------------- */
+    float *sdf_brick; /* [H][W][D][8] scratch or NULL.  When given, the fast path first
+                         re-packs sdf_vol so that the 8 corners of every cell are one 32-B
+                         record (2 x 16-B loads per sample instead of 4 x 8-B gathers) — the
+                         re-pack kernel is launched by selfocc_render_fwd on the same stream */
 } so_render_args;
 
 int selfocc_render_fwd(const so_render_args *args, void *stream);

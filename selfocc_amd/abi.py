@@ -6,7 +6,7 @@ its exported symbols being callable with these layouts.
 """
 import ctypes as C
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # enums ---------------------------------------------------------------------------
 RAYS_EXPLICIT, RAYS_PIXEL_GRID = 0, 1
@@ -47,6 +47,7 @@ class SoRenderArgs(C.Structure):
         ("depth", _p), ("acc", _p), ("rgb", _p), ("sem", _p), ("max_depth", _p),
         ("nears", _p), ("fars", _p),
         ("weights", _p), ("ts", _p), ("deltas", _p), ("sdf", _p), ("grad", _p),
+        ("sdf_brick", _p),
     ]
 
 

@@ -113,6 +113,7 @@ class RenderConfig:
     depth_div_norm: bool = True
     clamp_rgb: bool = False
     exact: bool = False               # canonical IEEE op order (bit-exact with the oracle), slower
+    brick: bool = True                # fast path: re-pack the SDF volume into 8-corner records per launch
 
 
 def _c(t, dtype=torch.float32):
@@ -200,8 +201,23 @@ def render_rays(vol: SDFVolume, rays: RaySet, cfg: RenderConfig, *, per_sample=F
     a, out, _keep = marshal_render_args(vol, rays, cfg, per_sample=per_sample,
                                         want_grad_samples=want_grad_samples, t_rand=t_rand,
                                         bkgd_rays=bkgd_rays, outputs=outputs)
+    if cfg.brick and not cfg.exact and rays.n_rays * cfg.n_samples >= 16 * vol.sdf.numel():
+        a.sdf_brick = ptr(_brick_workspace(vol.sdf))   # the re-pack only pays off for large ray batches
     check(lib().selfocc_render_fwd(a, current_stream(vol.sdf.device)), "selfocc_render_fwd")
     return out
+
+
+_BRICK_WS = {}
+
+
+def _brick_workspace(sdf):
+    """Per (device, shape) scratch for the 8-corner records of the SDF volume ([H][W][D][8] f32);
+    rewritten by every launch on the launch stream, so it is never stale."""
+    key = (sdf.device, tuple(sdf.shape))
+    ws = _BRICK_WS.get(key)
+    if ws is None:
+        ws = _BRICK_WS[key] = torch.empty(*sdf.shape, 8, dtype=torch.float32, device=sdf.device)
+    return ws
 
 
 class _RenderFunction(torch.autograd.Function):

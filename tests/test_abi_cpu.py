@@ -25,7 +25,7 @@ def test_struct_layouts_match_header(tmp_path):
     """compile a tiny C program against the header and compare sizeof / offsetof with ctypes"""
     src = tmp_path / "sz.c"
     fields = [("so_axis", "tot_len", abi.SoAxis), ("so_mapping", "d", abi.SoMapping),
-              ("so_render_args", "grad", abi.SoRenderArgs), ("so_render_args", "inv_s", abi.SoRenderArgs),
+              ("so_render_args", "grad", abi.SoRenderArgs), ("so_render_args", "sdf_brick", abi.SoRenderArgs), ("so_render_args", "inv_s", abi.SoRenderArgs),
               ("so_render_args", "t_rand", abi.SoRenderArgs), ("so_render_bwd_args", "g_inv_s", abi.SoRenderBwdArgs),
               ("so_query_args", "sem_argmax", abi.SoQueryArgs), ("so_occ_args", "sem", abi.SoOccArgs),
               ("so_occ_args", "thresh", abi.SoOccArgs), ("so_reproj_args", "wnorm", abi.SoReprojArgs),
