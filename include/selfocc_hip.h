@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SELFOCC_ABI_VERSION 4
+#define SELFOCC_ABI_VERSION 5
 
 int selfocc_abi_version(void);
 const char *selfocc_last_error(void);
@@ -176,6 +176,12 @@ int selfocc_msda_bwd(const float *value, const int32_t *shapes, const int32_t *s
                      float *g_value, float *g_loc, float *g_attw,
                      int32_t bs, int32_t nv, int32_t nq, int32_t heads, int32_t d,
                      int32_t L, int32_t P, void *stream);
+
+/* Optional hint for the NEXT selfocc_msda_bwd call of the calling thread: a HOST copy of `shapes`
+ * (L, 2).  With it the backward privatises the coarse pyramid levels in LDS (far less atomic
+ * contention); without it (or L > 8) the plain kernel runs.  Results are identical up to float
+ * summation order.  Pass NULL to clear. */
+int selfocc_msda_bwd_plan(const int32_t *host_shapes, int32_t L);
 
 /* ------------------------------------------------------------------------------------
  * Dense SDF / semantic query on a regular metre lattice + Occ3D occupancy tail.

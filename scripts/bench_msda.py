@@ -11,8 +11,8 @@ d = torch.device("cuda:0")
 torch.manual_seed(0)
 CASES = {
     # name: (bs, nq, shapes, P, visible fraction of queries per camera)
-    "cross_hw": (6, 66049 // 3, [[48, 100], [24, 50], [12, 25], [6, 13]], 8),
-    "cross_zh": (6, 6425 // 3 * 2, [[48, 100], [24, 50], [12, 25], [6, 13]], 48),
+    "cross_hw": (6, 66049 // 3, [[96, 200], [48, 100], [24, 50], [12, 25]], 8),
+    "cross_zh": (6, 6425 // 3 * 2, [[96, 200], [48, 100], [24, 50], [12, 25]], 48),
     "self_xview": (1, 78899, [[257, 257], [25, 257], [257, 25]], 12),
 }
 res = {}

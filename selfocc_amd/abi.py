@@ -6,7 +6,7 @@ its exported symbols being callable with these layouts.
 """
 import ctypes as C
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 # enums ---------------------------------------------------------------------------
 RAYS_EXPLICIT, RAYS_PIXEL_GRID = 0, 1
@@ -104,6 +104,7 @@ SYMBOLS = {
     "selfocc_render_bwd": (C.c_int, [C.POINTER(SoRenderBwdArgs), _p]),
     "selfocc_msda_fwd": (C.c_int, [_p, _p, _p, _p, _p, _p] + [_i] * 7 + [_p]),
     "selfocc_msda_bwd": (C.c_int, [_p] * 9 + [_i] * 7 + [_p]),
+    "selfocc_msda_bwd_plan": (C.c_int, [_p, _i]),
     "selfocc_field_query": (C.c_int, [C.POINTER(SoQueryArgs), _p]),
     "selfocc_occ_resample": (C.c_int, [C.POINTER(SoOccArgs), _p]),
     "selfocc_iou_counts": (C.c_int, [_p, _p, _p, C.c_int64, _p, _i, _i, _p, _p]),

@@ -265,6 +265,137 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(const float *__restrict__
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// backward, LDS-privatised variant for the coarse pyramid levels.  In the lifter's cross
+// attention every level receives the same number of sampling points, so the 12x25 / 24x50 maps
+// take ~2300 / ~580 float atomics PER ADDRESS per call (6.8 ms per call, 52 % of a nuscenes_occ
+// training iteration in profiles/r1_f_train_iteration.txt).  Here a block owns one (batch, head)
+// and a chunk of queries, accumulates the levels that fit its LDS budget with ds_add_f32 and
+// flushes each tile once with coalesced global atomics; the fine levels keep global atomics.
+// ---------------------------------------------------------------------------------------
+struct MsdaLdsPlan {
+    int off[8];       // float offset of level l's tile in LDS, -1 = not privatised
+    int total;        // floats
+    int q_per_block, n_chunks;
+};
+
+template <int D>
+__global__ __launch_bounds__(512) void msda_bwd_tiled_kernel(const float *__restrict__ value,
+                                                             const int32_t *__restrict__ shapes,
+                                                             const int32_t *__restrict__ starts,
+                                                             const float *__restrict__ loc,
+                                                             const float *__restrict__ attw,
+                                                             const float *__restrict__ g_out,
+                                                             float *__restrict__ g_value, float *__restrict__ g_loc,
+                                                             float *__restrict__ g_attw, MsdaDims dm, MsdaLdsPlan plan) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];
+    const int LP = dm.L * dm.P;
+    const int chunk = blockIdx.x % plan.n_chunks;
+    const int bh = blockIdx.x / plan.n_chunks;
+    const int h = bh % dm.heads, b = bh / dm.heads;
+    const int q0 = chunk * plan.q_per_block;
+    const int nq_here = min(plan.q_per_block, dm.nq - q0);
+    const int pix_stride = dm.heads * D;
+    for (int e = threadIdx.x; e < plan.total; e += blockDim.x) tile[e] = 0.0f;
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    constexpr int PPI = 64 / D;
+    const int sub = lane % D, grp = lane / D;
+    const int n_local = nq_here * LP;
+    for (int base = 0; base < n_local; base += blockDim.x) {       // uniform trip count per block
+        const int e = base + threadIdx.x;
+        const bool live = e < n_local;
+        const int ec = live ? e : n_local - 1;
+        const int q = q0 + ec / LP, pt = ec % LP;
+        const long long gq = ((long long)b * dm.nq + q) * dm.heads + h;
+        const long long idx = gq * LP + pt;
+        const int l = so_level_of(pt, dm.P, dm.L);
+        const int Hl = shapes[2 * l], Wl = shapes[2 * l + 1];
+        const float2 xy = *(const float2 *)(loc + 2 * idx);
+        const float aw = attw[idx];
+        const Bilin bl = so_bilinear_setup(xy.x, xy.y, Hl, Wl, 1);   // pixel indices (stride 1)
+        const int vbase = (int)((((long long)b * dm.nv + starts[l]) * dm.heads + h) * D);
+        float ga = 0.0f, gx = 0.0f, gy = 0.0f;
+        float wsc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (live && bl.any) {
+            const float *vl = value + vbase;
+            float go[D];
+            const float4 *gp = (const float4 *)(g_out + (size_t)gq * D);
+#pragma unroll
+            for (int qq = 0; qq < D / 4; ++qq) {
+                const float4 t = gp[qq];
+                go[4 * qq] = t.x; go[4 * qq + 1] = t.y; go[4 * qq + 2] = t.z; go[4 * qq + 3] = t.w;
+            }
+            float dot[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                dot[k] = 0.0f;
+                if (bl.valid[k]) {
+                    const float4 *p = (const float4 *)(vl + (size_t)bl.off[k] * pix_stride);
+                    wsc[k] = bl.w[k] * aw;
+#pragma unroll
+                    for (int qq = 0; qq < D / 4; ++qq) {
+                        const float4 t = p[qq];
+                        dot[k] = fmaf(t.x, go[4 * qq], dot[k]);
+                        dot[k] = fmaf(t.y, go[4 * qq + 1], dot[k]);
+                        dot[k] = fmaf(t.z, go[4 * qq + 2], dot[k]);
+                        dot[k] = fmaf(t.w, go[4 * qq + 3], dot[k]);
+                    }
+                }
+            }
+            ga = (bl.w[0] * dot[0] + bl.w[1] * dot[1]) + (bl.w[2] * dot[2] + bl.w[3] * dot[3]);
+            const float gw = (bl.hh * (dot[1] - dot[0])) + (bl.lh * (dot[3] - dot[2]));
+            const float gh = (bl.hw * (dot[2] - dot[0])) + (bl.lw * (dot[3] - dot[1]));
+            gx = (float)Wl * gw * aw;
+            gy = (float)Hl * gh * aw;
+        }
+        if (live) {
+            g_attw[idx] = ga;
+            *(float2 *)(g_loc + 2 * idx) = make_float2(gx, gy);
+        }
+        // transposed scatter: D lanes own the D channels of one point's corner
+        const int gq32 = (int)gq;
+        const int toff = plan.off[l];                               // -1: global atomics
+        for (int j = 0; j < 64 / PPI; ++j) {
+            const int src = j * PPI + grp;
+            const int q_src = __shfl(gq32, src, 64);
+            const int t_src = __shfl(toff, src, 64);
+            const int vb_src = __shfl(vbase, src, 64);
+            float w_src[4];
+            int p_src[4];
+            bool any = false;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                w_src[k] = __shfl(wsc[k], src, 64);
+                p_src[k] = __shfl(bl.off[k], src, 64);
+                any |= (w_src[k] != 0.0f);
+            }
+            if (any) {
+                const float goc = g_out[(size_t)q_src * D + sub];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (w_src[k] == 0.0f) continue;
+                    if (t_src >= 0) atomicAdd(&tile[t_src + p_src[k] * D + sub], w_src[k] * goc);
+                    else unsafeAtomicAdd(g_value + vb_src + p_src[k] * pix_stride + sub, w_src[k] * goc);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // flush the privatised levels: consecutive lanes = consecutive channels of consecutive pixels
+    for (int l = 0; l < dm.L; ++l) {
+        if (plan.off[l] < 0) continue;
+        const int n = shapes[2 * l] * shapes[2 * l + 1] * D;
+        float *gl = g_value + (((size_t)b * dm.nv + starts[l]) * dm.heads + h) * D;
+        for (int e = threadIdx.x; e < n; e += blockDim.x) {
+            const float v = tile[plan.off[l] + e];
+            if (v != 0.0f) unsafeAtomicAdd(gl + (size_t)(e / D) * pix_stride + (e % D), v);
+        }
+    }
+}
+
 int validate(const float *value, const int32_t *shapes, const int32_t *starts, const float *loc,
              const float *attw, int bs, int nv, int nq, int heads, int d, int L, int P) {
     SO_REQUIRE(bs >= 0 && nq >= 0 && nv >= 0, "msda: negative size");
@@ -278,6 +409,21 @@ int validate(const float *value, const int32_t *shapes, const int32_t *starts, c
 }
 
 }  // namespace
+
+// Host copy of the level shapes of the NEXT selfocc_msda_bwd call of this thread (optional): lets the
+// backward choose which pyramid levels to privatise in LDS without reading device memory.
+static thread_local int g_plan_shapes[16];
+static thread_local int g_plan_L = 0;
+static thread_local bool g_plan_valid = false;
+
+extern "C" int selfocc_msda_bwd_plan(const int32_t *host_shapes, int32_t L) {
+    g_plan_valid = false;
+    if (host_shapes == nullptr || L < 1 || L > 8) return 0;
+    for (int i = 0; i < 2 * L; ++i) g_plan_shapes[i] = host_shapes[i];
+    g_plan_L = L;
+    g_plan_valid = true;
+    return 0;
+}
 
 extern "C" int selfocc_msda_fwd(const float *value, const int32_t *shapes, const int32_t *starts,
                                 const float *loc, const float *attw, float *out, int32_t bs,
@@ -321,6 +467,34 @@ extern "C" int selfocc_msda_bwd(const float *value, const int32_t *shapes, const
     SO_REQUIRE(blocks < (1LL << 31), "msda_bwd: grid too large");
     MsdaDims dm{bs, nv, nq, heads, L, P};
     hipStream_t st = (hipStream_t)stream;
+    // LDS privatisation plan: needs the level shapes on the host (a 32-byte async copy + sync would stall
+    // the stream), so the caller may pass them through selfocc_msda_bwd_plan(); see below
+    if (g_plan_valid && g_plan_L == L && L <= 8 && nq >= 512 && d == 16) {
+        MsdaLdsPlan plan;
+        plan.total = 0;
+        const int budget = 28 * 1024;   // floats: 112 KiB of the CU's 160 KiB LDS
+        for (int l = L - 1; l >= 0; --l) {
+            const int n = g_plan_shapes[2 * l] * g_plan_shapes[2 * l + 1] * d;
+            if (plan.total + n <= budget) { plan.off[l] = plan.total; plan.total += n; }
+            else plan.off[l] = -1;
+        }
+        for (int l = L; l < 8; ++l) plan.off[l] = -1;
+        if (plan.total > 0) {
+            plan.q_per_block = 256;
+            plan.n_chunks = (nq + plan.q_per_block - 1) / plan.q_per_block;
+            const long long tb = (long long)bs * heads * plan.n_chunks;
+            SO_REQUIRE(tb < (1LL << 31), "msda_bwd: grid too large");
+            const size_t shm = (size_t)plan.total * sizeof(float);
+            static bool attr_set = false;
+            if (!attr_set) {
+                hipFuncSetAttribute((const void *)msda_bwd_tiled_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
+                attr_set = true;
+            }
+            hipLaunchKernelGGL((msda_bwd_tiled_kernel<16>), dim3((unsigned)tb), dim3(512), shm, st, value, shapes, starts,
+                               loc, attw, g_out, g_value, g_loc, g_attw, dm, plan);
+            return so_launch_status();
+        }
+    }
 #define SO_LAUNCH(DD)                                                                             \
     hipLaunchKernelGGL((msda_bwd_kernel<DD>), dim3((unsigned)blocks), dim3(256), 0, st, value,    \
                        shapes, starts, loc, attw, g_out, g_value, g_loc, g_attw, dm)

@@ -132,6 +132,7 @@ class TPVFormerLayer(_FormerLayerBase):
         for op in self.operation_order:
             if op == 'self_attn':   # cross-view hybrid attention: the 3 planes are the 3 "levels"
                 ss = torch.tensor([[H, W], [Z, H], [W, Z]], device=device)
+                ss._so_host = [H, W, Z, H, W, Z]
                 lsi = torch.tensor([0, H * W, H * W + Z * H], device=device)
                 q = torch.cat(query, dim=1)
                 q = self.attentions[attn_i](q, q, q, torch.cat(identity, dim=1) if self.pre_norm else None,
@@ -225,6 +226,7 @@ class _EncoderBase(BaseModule):
             flat.append(feat)
         flat = torch.cat(flat, 2).permute(0, 2, 1, 3)
         spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=device)
+        spatial_shapes._so_host = [int(v) for hw in shapes for v in hw]   # host copy for the MSDA backward plan
         level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
         return flat, spatial_shapes, level_start_index
 

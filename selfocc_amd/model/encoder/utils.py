@@ -25,7 +25,12 @@ def point_sampling(reference_points, img_metas):
     pts = pts.permute(1, 0, 2, 3)                                               # (D, B, Q, 4)
     D, B, Q = pts.shape[:3]
     N = lidar2img.size(1)
-    cam = torch.matmul(lidar2img.view(1, B, N, 1, 4, 4), pts.view(D, B, 1, Q, 4, 1)).squeeze(-1)
+    # 4x4 @ 4x1 per (pillar point, camera).  The reference writes this as a broadcast torch.matmul
+    # (bevformer/utils.py:138-140); on ROCm that lowers to a hipBLASLt GEMM that took 24-44 ms per plane
+    # (92 ms per nuscenes_occ iteration, profiles/r1_f_train_iteration.txt) — four broadcast FMAs do it in ~0.1 ms
+    Mv = lidar2img.view(1, B, N, 1, 4, 4)
+    p = pts.view(D, B, 1, Q, 4)
+    cam = ((Mv[..., 0] * p[..., 0:1] + Mv[..., 1] * p[..., 1:2]) + Mv[..., 2] * p[..., 2:3]) + Mv[..., 3] * p[..., 3:4]
     eps = 1e-5
     aug = img_metas[0].get('img_augmentation') if isinstance(img_metas[0], dict) else None
     if aug is not None and 'post_rots' in aug and 'post_trans' in aug:

@@ -48,6 +48,12 @@ class MultiScaleDeformableAttnFunction(Function):
               "selfocc_msda_fwd")
         ctx.save_for_backward(value, sh, st, loc, aw)
         ctx.dims = dims
+        # host copy of the level shapes for the backward's LDS-privatisation plan (no device read-back
+        # when the caller hands over CPU / python shapes; one small sync otherwise, in forward only)
+        host = getattr(value_spatial_shapes, '_so_host', None)
+        if host is None and ctx.needs_input_grad[0]:
+            host = [int(v) for v in value_spatial_shapes.reshape(-1).tolist()]
+        ctx.host_shapes = host if ctx.needs_input_grad[0] else None
         return out
 
     @staticmethod
@@ -59,6 +65,12 @@ class MultiScaleDeformableAttnFunction(Function):
         g_value = torch.zeros_like(value)
         g_loc = torch.empty_like(loc)
         g_aw = torch.empty_like(aw)
+        if ctx.host_shapes is not None:
+            import ctypes
+            arr = (ctypes.c_int32 * len(ctx.host_shapes))(*ctx.host_shapes)
+            lib().selfocc_msda_bwd_plan(ctypes.cast(arr, ctypes.c_void_p), L)
+        else:
+            lib().selfocc_msda_bwd_plan(None, 0)
         check(lib().selfocc_msda_bwd(ptr(value), ptr(sh), ptr(st), ptr(loc), ptr(aw), ptr(g_out),
                                      ptr(g_value), ptr(g_loc), ptr(g_aw),
                                      bs, nv, nq, heads, d, L, P, current_stream(value.device)),

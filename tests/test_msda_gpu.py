@@ -60,3 +60,19 @@ def test_msda_reference_shapes_properties(hip):
     assert torch.allclose(f(v, 0.5 * aw), 0.5 * o1, rtol=1e-5, atol=1e-5)
     sub = oracle.msda_fwd(value[:1, :, :, :], sh, st, loc[:1, :500], attw[:1, :500])
     assert torch.allclose(o1[:1, :500].cpu(), sub, rtol=1e-5, atol=1e-5)
+
+
+def test_msda_bwd_lds_privatised_levels(hip):
+    """nq >= 512 with coarse levels that fit LDS -> the tiled backward kernel; same gradients as the
+    oracle (and as the plain kernel, which the small cases above exercise)."""
+    case = (2, 700, 6, 16, [[24, 50], [12, 25], [6, 13], [3, 7]], 8)
+    value, shapes, starts, loc, attw = make_case(*case, seed=11)
+    d = torch.device("cuda:0")
+    v = value.to(d).requires_grad_(True); lc = loc.to(d).requires_grad_(True); aw = attw.to(d).requires_grad_(True)
+    out = MultiScaleDeformableAttnFunction.apply(v, shapes.to(d), starts.to(d), lc, aw, 64)
+    g = torch.randn(out.shape, generator=torch.Generator().manual_seed(9))
+    out.backward(g.to(d))
+    gv, gl, ga = oracle.msda_bwd(value, shapes, starts, loc, attw, g)
+    assert torch.allclose(v.grad.cpu(), gv, rtol=1e-4, atol=2e-4)
+    assert torch.allclose(aw.grad.cpu(), ga, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(lc.grad.cpu(), gl, rtol=1e-3, atol=1e-4)
