@@ -59,11 +59,18 @@ def main():
     assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # SELFOCC_BENCH_SHARE_GPU=1 (testing only): every rank uses cuda:0 over gloo, so that the N > 1 code
+    # path can be exercised on a 1-GPU box; the driver's real runs use one GPU per rank over RCCL
+    share = os.environ.get("SELFOCC_BENCH_SHARE_GPU") == "1"
+    dev_index = 0 if share else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        if share:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
     from selfocc_amd import synthetic as sy
     from selfocc_amd.render import render_rays, RaySet
@@ -79,25 +86,31 @@ def main():
                   sx=rays_cpu.sx, sy=rays_cpu.sy)
     n_rays = rays.n_rays
     out = render_rays(vol, rays, cfg)  # allocates outputs once
-    loss = torch.zeros(1, device=dev)
+    # ray-sharded ranks all-reduce the rendered-depth loss (north_star): one 4-byte RCCL all-reduce per
+    # step, issued asynchronously into its own slot so that step i+1's render never waits for it
+    losses = torch.zeros(args.steps + args.warmup, device=dev)
+    pending = []
 
-    def step():
+    def step(i):
         render_rays(vol, rays, cfg, outputs=out)
-        if world > 1:  # ray-sharded ranks: all-reduce of the rendered-depth loss (xGMI / RCCL)
-            torch.mean(out['depth'], dim=0, keepdim=True, out=loss)
-            dist.all_reduce(loss)
+        if world > 1:
+            slot = losses[i:i + 1]
+            torch.mean(out['depth'], dim=0, keepdim=True, out=slot)
+            pending.append(dist.all_reduce(slot, async_op=True))
 
     def fence():
+        while pending:
+            pending.pop().wait()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
