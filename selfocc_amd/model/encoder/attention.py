@@ -85,6 +85,22 @@ class BEVCrossAttention(BaseModule):
     def init_weight(self):
         xavier_init(self.output_proj, distribution='uniform', bias=0.)
 
+    @staticmethod
+    def rebatch_plan(bev_masks):
+        """Visible (camera, query) pairs and their slots in the per-camera re-batch.  Depends only on
+        the camera geometry, so an encoder computes it ONCE per forward and hands it to all its layers
+        (``rebatch_plan=`` kwarg): one host sync per plane per frame instead of one per plane per layer.
+        Like the reference, visibility is taken from batch element 0 (image_cross_attention.py:92)."""
+        vis = bev_masks[:, 0].sum(-1) > 0                                  # (num_cams, Q)
+        lens = vis.sum(-1)
+        max_len = int(lens.max())                                          # host sync (reference :95)
+        cam_idx, q_idx = vis.nonzero(as_tuple=True)                        # sorted by camera, then query
+        starts = torch.cumsum(lens, 0) - lens
+        slot = torch.arange(cam_idx.numel(), device=bev_masks.device) - starts[cam_idx]
+        count = (bev_masks.sum(-1) > 0).permute(1, 2, 0).sum(-1)
+        count = torch.clamp(count, min=1.0)
+        return cam_idx, q_idx, slot, max_len, count
+
     def forward(self, query, key, value, residual=None, spatial_shapes=None, reference_points_cams=None,
                 bev_masks=None, level_start_index=None, **kwargs):
         if key is None:
@@ -96,13 +112,10 @@ class BEVCrossAttention(BaseModule):
         bs, num_query, _ = query.size()
         num_cams = self.num_cams
         D = reference_points_cams.size(3)
-        # visible (camera, query) pairs; like the reference, visibility is taken from batch 0 (:92)
-        vis = bev_masks[:, 0].sum(-1) > 0                                  # (num_cams, Q)
-        lens = vis.sum(-1)
-        max_len = int(lens.max())                                          # the one host sync (:95)
-        cam_idx, q_idx = vis.nonzero(as_tuple=True)                        # sorted by camera, then query
-        starts = torch.cumsum(lens, 0) - lens
-        slot = torch.arange(cam_idx.numel(), device=query.device) - starts[cam_idx]
+        plan = kwargs.get('rebatch_plan')
+        if plan is None:
+            plan = self.rebatch_plan(bev_masks)
+        cam_idx, q_idx, slot, max_len, count = plan
         queries_rebatch = query.new_zeros([bs, num_cams, max_len, self.embed_dims])
         ref_rebatch = reference_points_cams.new_zeros([bs, num_cams, max_len, D, 2])
         queries_rebatch[:, cam_idx, slot] = query[:, q_idx]
@@ -119,9 +132,6 @@ class BEVCrossAttention(BaseModule):
         sampled = sampled.view(bs, num_cams, max_len, self.embed_dims)
         slots = torch.zeros_like(query)
         slots.index_add_(1, q_idx, sampled[:, cam_idx, slot])
-        count = bev_masks.sum(-1) > 0
-        count = count.permute(1, 2, 0).sum(-1)
-        count = torch.clamp(count, min=1.0)
         slots = slots / count[..., None]
         slots = self.output_proj(slots)
         return self.dropout(slots) + residual
@@ -151,9 +161,11 @@ class TPVCrossAttention(BaseModule):
 
     def forward(self, query, key, value, residual=None, spatial_shapes=None, reference_points_cams=None,
                 tpv_masks=None, level_start_index=None, **kwargs):
+        plans = kwargs.get('rebatch_plans') or [None] * 3
         return [self.attns[i](query[i], key, value, residual[i] if residual is not None else None,
                               spatial_shapes=spatial_shapes, level_start_index=level_start_index,
-                              reference_points_cams=reference_points_cams[i], bev_masks=tpv_masks[i])
+                              reference_points_cams=reference_points_cams[i], bev_masks=tpv_masks[i],
+                              rebatch_plan=plans[i])
                 for i in range(3)]
 
 
