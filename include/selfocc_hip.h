@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define SELFOCC_ABI_VERSION 5
+#define SELFOCC_ABI_VERSION 6
 
 int selfocc_abi_version(void);
 const char *selfocc_last_error(void);
@@ -169,6 +169,16 @@ int selfocc_msda_fwd(const float *value, const int32_t *shapes, const int32_t *s
                      const float *loc, const float *attw, float *out,
                      int32_t bs, int32_t nv, int32_t nq, int32_t heads, int32_t d,
                      int32_t L, int32_t P, void *stream);
+
+/* Inference form with the reference's prologue fused in (softmax over the L*P logits of a
+ * (query, head); loc = ref + off / (W_l, H_l); image_cross_attention.py:314-328,
+ * cross_view_hybrid_attention.py:88-99): the sampling_locations / attention_weights tensors are
+ * never materialised.   off_raw (bs,nq,heads,L,P,2)  logits (bs,nq,heads,L*P)
+ *   ref_kind 0: ref (bs,nq,L,2)   1: ref (bs,nq,P,2)   2: ref (bs,nq,L,P,2)        L*P <= 256 */
+int selfocc_msda_fused_fwd(const float *value, const int32_t *shapes, const int32_t *starts,
+                           const float *ref, int32_t ref_kind, const float *off_raw, const float *logits,
+                           float *out, int32_t bs, int32_t nv, int32_t nq, int32_t heads, int32_t d,
+                           int32_t L, int32_t P, void *stream);
 
 /* g_value must be zero-initialised by the caller (atomically accumulated). */
 int selfocc_msda_bwd(const float *value, const int32_t *shapes, const int32_t *starts,

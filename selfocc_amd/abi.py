@@ -6,7 +6,7 @@ its exported symbols being callable with these layouts.
 """
 import ctypes as C
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 # enums ---------------------------------------------------------------------------
 RAYS_EXPLICIT, RAYS_PIXEL_GRID = 0, 1
@@ -103,6 +103,7 @@ SYMBOLS = {
     "selfocc_render_fwd": (C.c_int, [C.POINTER(SoRenderArgs), _p]),
     "selfocc_render_bwd": (C.c_int, [C.POINTER(SoRenderBwdArgs), _p]),
     "selfocc_msda_fwd": (C.c_int, [_p, _p, _p, _p, _p, _p] + [_i] * 7 + [_p]),
+    "selfocc_msda_fused_fwd": (C.c_int, [_p, _p, _p, _p, _i, _p, _p, _p] + [_i] * 7 + [_p]),
     "selfocc_msda_bwd": (C.c_int, [_p] * 9 + [_i] * 7 + [_p]),
     "selfocc_msda_bwd_plan": (C.c_int, [_p, _i]),
     "selfocc_field_query": (C.c_int, [C.POINTER(SoQueryArgs), _p]),

@@ -162,6 +162,133 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const float *__restrict__
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// fused forward (inference): the prologue the reference runs as separate torch kernels around the
+// op — softmax over the L*P attention logits of a (query, head) and
+// loc = reference + offset / (W_l, H_l) (bevformer/attention/image_cross_attention.py:314-328,
+// tpvformer/attention/cross_view_hybrid_attention.py:88-99) — happens in registers, so the
+// 100-400 MB `sampling_locations` / `attention_weights` tensors are never written or re-read.
+//   ref_kind 0: ref (bs, nq, L, 2)      (mmcv base class)
+//            1: ref (bs, nq, P, 2)      (one anchor per point, all levels: BEVDeformableAttention)
+//            2: ref (bs, nq, L, P, 2)   (CrossViewHybridAttention)
+// ---------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256) void msda_fused_fwd_kernel(const float *__restrict__ value,
+                                                             const int32_t *__restrict__ shapes,
+                                                             const int32_t *__restrict__ starts,
+                                                             const float *__restrict__ ref, int ref_kind,
+                                                             const float *__restrict__ off_raw,
+                                                             const float *__restrict__ logits,
+                                                             float *__restrict__ out, MsdaDims dm, int G, int logG) {
+    constexpr int MAXR = 4;   // points per lane (host guarantees L * P <= MAXR * G)
+    const int LP = dm.L * dm.P;
+    const int groups_per_block = 256 / G;
+    const long long n_groups = (long long)dm.bs * dm.nq * dm.heads;
+    const long long gid = (long long)blockIdx.x * groups_per_block + (threadIdx.x / G);
+    const int gl = threadIdx.x & (G - 1);
+    const bool live = gid < n_groups;
+    const long long gq = live ? gid : 0;
+    const int h = (int)(gq % dm.heads);
+    const long long bq = gq / dm.heads;                 // b * nq + q
+    const int b = (int)(bq / dm.nq);
+    const int pix_stride = dm.heads * D;
+    const float *vbase = value + ((size_t)b * dm.nv * dm.heads + h) * D;
+
+    // softmax over the group's L * P logits
+    float lg[MAXR];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+        const int pt = gl + r * G;
+        lg[r] = (pt < LP) ? logits[(size_t)gq * LP + pt] : -INFINITY;
+        mx = fmaxf(mx, lg[r]);
+    }
+    for (int m = 1; m < G; m <<= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+    float den = 0.0f;
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+        lg[r] = (gl + r * G < LP) ? __expf(lg[r] - mx) : 0.0f;
+        den += lg[r];
+    }
+    for (int m = 1; m < G; m <<= 1) den += __shfl_xor(den, m, 64);
+    const float iden = 1.0f / den;
+
+    float acc[D];
+#pragma unroll
+    for (int c = 0; c < D; ++c) acc[c] = 0.0f;
+    if (live) {
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) {
+            const int pt = gl + r * G;
+            if (pt >= LP) break;
+            const int l = so_level_of(pt, dm.P, dm.L);
+            const int pp = pt - l * dm.P;
+            const int Hl = shapes[2 * l], Wl = shapes[2 * l + 1];
+            const size_t idx = (size_t)gq * LP + pt;
+            const float2 o = *(const float2 *)(off_raw + 2 * idx);
+            size_t ri;
+            if (ref_kind == 1) ri = (size_t)bq * dm.P + pp;
+            else if (ref_kind == 2) ri = ((size_t)bq * dm.L + l) * dm.P + pp;
+            else ri = (size_t)bq * dm.L + l;
+            const float2 rf = *(const float2 *)(ref + 2 * ri);
+            const float lx = rf.x + o.x / (float)Wl, ly = rf.y + o.y / (float)Hl;
+            const float aw = lg[r] * iden;
+            const Bilin bl = so_bilinear_setup(lx, ly, Hl, Wl, pix_stride);
+            if (!bl.any) continue;
+            const float *vl = vbase + (size_t)starts[l] * pix_stride;
+            float val[D];
+#pragma unroll
+            for (int c = 0; c < D; ++c) val[c] = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 *p = (const float4 *)(vl + bl.off[k]);
+#pragma unroll
+                for (int q = 0; q < D / 4; ++q) {
+                    const float4 t = p[q];
+                    val[4 * q + 0] = fmaf(bl.w[k], t.x, val[4 * q + 0]);
+                    val[4 * q + 1] = fmaf(bl.w[k], t.y, val[4 * q + 1]);
+                    val[4 * q + 2] = fmaf(bl.w[k], t.z, val[4 * q + 2]);
+                    val[4 * q + 3] = fmaf(bl.w[k], t.w, val[4 * q + 3]);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < D; ++c) acc[c] = fmaf(aw, val[c], acc[c]);
+        }
+    }
+    // same reduce-scatter as msda_fwd_kernel
+    int n = D, step = 0;
+#pragma unroll
+    for (int m = 1, nn = D; nn > 1; m <<= 1, nn >>= 1) {
+        if (step < logG) {
+            const bool upper = (gl & m) != 0;
+            const int hn = nn / 2;
+#pragma unroll
+            for (int c = 0; c < hn; ++c) {
+                const float send = upper ? acc[c] : acc[c + hn];
+                const float keep = upper ? acc[c + hn] : acc[c];
+                acc[c] = keep + __shfl_xor(send, m, 64);
+            }
+            n = hn;
+            ++step;
+        }
+    }
+    for (int m = 1 << step; m < G; m <<= 1) {
+#pragma unroll
+        for (int c = 0; c < D; ++c)
+            if (c < n) acc[c] += __shfl_xor(acc[c], m, 64);
+    }
+    if (!live) return;
+    if ((gl >> step) == 0) {
+        int base = 0, len = D;
+        for (int i = 0; i < step; ++i) { len >>= 1; if (gl & (1 << i)) base += len; }
+        float *o = out + (size_t)gq * D + base;
+#pragma unroll
+        for (int c = 0; c < D; ++c)
+            if (c < n) o[c] = acc[c];
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // backward.  Phase 1: lane per sampling point (no cross-lane reduction): the 4 corner . g_out
 // dot products give grad_attw and grad_loc (coalesced per-point stores).  Phase 2: the
@@ -444,6 +571,38 @@ extern "C" int selfocc_msda_fwd(const float *value, const int32_t *shapes, const
 #define SO_LAUNCH(DD)                                                                             \
     hipLaunchKernelGGL((msda_fwd_kernel<DD>), dim3((unsigned)blocks), dim3(256), 0, st, value,    \
                        shapes, starts, loc, attw, out, dm, G, logG)
+    switch (d) {
+        case 4: SO_LAUNCH(4); break;
+        case 8: SO_LAUNCH(8); break;
+        case 16: SO_LAUNCH(16); break;
+        default: SO_LAUNCH(32); break;
+    }
+#undef SO_LAUNCH
+    return so_launch_status();
+}
+
+
+extern "C" int selfocc_msda_fused_fwd(const float *value, const int32_t *shapes, const int32_t *starts,
+                                      const float *ref, int32_t ref_kind, const float *off_raw, const float *logits,
+                                      float *out, int32_t bs, int32_t nv, int32_t nq, int32_t heads, int32_t d,
+                                      int32_t L, int32_t P, void *stream) {
+    if (validate(value, shapes, starts, off_raw, logits, bs, nv, nq, heads, d, L, P)) return -1;
+    const long long n_groups = (long long)bs * nq * heads;
+    if (n_groups == 0) return 0;
+    SO_REQUIRE(out != nullptr && ref != nullptr, "msda_fused_fwd: NULL pointer");
+    SO_REQUIRE(ref_kind >= 0 && ref_kind <= 2, "msda_fused_fwd: ref_kind must be 0, 1 or 2");
+    const int LP = L * P;
+    SO_REQUIRE(LP <= 256, "msda_fused_fwd: L * P must be <= 256 (got %d); use the unfused op", LP);
+    int G = 1, logG = 0;
+    while (G < LP && G < 64) { G <<= 1; ++logG; }
+    const int gpb = 256 / G;
+    const long long blocks = (n_groups + gpb - 1) / gpb;
+    SO_REQUIRE(blocks < (1LL << 31), "msda_fused_fwd: grid too large");
+    MsdaDims dm{bs, nv, nq, heads, L, P};
+    hipStream_t st = (hipStream_t)stream;
+#define SO_LAUNCH(DD)                                                                                   \
+    hipLaunchKernelGGL((msda_fused_fwd_kernel<DD>), dim3((unsigned)blocks), dim3(256), 0, st, value,    \
+                       shapes, starts, ref, ref_kind, off_raw, logits, out, dm, G, logG)
     switch (d) {
         case 4: SO_LAUNCH(4); break;
         case 8: SO_LAUNCH(8); break;

@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from ..registry import MODELS
-from ..msda import MultiScaleDeformableAttnFunction
+from ..msda import MultiScaleDeformableAttnFunction, msda_fused_inference
 
 
 class BaseModule(nn.Module):
@@ -105,12 +105,18 @@ def deformable_sampling(module, query, value, reference_points, spatial_shapes, 
     value = value.view(bs, num_value, module.num_heads, -1)
     off = module.sampling_offsets(query).view(bs, num_query, module.num_heads, module.num_levels,
                                               module.num_points, 2)
-    aw = module.attention_weights(query).view(bs, num_query, module.num_heads,
-                                              module.num_levels * module.num_points).softmax(-1)
-    aw = aw.view(bs, num_query, module.num_heads, module.num_levels, module.num_points)
     if reference_points.shape[-1] != 2:
         raise ValueError('Last dim of reference_points must be 2 on the SelfOcc path, '
                          f'got {reference_points.shape[-1]}')
+    LP = module.num_levels * module.num_points
+    if not torch.is_grad_enabled() and LP <= 256:
+        # inference: softmax + sampling-location prologue fused into the HIP kernel (no loc / weight tensors)
+        logits = module.attention_weights(query).view(bs, num_query, module.num_heads, LP)
+        kind = {'level': 0, 'point': 1, 'level_point': 2}[per_level_reference]
+        return msda_fused_inference(value, spatial_shapes, level_start_index, reference_points, kind, off, logits)
+    aw = module.attention_weights(query).view(bs, num_query, module.num_heads,
+                                              module.num_levels * module.num_points).softmax(-1)
+    aw = aw.view(bs, num_query, module.num_heads, module.num_levels, module.num_points)
     normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
     if per_level_reference == 'level_point':      # (bs, nq, L, P, 2)
         ref = reference_points[:, :, None, :, :, :]

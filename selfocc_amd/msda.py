@@ -82,3 +82,25 @@ def multi_scale_deformable_attn(value, spatial_shapes, level_start_index, sampli
                                 attention_weights):
     return MultiScaleDeformableAttnFunction.apply(value, spatial_shapes, level_start_index,
                                                   sampling_locations, attention_weights, 64)
+
+
+def msda_fused_inference(value, spatial_shapes, level_start_index, reference_points, ref_kind, sampling_offsets,
+                         attention_logits):
+    """Inference-only fused op (no autograd): value (bs,nv,h,d); reference_points per ``ref_kind``
+    (0: (bs,nq,L,2), 1: (bs,nq,P,2), 2: (bs,nq,L,P,2)); sampling_offsets (bs,nq,h,L,P,2) raw linear
+    output; attention_logits (bs,nq,h,L*P) before softmax.  Returns (bs, nq, h*d)."""
+    if not value.is_cuda:
+        raise RuntimeError("msda_fused_inference needs CUDA(HIP) tensors: selfocc_amd has no CPU fallback")
+    bs, nv, heads, d = value.shape
+    _, nq, _, L, P, _ = sampling_offsets.shape
+    value = value.contiguous().float()
+    off = sampling_offsets.contiguous().float()
+    lg = attention_logits.contiguous().float()
+    ref = reference_points.contiguous().float()
+    sh = spatial_shapes.to(device=value.device, dtype=torch.int32).contiguous()
+    st = level_start_index.to(device=value.device, dtype=torch.int32).contiguous()
+    out = torch.empty(bs, nq, heads * d, device=value.device, dtype=torch.float32)
+    check(lib().selfocc_msda_fused_fwd(ptr(value), ptr(sh), ptr(st), ptr(ref), int(ref_kind), ptr(off), ptr(lg),
+                                       ptr(out), bs, nv, nq, heads, d, L, P, current_stream(value.device)),
+          "selfocc_msda_fused_fwd")
+    return out

@@ -76,3 +76,26 @@ def test_msda_bwd_lds_privatised_levels(hip):
     assert torch.allclose(v.grad.cpu(), gv, rtol=1e-4, atol=2e-4)
     assert torch.allclose(aw.grad.cpu(), ga, rtol=1e-4, atol=1e-5)
     assert torch.allclose(lc.grad.cpu(), gl, rtol=1e-3, atol=1e-4)
+
+
+@pytest.mark.parametrize("kind,P,L", [(0, 4, 3), (1, 8, 4), (1, 48, 4), (2, 12, 3), (2, 70, 3)])
+def test_msda_fused_prologue_matches_unfused(hip, kind, P, L):
+    """selfocc_msda_fused_fwd (softmax + ref + off / (W, H) in-kernel) == torch prologue + plain op"""
+    from selfocc_amd.msda import msda_fused_inference
+    g = torch.Generator().manual_seed(kind * 100 + P)
+    shapes = torch.tensor([[24, 50], [12, 25], [6, 13], [3, 7]][:L])
+    starts = torch.cat([torch.zeros(1, dtype=torch.int64), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    nv = int((shapes[:, 0] * shapes[:, 1]).sum())
+    bs, nq, H, D = 2, 137, 6, 16
+    value = torch.randn(bs, nv, H, D, generator=g)
+    off = torch.randn(bs, nq, H, L, P, 2, generator=g) * 3
+    logits = torch.randn(bs, nq, H, L * P, generator=g) * 2
+    ref = torch.rand(*{0: (bs, nq, L, 2), 1: (bs, nq, P, 2), 2: (bs, nq, L, P, 2)}[kind], generator=g)
+    d = torch.device("cuda:0")
+    got = msda_fused_inference(value.to(d), shapes.to(d), starts.to(d), ref.to(d), kind, off.to(d), logits.to(d))
+    normalizer = torch.stack([shapes[..., 1], shapes[..., 0]], -1).float()
+    r = ref[:, :, None, :, None, :] if kind == 0 else (ref[:, :, None, None, :, :] if kind == 1 else ref[:, :, None, :, :, :])
+    loc = r + off / normalizer[None, None, None, :, None, :]
+    aw = logits.softmax(-1).view(bs, nq, H, L, P)
+    want = oracle.msda_fwd(value, shapes, starts, loc.contiguous(), aw.contiguous())
+    assert torch.allclose(got.cpu(), want, rtol=1e-4, atol=1e-5)
