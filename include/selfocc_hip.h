@@ -17,13 +17,14 @@
 #ifndef SELFOCC_HIP_H
 #define SELFOCC_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define SELFOCC_ABI_VERSION 6
+#define SELFOCC_ABI_VERSION 7
 
 int selfocc_abi_version(void);
 const char *selfocc_last_error(void);
@@ -187,11 +188,21 @@ int selfocc_msda_bwd(const float *value, const int32_t *shapes, const int32_t *s
                      int32_t bs, int32_t nv, int32_t nq, int32_t heads, int32_t d,
                      int32_t L, int32_t P, void *stream);
 
-/* Optional hint for the NEXT selfocc_msda_bwd call of the calling thread: a HOST copy of `shapes`
- * (L, 2).  With it the backward privatises the coarse pyramid levels in LDS (far less atomic
- * contention); without it (or L > 8) the plain kernel runs.  Results are identical up to float
- * summation order.  Pass NULL to clear. */
-int selfocc_msda_bwd_plan(const int32_t *host_shapes, int32_t L);
+/* Banded (output-stationary) backward, same results as selfocc_msda_bwd up to summation order
+ * (grad_value is accumulated in double precision and rounded once).  A block owns a band of rows
+ * of one level's map of one (batch, head) in LDS and adds every sampling point that touches it
+ * with ds_add_f64 — no global atomics in the scatter.  Needs a HOST copy of `shapes` (L, 2) for
+ * the work decomposition (L <= 8) and a 16-byte aligned device workspace of
+ * selfocc_msda_bwd_banded_workspace(...) bytes (2 bytes per sampling point, contents undefined
+ * before and after).  g_value must be zero-initialised by the caller.  Falls back to
+ * selfocc_msda_bwd when a level is wider than the LDS tile or the maps are huge relative to the
+ * number of points. */
+size_t selfocc_msda_bwd_banded_workspace(int32_t bs, int32_t nq, int32_t heads, int32_t L, int32_t P);
+int selfocc_msda_bwd_banded(const float *value, const int32_t *shapes, const int32_t *starts,
+                            const int32_t *host_shapes, const float *loc, const float *attw,
+                            const float *g_out, float *g_value, float *g_loc, float *g_attw,
+                            int32_t bs, int32_t nv, int32_t nq, int32_t heads, int32_t d,
+                            int32_t L, int32_t P, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Dense SDF / semantic query on a regular metre lattice + Occ3D occupancy tail.

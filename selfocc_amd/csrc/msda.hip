@@ -21,6 +21,7 @@
 //     point (lane-local, coalesced stores) and grad_value is scattered with hardware
 //     float atomics (global_atomic_add_f32).
 #include "so_device.h"
+#include <algorithm>
 
 namespace {
 
@@ -34,6 +35,7 @@ struct Bilin {
     float w[4];        // bilinear weights, 0 for out-of-map corners
     float lh, lw, hh, hw;
     bool valid[4];
+    int h_low, w_low;  // floor(h_im), floor(w_im) (may be -1)
 };
 
 SO_DEVFN Bilin so_bilinear_setup(float lx, float ly, int Hl, int Wl, int pix_stride) {
@@ -44,6 +46,7 @@ SO_DEVFN Bilin so_bilinear_setup(float lx, float ly, int Hl, int Wl, int pix_str
     const float fh = floorf(h_im), fw = floorf(w_im);
     const int h_low = (int)fh, w_low = (int)fw;
     const int h_high = h_low + 1, w_high = w_low + 1;
+    r.h_low = h_low; r.w_low = w_low;
     r.lh = h_im - fh; r.lw = w_im - fw;
     r.hh = 1.0f - r.lh; r.hw = 1.0f - r.lw;
     r.valid[0] = r.any && h_low >= 0 && w_low >= 0;
@@ -457,132 +460,278 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(const float *__restrict__
 
 
 // ---------------------------------------------------------------------------------------
-// backward, LDS-privatised variant for the coarse pyramid levels.  In the lifter's cross
-// attention every level receives the same number of sampling points, so the 12x25 / 24x50 maps
-// take ~2300 / ~580 float atomics PER ADDRESS per call (6.8 ms per call, 52 % of a nuscenes_occ
-// training iteration in profiles/r1_f_train_iteration.txt).  Here a block owns one (batch, head)
-// and a chunk of queries, accumulates the levels that fit its LDS budget with ds_add_f32 and
-// flushes each tile once with coalesced global atomics; the fine levels keep global atomics.
+// backward, banded (output-stationary) form.
+//
+// grad_value is 64 scattered float adds per sampling point (4 corners x 16 channels): 1.6 G adds per
+// call at the nuscenes_occ hw-plane shape, ~110 per output element and ~2300 per element on the
+// 12x25 level.  Measured on MI355X (scripts/micro/atomics2.hip): global_atomic_add_f32 sustains
+// ~330 G lane-ops/s chip-wide (one dword per L2 channel per clock; ~90 G/s when the rows of one
+// instruction share a line), ds_add_f32 only ~200 G/s (~3 clocks per LANE), but ds_add_f64 runs
+// at 3.7 T lane-ops/s.  So the scatter goes through LDS in double precision, and to make every
+// add an LDS add the work is split by OUTPUT: a block owns a band of rows of one level's map of one
+// (batch, head), keeps it in LDS as f64, and looks only at the sampling points that touch the band.
+//
+//   kernel 1 (points):  lane per sampling point; channel teams gather the 4 corners (as in the
+//       forward), dot them with g_out -> grad_attw / grad_loc; also writes a 2-byte key per point
+//       (the corner row floor(h_im), or "outside") into keys[b][h][l][q][p].
+//   kernel 2 (bands):   block = (b, h, level, row band, query chunk).  Streams the level's keys
+//       (2 bytes per point instead of 12), compacts the hits into a wave-private LDS ring, and for
+//       every 64 hits: lanes rebuild the bilinear weights of their own point, then 16-lane rows
+//       (one channel per lane) add w * attw * g_out into the band with ds_add_f64.  The band is
+//       flushed once (float atomics only so that query chunks of one band can share it).
+// Besides the rate, f64 accumulation makes a band's sums order-independent to ~1e-16 relative (only the
+// float flush of several query chunks into one band is order-dependent).
 // ---------------------------------------------------------------------------------------
-struct MsdaLdsPlan {
-    int off[8];       // float offset of level l's tile in LDS, -1 = not privatised
-    int total;        // floats
-    int q_per_block, n_chunks;
-};
+constexpr int kKeyOutside = -32768;
+
+template <int QL>
+SO_DEVFN float so_team_sum(float x) {   // sum over the QL lanes of a channel team, result in every lane
+    if constexpr (QL >= 2)
+        x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0xB1, 0xf, 0xf, true));  // [1,0,3,2]
+    if constexpr (QL >= 4)
+        x += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x4E, 0xf, 0xf, true));  // [2,3,0,1]
+    if constexpr (QL >= 8) x += __shfl_xor(x, 4, 64);
+    return x;
+}
+
+// team step I: the team computes value(corner k) . g_out for the point owned by its sub-lane I
+template <int D, int I>
+SO_DEVFN void so_bwd_team_step(const float *__restrict__ value, const float *__restrict__ g_out, int s,
+                               const int (&goff)[4], int gq32, float (&dot)[4]) {
+    constexpr int QL = D / 4;
+    const int gqi = so_team_bcast<QL, I>(gq32);
+    const float4 go = *(const float4 *)(g_out + (size_t)gqi * D + 4 * s);
+    float part[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int off = so_team_bcast<QL, I>(goff[k]);
+        const float4 t = *(const float4 *)(value + off + 4 * s);
+        part[k] = t.x * go.x;
+        part[k] = fmaf(t.y, go.y, part[k]);
+        part[k] = fmaf(t.z, go.z, part[k]);
+        part[k] = fmaf(t.w, go.w, part[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float d = so_team_sum<QL>(part[k]);
+        if (s == I) dot[k] = d;
+    }
+}
 
 template <int D>
-__global__ __launch_bounds__(512) void msda_bwd_tiled_kernel(const float *__restrict__ value,
+__global__ __launch_bounds__(256) void msda_bwd_point_kernel(const float *__restrict__ value,
                                                              const int32_t *__restrict__ shapes,
                                                              const int32_t *__restrict__ starts,
                                                              const float *__restrict__ loc,
                                                              const float *__restrict__ attw,
                                                              const float *__restrict__ g_out,
-                                                             float *__restrict__ g_value, float *__restrict__ g_loc,
-                                                             float *__restrict__ g_attw, MsdaDims dm, MsdaLdsPlan plan) {
-    extern __shared__ __attribute__((aligned(16))) float tile[];
+                                                             float *__restrict__ g_loc, float *__restrict__ g_attw,
+                                                             int16_t *__restrict__ keys, MsdaDims dm) {
+    constexpr int QL = D / 4;
     const int LP = dm.L * dm.P;
-    const int chunk = blockIdx.x % plan.n_chunks;
-    const int bh = blockIdx.x / plan.n_chunks;
-    const int h = bh % dm.heads, b = bh / dm.heads;
-    const int q0 = chunk * plan.q_per_block;
-    const int nq_here = min(plan.q_per_block, dm.nq - q0);
+    const long long n_pts = (long long)dm.bs * dm.nq * dm.heads * LP;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = idx < n_pts;
+    const long long idc = live ? idx : n_pts - 1;
+    long long gq;
+    int pt;
+    if (n_pts < (1LL << 31)) {   // uniform: 32-bit division
+        const unsigned g = (unsigned)idc / (unsigned)LP;
+        gq = g;
+        pt = (int)((unsigned)idc - g * (unsigned)LP);
+    } else {
+        gq = idc / LP;
+        pt = (int)(idc - gq * LP);
+    }
+    int h, b;
+    long long bq;
+    so_split_group(gq, n_pts, dm.nq, dm.heads, h, b, bq);
+    const int l = so_level_of(pt, dm.P, dm.L);
+    const int Hl = shapes[2 * l], Wl = shapes[2 * l + 1];
     const int pix_stride = dm.heads * D;
-    for (int e = threadIdx.x; e < plan.total; e += blockDim.x) tile[e] = 0.0f;
+    const float2 xy = *(const float2 *)(loc + 2 * idc);
+    const float aw = attw[idc];
+    const Bilin bl = so_bilinear_setup(xy.x, xy.y, Hl, Wl, pix_stride);
+    const int vbase = (int)((((long long)b * dm.nv + starts[l]) * dm.heads + h) * D);  // < 2^31 (validated)
+    int goff[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) goff[k] = vbase + bl.off[k];
+    const int s = threadIdx.x & (QL - 1);
+    float dot[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    so_bwd_team_step<D, 0>(value, g_out, s, goff, (int)gq, dot);
+    if constexpr (QL > 1) so_bwd_team_step<D, 1>(value, g_out, s, goff, (int)gq, dot);
+    if constexpr (QL > 2) {
+        so_bwd_team_step<D, 2>(value, g_out, s, goff, (int)gq, dot);
+        so_bwd_team_step<D, 3>(value, g_out, s, goff, (int)gq, dot);
+    }
+    if constexpr (QL > 4) {
+        so_bwd_team_step<D, 4>(value, g_out, s, goff, (int)gq, dot);
+        so_bwd_team_step<D, 5>(value, g_out, s, goff, (int)gq, dot);
+        so_bwd_team_step<D, 6>(value, g_out, s, goff, (int)gq, dot);
+        so_bwd_team_step<D, 7>(value, g_out, s, goff, (int)gq, dot);
+    }
+    if (!live) return;
+    float ga = 0.0f, gx = 0.0f, gy = 0.0f;
+    if (bl.any) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dot[k] = bl.valid[k] ? dot[k] : 0.0f;
+        // d out / d attw = bilinear value . g_out ;  d / d (w_im, h_im) from the weight derivatives
+        ga = (bl.w[0] * dot[0] + bl.w[1] * dot[1]) + (bl.w[2] * dot[2] + bl.w[3] * dot[3]);
+        const float gw = (bl.hh * (dot[1] - dot[0])) + (bl.lh * (dot[3] - dot[2]));
+        const float gh = (bl.hw * (dot[2] - dot[0])) + (bl.lw * (dot[3] - dot[1]));
+        gx = (float)Wl * gw * aw;
+        gy = (float)Hl * gh * aw;
+    }
+    g_attw[idx] = ga;
+    *(float2 *)(g_loc + 2 * idx) = make_float2(gx, gy);
+    const int q = (int)(bq - (long long)b * dm.nq);
+    const int p = pt - l * dm.P;
+    keys[((((size_t)b * dm.heads + h) * dm.L + l) * dm.nq + q) * dm.P + p] = (int16_t)(bl.any ? bl.h_low : kKeyOutside);
+}
+
+struct MsdaBandPlan {
+    int rows[8];      // rows per band of level l
+    int bands[8];     // bands of level l
+    int chunks[8];    // query chunks per band of level l
+    int prefix[9];    // first work item of level l within a (batch, head)
+    int items;        // work items per (batch, head)
+};
+
+constexpr int kBandThreads = 512;
+constexpr int kBandTileBytes = 52 * 1024;
+
+template <int D>
+__global__ __launch_bounds__(kBandThreads) void msda_bwd_band_kernel(const int32_t *__restrict__ shapes,
+                                                                     const int32_t *__restrict__ starts,
+                                                                     const float *__restrict__ loc,
+                                                                     const float *__restrict__ attw,
+                                                                     const float *__restrict__ g_out,
+                                                                     float *__restrict__ g_value,
+                                                                     const int16_t *__restrict__ keys, MsdaDims dm,
+                                                                     MsdaBandPlan plan) {
+    constexpr int ROWS = 64 / D;        // sampling points served per atomic instruction
+    constexpr int NJ = 64 / ROWS;       // row steps per batch of 64 points (= D)
+    extern __shared__ __attribute__((aligned(16))) double tile[];
+    __shared__ int ring[kBandThreads / 64][128];
+    __shared__ int4 recP[kBandThreads];
+    __shared__ float4 recW[kBandThreads];
+    __shared__ int recQ[kBandThreads];
+
+    const int bh = blockIdx.x / plan.items, item = blockIdx.x - bh * plan.items;
+    const int h = bh % dm.heads, b = bh / dm.heads;
+    int l = 0;
+    for (int k = 1; k < dm.L; ++k) l += (item >= plan.prefix[k]);
+    int rows_l = plan.rows[0], chunks_l = plan.chunks[0], first = 0;
+    for (int k = 1; k < 8; ++k)
+        if (k == l) { rows_l = plan.rows[k]; chunks_l = plan.chunks[k]; first = plan.prefix[k]; }
+    const int r = item - first;
+    const int band = r / chunks_l, chunk = r - band * chunks_l;
+    const int Hl = shapes[2 * l], Wl = shapes[2 * l + 1];
+    const int y0 = band * rows_l, y1 = min(Hl, y0 + rows_l);
+    const int n_tile = (y1 - y0) * Wl * D;
+    const int qper = (dm.nq + chunks_l - 1) / chunks_l;
+    const int qa = min(dm.nq, chunk * qper), qb = min(dm.nq, qa + qper);
+    const int LP = dm.L * dm.P;
+
+    for (int e = threadIdx.x; e < n_tile; e += kBandThreads) tile[e] = 0.0;
     __syncthreads();
 
-    const int lane = threadIdx.x & 63;
-    constexpr int PPI = 64 / D;
-    const int sub = lane % D, grp = lane / D;
-    const int n_local = nq_here * LP;
-    for (int base = 0; base < n_local; base += blockDim.x) {       // uniform trip count per block
-        const int e = base + threadIdx.x;
-        const bool live = e < n_local;
-        const int ec = live ? e : n_local - 1;
-        const int q = q0 + ec / LP, pt = ec % LP;
-        const long long gq = ((long long)b * dm.nq + q) * dm.heads + h;
-        const long long idx = gq * LP + pt;
-        const int l = so_level_of(pt, dm.P, dm.L);
-        const int Hl = shapes[2 * l], Wl = shapes[2 * l + 1];
-        const float2 xy = *(const float2 *)(loc + 2 * idx);
-        const float aw = attw[idx];
-        const Bilin bl = so_bilinear_setup(xy.x, xy.y, Hl, Wl, 1);   // pixel indices (stride 1)
-        const int vbase = (int)((((long long)b * dm.nv + starts[l]) * dm.heads + h) * D);
-        float ga = 0.0f, gx = 0.0f, gy = 0.0f;
-        float wsc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (live && bl.any) {
-            const float *vl = value + vbase;
-            float go[D];
-            const float4 *gp = (const float4 *)(g_out + (size_t)gq * D);
-#pragma unroll
-            for (int qq = 0; qq < D / 4; ++qq) {
-                const float4 t = gp[qq];
-                go[4 * qq] = t.x; go[4 * qq + 1] = t.y; go[4 * qq + 2] = t.z; go[4 * qq + 3] = t.w;
-            }
-            float dot[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wave0 = threadIdx.x & ~63;
+    const int sub = lane % D, row = lane / D;
+    int head = 0, tail = 0;   // wave-uniform ring cursors
+
+    // the 64 (or n < 64) oldest hits of this wave's ring -> band
+    auto process = [&](int n) {
+        float4 w4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        int4 p4 = make_int4(0, 0, 0, 0);
+        int gq32 = 0;
+        if (lane < n) {
+            const int e = ring[wv][(head + lane) & 127];
+            const int q = e / dm.P, p = e - q * dm.P;
+            const long long gq = ((long long)b * dm.nq + q) * dm.heads + h;
+            const long long idx = gq * LP + l * dm.P + p;
+            const float2 xy = *(const float2 *)(loc + 2 * idx);
+            const float aw = attw[idx];
+            const Bilin bl = so_bilinear_setup(xy.x, xy.y, Hl, Wl, 1);
+            float wk[4];
+            int pk[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                dot[k] = 0.0f;
-                if (bl.valid[k]) {
-                    const float4 *p = (const float4 *)(vl + (size_t)bl.off[k] * pix_stride);
-                    wsc[k] = bl.w[k] * aw;
+                const int ry = bl.h_low + (k >> 1), cx = bl.w_low + (k & 1);
+                const bool in = bl.valid[k] && ry >= y0 && ry < y1;
+                pk[k] = in ? ((ry - y0) * Wl + cx) * D : 0;
+                wk[k] = in ? bl.w[k] * aw : 0.0f;
+            }
+            w4 = make_float4(wk[0], wk[1], wk[2], wk[3]);
+            p4 = make_int4(pk[0], pk[1], pk[2], pk[3]);
+            gq32 = (int)gq;
+        }
+        recW[threadIdx.x] = w4;
+        recP[threadIdx.x] = p4;
+        recQ[threadIdx.x] = gq32;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        float goc[NJ];
 #pragma unroll
-                    for (int qq = 0; qq < D / 4; ++qq) {
-                        const float4 t = p[qq];
-                        dot[k] = fmaf(t.x, go[4 * qq], dot[k]);
-                        dot[k] = fmaf(t.y, go[4 * qq + 1], dot[k]);
-                        dot[k] = fmaf(t.z, go[4 * qq + 2], dot[k]);
-                        dot[k] = fmaf(t.w, go[4 * qq + 3], dot[k]);
-                    }
+        for (int j = 0; j < NJ; ++j) goc[j] = g_out[(size_t)recQ[wave0 + j * ROWS + row] * D + sub];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int src = wave0 + j * ROWS + row;
+            const float4 ws = recW[src];
+            const int4 ps = recP[src];
+            if (ws.x != 0.0f) unsafeAtomicAdd(&tile[ps.x + sub], (double)(ws.x * goc[j]));
+            if (ws.y != 0.0f) unsafeAtomicAdd(&tile[ps.y + sub], (double)(ws.y * goc[j]));
+            if (ws.z != 0.0f) unsafeAtomicAdd(&tile[ps.z + sub], (double)(ws.z * goc[j]));
+            if (ws.w != 0.0f) unsafeAtomicAdd(&tile[ps.w + sub], (double)(ws.w * goc[j]));
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    // stream this level's keys of the chunk's queries, 8 keys (16 bytes) per lane and step
+    const long long kbase = (((long long)b * dm.heads + h) * dm.L + l) * (long long)dm.nq * dm.P;
+    const long long lo = kbase + (long long)qa * dm.P, hi = kbase + (long long)qb * dm.P;
+    const int klo = y0 - 1, khi = y1 - 1;
+    const int4 none = make_int4((int)0x80008000, (int)0x80008000, (int)0x80008000, (int)0x80008000);
+    const long long step = (long long)kBandThreads * 8;
+    long long pos = (lo & ~7LL) + (long long)threadIdx.x * 8;
+    int4 cur = (pos < hi) ? *(const int4 *)(keys + pos) : none;
+    for (long long bp = (lo & ~7LL); bp < hi; bp += step) {   // uniform trip count
+        const int4 nxt = (pos + step < hi) ? *(const int4 *)(keys + pos + step) : none;
+        const unsigned long long k03 = ((unsigned long long)(unsigned)cur.y << 32) | (unsigned)cur.x;
+        const unsigned long long k47 = ((unsigned long long)(unsigned)cur.w << 32) | (unsigned)cur.z;
+#pragma unroll 1
+        for (int k = 0; k < 8; ++k) {   // not unrolled: process() is large
+            const int key = (int)(short)(((k & 4) ? k47 : k03) >> (16 * (k & 3)));
+            const long long gi = pos + k;
+            const bool hit = key >= klo && key <= khi && gi >= lo && gi < hi;
+            const unsigned long long m = __ballot(hit);
+            if (m != 0ULL) {   // uniform
+                if (hit) ring[wv][(tail + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))) & 127] = (int)(gi - kbase);
+                tail += __popcll(m);
+                if (tail - head >= 64) {
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    process(64);
+                    head += 64;
                 }
             }
-            ga = (bl.w[0] * dot[0] + bl.w[1] * dot[1]) + (bl.w[2] * dot[2] + bl.w[3] * dot[3]);
-            const float gw = (bl.hh * (dot[1] - dot[0])) + (bl.lh * (dot[3] - dot[2]));
-            const float gh = (bl.hw * (dot[2] - dot[0])) + (bl.lw * (dot[3] - dot[1]));
-            gx = (float)Wl * gw * aw;
-            gy = (float)Hl * gh * aw;
         }
-        if (live) {
-            g_attw[idx] = ga;
-            *(float2 *)(g_loc + 2 * idx) = make_float2(gx, gy);
-        }
-        // transposed scatter: D lanes own the D channels of one point's corner
-        const int gq32 = (int)gq;
-        const int toff = plan.off[l];                               // -1: global atomics
-        for (int j = 0; j < 64 / PPI; ++j) {
-            const int src = j * PPI + grp;
-            const int q_src = __shfl(gq32, src, 64);
-            const int t_src = __shfl(toff, src, 64);
-            const int vb_src = __shfl(vbase, src, 64);
-            float w_src[4];
-            int p_src[4];
-            bool any = false;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                w_src[k] = __shfl(wsc[k], src, 64);
-                p_src[k] = __shfl(bl.off[k], src, 64);
-                any |= (w_src[k] != 0.0f);
-            }
-            if (any) {
-                const float goc = g_out[(size_t)q_src * D + sub];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    if (w_src[k] == 0.0f) continue;
-                    if (t_src >= 0) atomicAdd(&tile[t_src + p_src[k] * D + sub], w_src[k] * goc);
-                    else unsafeAtomicAdd(g_value + vb_src + p_src[k] * pix_stride + sub, w_src[k] * goc);
-                }
-            }
-        }
+        cur = nxt;
+        pos += step;
+    }
+    if (tail > head) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        process(tail - head);
     }
     __syncthreads();
-    // flush the privatised levels: consecutive lanes = consecutive channels of consecutive pixels
-    for (int l = 0; l < dm.L; ++l) {
-        if (plan.off[l] < 0) continue;
-        const int n = shapes[2 * l] * shapes[2 * l + 1] * D;
-        float *gl = g_value + (((size_t)b * dm.nv + starts[l]) * dm.heads + h) * D;
-        for (int e = threadIdx.x; e < n; e += blockDim.x) {
-            const float v = tile[plan.off[l] + e];
-            if (v != 0.0f) unsafeAtomicAdd(gl + (size_t)(e / D) * pix_stride + (e % D), v);
-        }
+
+    // flush: consecutive lanes = consecutive channels of consecutive pixels of the band
+    const int pix_stride = dm.heads * D;
+    float *gl = g_value + (((size_t)b * dm.nv + starts[l] + (size_t)y0 * Wl) * dm.heads + h) * D;
+    for (int e = threadIdx.x; e < n_tile; e += kBandThreads) {
+        const double v = tile[e];
+        if (v != 0.0) unsafeAtomicAdd(gl + (size_t)(e / D) * pix_stride + (e % D), (float)v);
     }
 }
 
@@ -599,21 +748,6 @@ int validate(const float *value, const int32_t *shapes, const int32_t *starts, c
 }
 
 }  // namespace
-
-// Host copy of the level shapes of the NEXT selfocc_msda_bwd call of this thread (optional): lets the
-// backward choose which pyramid levels to privatise in LDS without reading device memory.
-static thread_local int g_plan_shapes[16];
-static thread_local int g_plan_L = 0;
-static thread_local bool g_plan_valid = false;
-
-extern "C" int selfocc_msda_bwd_plan(const int32_t *host_shapes, int32_t L) {
-    g_plan_valid = false;
-    if (host_shapes == nullptr || L < 1 || L > 8) return 0;
-    for (int i = 0; i < 2 * L; ++i) g_plan_shapes[i] = host_shapes[i];
-    g_plan_L = L;
-    g_plan_valid = true;
-    return 0;
-}
 
 extern "C" int selfocc_msda_fwd(const float *value, const int32_t *shapes, const int32_t *starts,
                                 const float *loc, const float *attw, float *out, int32_t bs,
@@ -715,37 +849,95 @@ extern "C" int selfocc_msda_bwd(const float *value, const int32_t *shapes, const
     SO_REQUIRE(blocks < (1LL << 31), "msda_bwd: grid too large");
     MsdaDims dm{bs, nv, nq, heads, L, P};
     hipStream_t st = (hipStream_t)stream;
-    // LDS privatisation plan: needs the level shapes on the host (a 32-byte async copy + sync would stall
-    // the stream), so the caller may pass them through selfocc_msda_bwd_plan(); see below
-    if (g_plan_valid && g_plan_L == L && L <= 8 && nq >= 512 && d == 16) {
-        MsdaLdsPlan plan;
-        plan.total = 0;
-        const int budget = 28 * 1024;   // floats: 112 KiB of the CU's 160 KiB LDS
-        for (int l = L - 1; l >= 0; --l) {
-            const int n = g_plan_shapes[2 * l] * g_plan_shapes[2 * l + 1] * d;
-            if (plan.total + n <= budget) { plan.off[l] = plan.total; plan.total += n; }
-            else plan.off[l] = -1;
-        }
-        for (int l = L; l < 8; ++l) plan.off[l] = -1;
-        if (plan.total > 0) {
-            plan.q_per_block = 256;
-            plan.n_chunks = (nq + plan.q_per_block - 1) / plan.q_per_block;
-            const long long tb = (long long)bs * heads * plan.n_chunks;
-            SO_REQUIRE(tb < (1LL << 31), "msda_bwd: grid too large");
-            const size_t shm = (size_t)plan.total * sizeof(float);
-            static bool attr_set = false;
-            if (!attr_set) {
-                (void)hipFuncSetAttribute((const void *)msda_bwd_tiled_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024);
-                attr_set = true;
-            }
-            hipLaunchKernelGGL((msda_bwd_tiled_kernel<16>), dim3((unsigned)tb), dim3(512), shm, st, value, shapes, starts,
-                               loc, attw, g_out, g_value, g_loc, g_attw, dm, plan);
-            return so_launch_status();
-        }
-    }
 #define SO_LAUNCH(DD)                                                                             \
     hipLaunchKernelGGL((msda_bwd_kernel<DD>), dim3((unsigned)blocks), dim3(256), 0, st, value,    \
                        shapes, starts, loc, attw, g_out, g_value, g_loc, g_attw, dm)
+    switch (d) {
+        case 4: SO_LAUNCH(4); break;
+        case 8: SO_LAUNCH(8); break;
+        case 16: SO_LAUNCH(16); break;
+        default: SO_LAUNCH(32); break;
+    }
+#undef SO_LAUNCH
+    return so_launch_status();
+}
+
+
+// ---- banded backward -------------------------------------------------------------------------
+static size_t so_band_ws_bytes(long long n_pts) { return (size_t)((n_pts + 8) * 2 + 15) / 16 * 16; }
+
+extern "C" size_t selfocc_msda_bwd_banded_workspace(int32_t bs, int32_t nq, int32_t heads, int32_t L, int32_t P) {
+    if (bs < 0 || nq < 0 || heads < 1 || L < 1 || P < 1) return 0;
+    return so_band_ws_bytes((long long)bs * nq * heads * L * P);
+}
+
+extern "C" int selfocc_msda_bwd_banded(const float *value, const int32_t *shapes, const int32_t *starts,
+                                       const int32_t *host_shapes, const float *loc, const float *attw,
+                                       const float *g_out, float *g_value, float *g_loc, float *g_attw,
+                                       int32_t bs, int32_t nv, int32_t nq, int32_t heads, int32_t d, int32_t L,
+                                       int32_t P, void *workspace, size_t workspace_bytes, void *stream) {
+    if (validate(value, shapes, starts, loc, attw, bs, nv, nq, heads, d, L, P)) return -1;
+    const long long n_pts = (long long)bs * nq * heads * L * P;
+    if (n_pts == 0) return 0;
+    SO_REQUIRE(g_out && g_value && g_loc && g_attw, "msda_bwd_banded: NULL gradient pointer");
+    SO_REQUIRE(host_shapes != nullptr, "msda_bwd_banded: host_shapes is NULL (host copy of the (L, 2) level shapes)");
+    SO_REQUIRE(L <= 8, "msda_bwd_banded: at most 8 levels (got %d); use selfocc_msda_bwd", L);
+    SO_REQUIRE(workspace != nullptr && workspace_bytes >= so_band_ws_bytes(n_pts),
+               "msda_bwd_banded: workspace too small (%zu bytes, need %zu)", workspace_bytes, so_band_ws_bytes(n_pts));
+    SO_REQUIRE(((uintptr_t)workspace & 15) == 0, "msda_bwd_banded: workspace must be 16-byte aligned");
+    SO_REQUIRE((long long)nq * P < (1LL << 31), "msda_bwd_banded: nq * P must be < 2^31");
+
+    // work decomposition: bands of rows that fit the LDS tile, query chunks to even out the load
+    MsdaBandPlan plan;
+    const int cap_px = kBandTileBytes / (8 * d);
+    long long exam = 0;
+    int max_tile_px = 0, items = 0;
+    bool ok = true;
+    for (int l = 0; l < 8; ++l) { plan.rows[l] = 1; plan.bands[l] = 0; plan.chunks[l] = 1; plan.prefix[l] = 0; }
+    for (int l = 0; l < L; ++l) {
+        const int Hl = host_shapes[2 * l], Wl = host_shapes[2 * l + 1];
+        SO_REQUIRE(Hl >= 0 && Wl >= 0 && Hl < 32767, "msda_bwd_banded: bad level shape (%d, %d)", Hl, Wl);
+        plan.prefix[l] = items;
+        if (Hl == 0 || Wl == 0) continue;
+        if (Wl > cap_px) { ok = false; break; }
+        plan.rows[l] = std::min(Hl, cap_px / Wl);
+        plan.bands[l] = (Hl + plan.rows[l] - 1) / plan.rows[l];
+        const double pts = (double)nq * P;   // points of this level per (batch, head)
+        const double hits = pts * std::min(1.0, (plan.rows[l] + 1.0) / Hl);
+        int ch = (int)(hits / 8192.0 + 0.5);
+        ch = std::max(1, std::min(ch, std::min(nq, 256)));
+        plan.chunks[l] = ch;
+        items += plan.bands[l] * ch;
+        exam += (long long)plan.bands[l] * nq * P;
+        max_tile_px = std::max(max_tile_px, plan.rows[l] * Wl);
+    }
+    for (int l = L; l <= 8; ++l) plan.prefix[l] = items;
+    plan.items = items;
+    hipStream_t st = (hipStream_t)stream;
+    // very large maps with few queries: scanning every band's keys would cost more than the atomics
+    if (!ok || items == 0 || exam > 256LL * L * nq * P || (long long)bs * heads * items >= (1LL << 31))
+        return selfocc_msda_bwd(value, shapes, starts, loc, attw, g_out, g_value, g_loc, g_attw, bs, nv, nq, heads,
+                                d, L, P, stream);
+
+    MsdaDims dm{bs, nv, nq, heads, L, P};
+    int16_t *keys = (int16_t *)workspace;
+    const long long pblocks = (n_pts + 255) / 256;
+    SO_REQUIRE(pblocks < (1LL << 31), "msda_bwd_banded: grid too large");
+    const unsigned bblocks = (unsigned)((long long)bs * heads * items);
+    const size_t shm = (size_t)max_tile_px * d * sizeof(double);
+#define SO_LAUNCH(DD)                                                                                        \
+    {                                                                                                        \
+        static bool attr_set = false;                                                                        \
+        if (!attr_set) {                                                                                     \
+            (void)hipFuncSetAttribute((const void *)msda_bwd_band_kernel<DD>,                                \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kBandTileBytes);           \
+            attr_set = true;                                                                                 \
+        }                                                                                                    \
+        hipLaunchKernelGGL((msda_bwd_point_kernel<DD>), dim3((unsigned)pblocks), dim3(256), 0, st, value,    \
+                           shapes, starts, loc, attw, g_out, g_loc, g_attw, keys, dm);                       \
+        hipLaunchKernelGGL((msda_bwd_band_kernel<DD>), dim3(bblocks), dim3(kBandThreads), shm, st, shapes,   \
+                           starts, loc, attw, g_out, g_value, keys, dm, plan);                               \
+    }
     switch (d) {
         case 4: SO_LAUNCH(4); break;
         case 8: SO_LAUNCH(8); break;

@@ -29,6 +29,11 @@ def _prep(value, spatial_shapes, level_start_index, sampling_locations, attentio
     return value, sh, st, loc, aw, (bs, nv, nq, heads, d, L, P)
 
 
+# 'banded': selfocc_msda_bwd_banded (LDS f64 accumulation, default); 'atomic': selfocc_msda_bwd (global float
+# atomics; what a C caller without host shapes / workspace gets).  Same gradients up to summation order.
+BACKWARD_MODE = 'banded'
+
+
 class MultiScaleDeformableAttnFunction(Function):
 
     @staticmethod
@@ -48,7 +53,7 @@ class MultiScaleDeformableAttnFunction(Function):
               "selfocc_msda_fwd")
         ctx.save_for_backward(value, sh, st, loc, aw)
         ctx.dims = dims
-        # host copy of the level shapes for the backward's LDS-privatisation plan (no device read-back
+        # host copy of the level shapes for the banded backward's work decomposition (no device read-back
         # when the caller hands over CPU / python shapes; one small sync otherwise, in forward only)
         host = getattr(value_spatial_shapes, '_so_host', None)
         if host is None and ctx.needs_input_grad[0]:
@@ -65,16 +70,21 @@ class MultiScaleDeformableAttnFunction(Function):
         g_value = torch.zeros_like(value)
         g_loc = torch.empty_like(loc)
         g_aw = torch.empty_like(aw)
-        if ctx.host_shapes is not None:
+        if ctx.host_shapes is not None and L <= 8 and BACKWARD_MODE == 'banded':
             import ctypes
             arr = (ctypes.c_int32 * len(ctx.host_shapes))(*ctx.host_shapes)
-            lib().selfocc_msda_bwd_plan(ctypes.cast(arr, ctypes.c_void_p), L)
+            nbytes = int(lib().selfocc_msda_bwd_banded_workspace(bs, nq, heads, L, P))
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=value.device)
+            check(lib().selfocc_msda_bwd_banded(ptr(value), ptr(sh), ptr(st), ctypes.cast(arr, ctypes.c_void_p),
+                                                ptr(loc), ptr(aw), ptr(g_out), ptr(g_value), ptr(g_loc), ptr(g_aw),
+                                                bs, nv, nq, heads, d, L, P, ptr(ws), nbytes,
+                                                current_stream(value.device)),
+                  "selfocc_msda_bwd_banded")
         else:
-            lib().selfocc_msda_bwd_plan(None, 0)
-        check(lib().selfocc_msda_bwd(ptr(value), ptr(sh), ptr(st), ptr(loc), ptr(aw), ptr(g_out),
-                                     ptr(g_value), ptr(g_loc), ptr(g_aw),
-                                     bs, nv, nq, heads, d, L, P, current_stream(value.device)),
-              "selfocc_msda_bwd")
+            check(lib().selfocc_msda_bwd(ptr(value), ptr(sh), ptr(st), ptr(loc), ptr(aw), ptr(g_out),
+                                         ptr(g_value), ptr(g_loc), ptr(g_aw),
+                                         bs, nv, nq, heads, d, L, P, current_stream(value.device)),
+                  "selfocc_msda_bwd")
         return g_value, None, None, g_loc, g_aw, None
 
 

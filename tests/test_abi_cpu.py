@@ -12,7 +12,7 @@ HEADER = open(os.path.join(ROOT, "include", "selfocc_hip.h")).read()
 
 
 def test_every_declared_symbol_is_exported_and_mirrored():
-    declared = set(re.findall(r"^\s*(?:int|const char \*)\s*\*?\s*(selfocc_\w+)\s*\(", HEADER, re.M))
+    declared = set(re.findall(r"^\s*(?:int|size_t|const char \*)\s*\*?\s*(selfocc_\w+)\s*\(", HEADER, re.M))
     assert declared == set(abi.SYMBOLS), declared ^ set(abi.SYMBOLS)
     from selfocc_amd._lib import lib
     l = lib()                       # raises if the .so is missing or a symbol is absent

@@ -16,8 +16,11 @@ GPU_CASES = CASES + [
 ]
 
 
+@pytest.mark.parametrize("mode", ["banded", "atomic"])
 @pytest.mark.parametrize("case", GPU_CASES)
-def test_msda_fwd_bwd_vs_oracle(hip, case):
+def test_msda_fwd_bwd_vs_oracle(hip, case, mode, monkeypatch):
+    import selfocc_amd.msda as M
+    monkeypatch.setattr(M, "BACKWARD_MODE", mode)
     value, shapes, starts, loc, attw = make_case(*case, seed=5)
     d = torch.device("cuda:0")
     v = value.to(d).requires_grad_(True); lc = loc.to(d).requires_grad_(True); aw = attw.to(d).requires_grad_(True)
@@ -62,20 +65,42 @@ def test_msda_reference_shapes_properties(hip):
     assert torch.allclose(o1[:1, :500].cpu(), sub, rtol=1e-5, atol=1e-5)
 
 
-def test_msda_bwd_lds_privatised_levels(hip):
-    """nq >= 512 with coarse levels that fit LDS -> the tiled backward kernel; same gradients as the
-    oracle (and as the plain kernel, which the small cases above exercise)."""
-    case = (2, 700, 6, 16, [[24, 50], [12, 25], [6, 13], [3, 7]], 8)
+@pytest.mark.parametrize("case", [
+    (2, 700, 6, 16, [[24, 50], [12, 25], [6, 13], [3, 7]], 8),     # several bands on level 0, one on the rest
+    (1, 3000, 2, 16, [[40, 60], [5, 7]], 8),                       # many bands + query chunks on the 5x7 level
+    (1, 900, 3, 32, [[30, 40], [15, 20]], 4),                      # 32 channels: 2 points per atomic instruction
+    (2, 500, 2, 8, [[30, 40], [15, 20], [8, 10]], 5),              # 8 channels, odd P (keys not 16-byte aligned)
+    (1, 400, 2, 4, [[64, 100]], 3),                                # 4 channels, single level
+])
+def test_msda_bwd_banded_decompositions(hip, case):
+    """banded backward (bands x query chunks x channel widths) == oracle == atomic kernel"""
+    import selfocc_amd.msda as M
     value, shapes, starts, loc, attw = make_case(*case, seed=11)
+    # spread the points beyond the map on every side so that 'outside' keys and partial corners occur
+    loc = (loc - 0.5) * 1.3 + 0.5
     d = torch.device("cuda:0")
-    v = value.to(d).requires_grad_(True); lc = loc.to(d).requires_grad_(True); aw = attw.to(d).requires_grad_(True)
-    out = MultiScaleDeformableAttnFunction.apply(v, shapes.to(d), starts.to(d), lc, aw, 64)
-    g = torch.randn(out.shape, generator=torch.Generator().manual_seed(9))
-    out.backward(g.to(d))
+    grads = {}
+    for mode in ("banded", "atomic"):
+        M.BACKWARD_MODE = mode
+        try:
+            v = value.to(d).requires_grad_(True); lc = loc.to(d).requires_grad_(True); aw = attw.to(d).requires_grad_(True)
+            out = MultiScaleDeformableAttnFunction.apply(v, shapes.to(d), starts.to(d), lc, aw, 64)
+            g = torch.randn(out.shape, generator=torch.Generator().manual_seed(9))
+            out.backward(g.to(d))
+            grads[mode] = (v.grad.cpu(), lc.grad.cpu(), aw.grad.cpu())
+        finally:
+            M.BACKWARD_MODE = "banded"
     gv, gl, ga = oracle.msda_bwd(value, shapes, starts, loc, attw, g)
-    assert torch.allclose(v.grad.cpu(), gv, rtol=1e-4, atol=2e-4)
-    assert torch.allclose(aw.grad.cpu(), ga, rtol=1e-4, atol=1e-5)
-    assert torch.allclose(lc.grad.cpu(), gl, rtol=1e-3, atol=1e-4)
+    for mode, (v_g, l_g, a_g) in grads.items():
+        assert torch.allclose(v_g, gv, rtol=1e-4, atol=2e-4), mode
+        assert torch.allclose(a_g, ga, rtol=1e-4, atol=1e-5), mode
+        assert torch.allclose(l_g, gl, rtol=1e-3, atol=1e-4), mode
+    # f64 accumulation inside a band: run-to-run differences only from the float flush of query chunks
+    M.BACKWARD_MODE = "banded"
+    v = value.to(d).requires_grad_(True)
+    out = MultiScaleDeformableAttnFunction.apply(v, shapes.to(d), starts.to(d), loc.to(d), attw.to(d), 64)
+    out.backward(g.to(d))
+    assert torch.allclose(v.grad.cpu(), grads["banded"][0], rtol=1e-6, atol=1e-6)
 
 
 @pytest.mark.parametrize("kind,P,L", [(0, 4, 3), (1, 8, 4), (1, 48, 4), (2, 12, 3), (2, 70, 3)])
