@@ -22,6 +22,7 @@
 //     float atomics (global_atomic_add_f32).
 #include "so_device.h"
 #include <algorithm>
+#include <type_traits>
 
 namespace {
 
@@ -526,7 +527,8 @@ __global__ __launch_bounds__(256) void msda_bwd_point_kernel(const float *__rest
                                                              const float *__restrict__ attw,
                                                              const float *__restrict__ g_out,
                                                              float *__restrict__ g_loc, float *__restrict__ g_attw,
-                                                             int16_t *__restrict__ keys, MsdaDims dm) {
+                                                             int16_t *__restrict__ keys, float4 *__restrict__ recs,
+                                                             MsdaDims dm) {
     constexpr int QL = D / 4;
     const int LP = dm.L * dm.P;
     const long long n_pts = (long long)dm.bs * dm.nq * dm.heads * LP;
@@ -586,7 +588,10 @@ __global__ __launch_bounds__(256) void msda_bwd_point_kernel(const float *__rest
     *(float2 *)(g_loc + 2 * idx) = make_float2(gx, gy);
     const int q = (int)(bq - (long long)b * dm.nq);
     const int p = pt - l * dm.P;
-    keys[((((size_t)b * dm.heads + h) * dm.L + l) * dm.nq + q) * dm.P + p] = (int16_t)(bl.any ? bl.h_low : kKeyOutside);
+    const size_t ki = ((((size_t)b * dm.heads + h) * dm.L + l) * dm.nq + q) * dm.P + p;
+    keys[ki] = (int16_t)(bl.any ? bl.h_low : kKeyOutside);
+    // everything the band kernel needs of this point, in ITS order (points of one (b, h, level) contiguous)
+    recs[ki] = make_float4(bl.lh, bl.lw, aw, __int_as_float((int)(((unsigned)bl.h_low << 16) | ((unsigned)bl.w_low & 0xffffu))));
 }
 
 struct MsdaBandPlan {
@@ -603,19 +608,21 @@ constexpr int kBandTileBytes = 52 * 1024;
 template <int D>
 __global__ __launch_bounds__(kBandThreads) void msda_bwd_band_kernel(const int32_t *__restrict__ shapes,
                                                                      const int32_t *__restrict__ starts,
-                                                                     const float *__restrict__ loc,
-                                                                     const float *__restrict__ attw,
                                                                      const float *__restrict__ g_out,
                                                                      float *__restrict__ g_value,
-                                                                     const int16_t *__restrict__ keys, MsdaDims dm,
+                                                                     const int16_t *__restrict__ keys,
+                                                                     const float4 *__restrict__ recs, MsdaDims dm,
                                                                      MsdaBandPlan plan) {
     constexpr int ROWS = 64 / D;        // sampling points served per atomic instruction
     constexpr int NJ = 64 / ROWS;       // row steps per batch of 64 points (= D)
     extern __shared__ __attribute__((aligned(16))) double tile[];
-    __shared__ int ring[kBandThreads / 64][128];
-    __shared__ int4 recP[kBandThreads];
-    __shared__ float4 recW[kBandThreads];
-    __shared__ int recQ[kBandThreads];
+    // hits wait in two wave-private rings: FULL (both corner rows inside the band: 4 adds) and EDGE
+    // (h_low is the row above the band or the band's last row: only one corner row, 2 adds) so that
+    // a batch emits exactly its corners, unconditionally (no per-corner tests or branches)
+    __shared__ int ring[kBandThreads / 64][2][128];
+    __shared__ int4 recP[kBandThreads];     // band-local element offsets of the 4 (or 2) corners
+    __shared__ float4 recW[kBandThreads];   // corner weight x attention weight
+    __shared__ int recQ[kBandThreads];      // (b, q, h) group index: row of g_out
 
     const int bh = blockIdx.x / plan.items, item = blockIdx.x - bh * plan.items;
     const int h = bh % dm.heads, b = bh / dm.heads;
@@ -631,40 +638,48 @@ __global__ __launch_bounds__(kBandThreads) void msda_bwd_band_kernel(const int32
     const int n_tile = (y1 - y0) * Wl * D;
     const int qper = (dm.nq + chunks_l - 1) / chunks_l;
     const int qa = min(dm.nq, chunk * qper), qb = min(dm.nq, qa + qper);
-    const int LP = dm.L * dm.P;
 
     for (int e = threadIdx.x; e < n_tile; e += kBandThreads) tile[e] = 0.0;
     __syncthreads();
 
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wave0 = threadIdx.x & ~63;
     const int sub = lane % D, row = lane / D;
-    int head = 0, tail = 0;   // wave-uniform ring cursors
+    const long long kbase = (((long long)b * dm.heads + h) * dm.L + l) * (long long)dm.nq * dm.P;
+    int head0 = 0, head1 = 0, tail0 = 0, tail1 = 0;   // wave-uniform ring cursors (FULL, EDGE)
 
-    // the 64 (or n < 64) oldest hits of this wave's ring -> band
-    auto process = [&](int n) {
+    // the n <= 64 oldest hits of ring c -> band
+    auto process = [&](auto cls, int n) {
+        constexpr int C = decltype(cls)::value;     // 0: FULL, 1: EDGE
         float4 w4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         int4 p4 = make_int4(0, 0, 0, 0);
         int gq32 = 0;
         if (lane < n) {
-            const int e = ring[wv][(head + lane) & 127];
-            const int q = e / dm.P, p = e - q * dm.P;
-            const long long gq = ((long long)b * dm.nq + q) * dm.heads + h;
-            const long long idx = gq * LP + l * dm.P + p;
-            const float2 xy = *(const float2 *)(loc + 2 * idx);
-            const float aw = attw[idx];
-            const Bilin bl = so_bilinear_setup(xy.x, xy.y, Hl, Wl, 1);
-            float wk[4];
-            int pk[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int ry = bl.h_low + (k >> 1), cx = bl.w_low + (k & 1);
-                const bool in = bl.valid[k] && ry >= y0 && ry < y1;
-                pk[k] = in ? ((ry - y0) * Wl + cx) * D : 0;
-                wk[k] = in ? bl.w[k] * aw : 0.0f;
+            const int e = ring[wv][C][((C == 0 ? head0 : head1) + lane) & 127];
+            const int q = e / dm.P;
+            const float4 rc = recs[kbase + e];
+            const int hw_ = __float_as_int(rc.w);
+            const int h_low = hw_ >> 16, w_low = (int)(short)(hw_ & 0xffff);
+            const float lh = rc.x, lw = rc.y, aw = rc.z;
+            const float hh = 1.0f - lh, hw = 1.0f - lw;
+            const bool c0 = w_low >= 0, c1 = w_low + 1 <= Wl - 1;
+            const int x0 = max(w_low, 0), x1 = min(w_low + 1, Wl - 1);
+            if (C == 0) {
+                // rows h_low and h_low + 1 are both inside [y0, y1) (hence inside the map)
+                const int r0 = (h_low - y0) * Wl, r1 = r0 + Wl;
+                w4 = make_float4(c0 ? (hh * hw) * aw : 0.0f, c1 ? (hh * lw) * aw : 0.0f,
+                                 c0 ? (lh * hw) * aw : 0.0f, c1 ? (lh * lw) * aw : 0.0f);
+                p4 = make_int4((r0 + x0) * D, (r0 + x1) * D, (r1 + x0) * D, (r1 + x1) * D);
+            } else {
+                // one corner row inside the band: the lower one (h_low + 1 == y0) or the upper one (h_low == y1 - 1)
+                const bool lower = h_low < y0;
+                const int ry = lower ? h_low + 1 : h_low;
+                const bool rv = ry >= 0 && ry <= Hl - 1;                 // always true by construction of the key test
+                const float wy = lower ? lh : hh;
+                const int r0 = (ry - y0) * Wl;
+                w4 = make_float4((rv && c0) ? (wy * hw) * aw : 0.0f, (rv && c1) ? (wy * lw) * aw : 0.0f, 0.0f, 0.0f);
+                p4 = make_int4((r0 + x0) * D, (r0 + x1) * D, 0, 0);
             }
-            w4 = make_float4(wk[0], wk[1], wk[2], wk[3]);
-            p4 = make_int4(pk[0], pk[1], pk[2], pk[3]);
-            gq32 = (int)gq;
+            gq32 = (int)(((long long)b * dm.nq + q) * dm.heads + h);
         }
         recW[threadIdx.x] = w4;
         recP[threadIdx.x] = p4;
@@ -679,16 +694,30 @@ __global__ __launch_bounds__(kBandThreads) void msda_bwd_band_kernel(const int32
             const int src = wave0 + j * ROWS + row;
             const float4 ws = recW[src];
             const int4 ps = recP[src];
-            if (ws.x != 0.0f) unsafeAtomicAdd(&tile[ps.x + sub], (double)(ws.x * goc[j]));
-            if (ws.y != 0.0f) unsafeAtomicAdd(&tile[ps.y + sub], (double)(ws.y * goc[j]));
-            if (ws.z != 0.0f) unsafeAtomicAdd(&tile[ps.z + sub], (double)(ws.z * goc[j]));
-            if (ws.w != 0.0f) unsafeAtomicAdd(&tile[ps.w + sub], (double)(ws.w * goc[j]));
+            // unconditional: a corner outside the map carries weight 0 (adds 0.0 to the band's first pixel)
+            unsafeAtomicAdd(&tile[ps.x + sub], (double)(ws.x * goc[j]));
+            unsafeAtomicAdd(&tile[ps.y + sub], (double)(ws.y * goc[j]));
+            if (C == 0) {
+                unsafeAtomicAdd(&tile[ps.z + sub], (double)(ws.z * goc[j]));
+                unsafeAtomicAdd(&tile[ps.w + sub], (double)(ws.w * goc[j]));
+            }
         }
         __builtin_amdgcn_wave_barrier();
     };
+    auto drain_full = [&](int n) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        process(std::integral_constant<int, 0>{}, n);
+        head0 += n;
+    };
+    auto drain_edge = [&](int n) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        process(std::integral_constant<int, 1>{}, n);
+        head1 += n;
+    };
 
     // stream this level's keys of the chunk's queries, 8 keys (16 bytes) per lane and step
-    const long long kbase = (((long long)b * dm.heads + h) * dm.L + l) * (long long)dm.nq * dm.P;
     const long long lo = kbase + (long long)qa * dm.P, hi = kbase + (long long)qb * dm.P;
     const int klo = y0 - 1, khi = y1 - 1;
     const int4 none = make_int4((int)0x80008000, (int)0x80008000, (int)0x80008000, (int)0x80008000);
@@ -704,26 +733,25 @@ __global__ __launch_bounds__(kBandThreads) void msda_bwd_band_kernel(const int32
             const int key = (int)(short)(((k & 4) ? k47 : k03) >> (16 * (k & 3)));
             const long long gi = pos + k;
             const bool hit = key >= klo && key <= khi && gi >= lo && gi < hi;
-            const unsigned long long m = __ballot(hit);
-            if (m != 0ULL) {   // uniform
-                if (hit) ring[wv][(tail + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0))) & 127] = (int)(gi - kbase);
-                tail += __popcll(m);
-                if (tail - head >= 64) {
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    process(64);
-                    head += 64;
-                }
+            const bool edge = key == klo || key == khi;
+            const unsigned long long mf = __ballot(hit && !edge), me = __ballot(hit && edge);
+            if ((mf | me) == 0ULL) continue;   // uniform
+            if (hit) {
+                const unsigned long long mm = edge ? me : mf;
+                const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0));
+                if (edge) ring[wv][1][(tail1 + pre) & 127] = (int)(gi - kbase);
+                else ring[wv][0][(tail0 + pre) & 127] = (int)(gi - kbase);
             }
+            tail0 += __popcll(mf);
+            tail1 += __popcll(me);
+            if (tail0 - head0 >= 64) drain_full(64);
+            if (tail1 - head1 >= 64) drain_edge(64);
         }
         cur = nxt;
         pos += step;
     }
-    if (tail > head) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        process(tail - head);
-    }
+    if (tail0 > head0) drain_full(tail0 - head0);
+    if (tail1 > head1) drain_edge(tail1 - head1);
     __syncthreads();
 
     // flush: consecutive lanes = consecutive channels of consecutive pixels of the band
@@ -864,7 +892,8 @@ extern "C" int selfocc_msda_bwd(const float *value, const int32_t *shapes, const
 
 
 // ---- banded backward -------------------------------------------------------------------------
-static size_t so_band_ws_bytes(long long n_pts) { return (size_t)((n_pts + 8) * 2 + 15) / 16 * 16; }
+static size_t so_band_key_bytes(long long n_pts) { return (size_t)((n_pts + 8) * 2 + 15) / 16 * 16; }
+static size_t so_band_ws_bytes(long long n_pts) { return so_band_key_bytes(n_pts) + (size_t)n_pts * 16; }
 
 extern "C" size_t selfocc_msda_bwd_banded_workspace(int32_t bs, int32_t nq, int32_t heads, int32_t L, int32_t P) {
     if (bs < 0 || nq < 0 || heads < 1 || L < 1 || P < 1) return 0;
@@ -896,7 +925,7 @@ extern "C" int selfocc_msda_bwd_banded(const float *value, const int32_t *shapes
     for (int l = 0; l < 8; ++l) { plan.rows[l] = 1; plan.bands[l] = 0; plan.chunks[l] = 1; plan.prefix[l] = 0; }
     for (int l = 0; l < L; ++l) {
         const int Hl = host_shapes[2 * l], Wl = host_shapes[2 * l + 1];
-        SO_REQUIRE(Hl >= 0 && Wl >= 0 && Hl < 32767, "msda_bwd_banded: bad level shape (%d, %d)", Hl, Wl);
+        SO_REQUIRE(Hl >= 0 && Wl >= 0 && Hl < 32767 && Wl < 32767, "msda_bwd_banded: bad level shape (%d, %d)", Hl, Wl);
         plan.prefix[l] = items;
         if (Hl == 0 || Wl == 0) continue;
         if (Wl > cap_px) { ok = false; break; }
@@ -921,6 +950,7 @@ extern "C" int selfocc_msda_bwd_banded(const float *value, const int32_t *shapes
 
     MsdaDims dm{bs, nv, nq, heads, L, P};
     int16_t *keys = (int16_t *)workspace;
+    float4 *recs = (float4 *)((char *)workspace + so_band_key_bytes(n_pts));
     const long long pblocks = (n_pts + 255) / 256;
     SO_REQUIRE(pblocks < (1LL << 31), "msda_bwd_banded: grid too large");
     const unsigned bblocks = (unsigned)((long long)bs * heads * items);
@@ -934,9 +964,9 @@ extern "C" int selfocc_msda_bwd_banded(const float *value, const int32_t *shapes
             attr_set = true;                                                                                 \
         }                                                                                                    \
         hipLaunchKernelGGL((msda_bwd_point_kernel<DD>), dim3((unsigned)pblocks), dim3(256), 0, st, value,    \
-                           shapes, starts, loc, attw, g_out, g_loc, g_attw, keys, dm);                       \
+                           shapes, starts, loc, attw, g_out, g_loc, g_attw, keys, recs, dm);                 \
         hipLaunchKernelGGL((msda_bwd_band_kernel<DD>), dim3(bblocks), dim3(kBandThreads), shm, st, shapes,   \
-                           starts, loc, attw, g_out, g_value, keys, dm, plan);                               \
+                           starts, g_out, g_value, keys, recs, dm, plan);                                    \
     }
     switch (d) {
         case 4: SO_LAUNCH(4); break;

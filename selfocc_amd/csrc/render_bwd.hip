@@ -309,7 +309,10 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba) 
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const int sub = lane % GS, grp = lane / GS;
                 for (int t = 0; t < GS; ++t) {
-                    const float *r = rec + (t * (64 / GS) + grp) * REC;
+                    // row grp serves the sample of lane grp * GS + t: the rows of one atomic instruction are
+                    // GS lanes (GS * M samples) apart on the ray, i.e. in different voxels — rows that share a
+                    // line serialise in the L2 atomic unit (94 vs 330 G lane-ops/s, scripts/micro/atomics2.hip)
+                    const float *r = rec + (grp * GS + t) * REC;
                     const int base = __float_as_int(r[0]);
                     const float dfc = (sub < NF) ? r[9 + sub] : 0.0f;
                     if (sub < NF && dfc != 0.0f) {
