@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SELFOCC_ABI_VERSION 7
+#define SELFOCC_ABI_VERSION 8
 
 int selfocc_abi_version(void);
 const char *selfocc_last_error(void);
@@ -223,6 +223,21 @@ typedef struct so_query_args {
 } so_query_args;
 
 int selfocc_field_query(const so_query_args *args, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Tri-plane -> dense volume: the head's pre_compute_density_color(representation)
+ * (sdfstudio-fork SDFCustomField, driven from model/head/neus_head/neus_head.py:295-306;
+ * in-repo analogue BEVNeRF, model/head/nerfacc_head/bev_nerf.py:74-95), forward only:
+ *   x[h,w,d,:] = hw[h,w,:] + zh[d,h,:] + wz[w,d,:]                        hw (H*W, C)  zh (D*H, C)  wz (W*D, C)
+ *   out = Linear_out(Softplus(Linear_hidden(Softplus(x))))  (n_hidden = 1; n_hidden = 0 drops the hidden layer)
+ *   sdf[h,w,d] = out[0];  feat[h,w,d,0..out_dim-2] = out[1..], channels up to feat_stride zero-filled.
+ * Weights in torch.nn.Linear layout: w_hidden (C, C), w_out (out_dim, C).  C in {64, 96, 128},
+ * out_dim <= 32, feat_stride <= 31.  One fused MFMA-f32 kernel (exact float32 arithmetic); the
+ * H*W*D x C intermediate is never materialised. */
+int selfocc_field_volume_fwd(const float *hw, const float *zh, const float *wz, int32_t H, int32_t W,
+                             int32_t D, int32_t C, const float *w_hidden, const float *b_hidden,
+                             int32_t n_hidden, const float *w_out, const float *b_out, int32_t out_dim,
+                             float *sdf, void *feat, int32_t feat_dtype, int32_t feat_stride, void *stream);
 
 /* Occ3D evaluation tail, eval_iou.py:211-250: trilinear resample (F.grid_sample,
  * align_corners=True, zero padding — bit-exact with torch's CPU kernel) of the dense SDF

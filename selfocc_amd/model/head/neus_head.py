@@ -25,6 +25,7 @@ import torch.nn as nn
 from ... import abi
 from ...mapping import GridMeterMapping
 from ...occ import field_query, uniform_lattice
+from ...field import field_volume, field_volume_supported
 from ...registry import HEADS
 from ...render import SDFVolume, RaySet, RenderConfig, render_rays, render_rays_autograd
 from ..bricks import BaseModule
@@ -178,6 +179,7 @@ class SDFField(BaseModule):
         self.density_net = nn.Sequential(*layers)
         self.variance = nn.Parameter(beta_init * torch.ones(1), requires_grad=beta_learnable)
         self.feat_dtype = feat_dtype
+        self.fused_volume = True     # inference uses selfocc_field_volume_fwd when the configuration allows
         self.volume = None
 
     def inv_s(self):
@@ -195,6 +197,14 @@ class SDFField(BaseModule):
             if self.tpv:
                 hw, zh, wz = (t.float() for t in representation)
                 assert hw.shape[0] == 1, 'only support bs = 1 currently'
+                linears = [m for m in self.density_net if isinstance(m, nn.Linear)]
+                F = SDFVolume.feat_width(self.n_rgb, self.n_sem)
+                if (self.fused_volume and not torch.is_grad_enabled() and hw.is_cuda
+                        and field_volume_supported(C, len(linears), 1 + self.color_dims, F)):
+                    # inference: plane sum + MLP + layout in one MFMA kernel, no (H*W*D, C) intermediate
+                    sdf, feat_vol = field_volume(hw, zh, wz, (H, W, D), linears, F, self.feat_dtype)
+                    self.volume = SDFVolume(self.mapping, sdf, feat_vol, self.n_rgb, self.n_sem)
+                    return self.volume
                 feat = hw.reshape(H, W, 1, C) + zh.reshape(D, H, 1, C).permute(1, 2, 0, 3) + \
                     wz.reshape(W, D, 1, C).permute(2, 0, 1, 3)                       # H, W, D, C
                 out = self._mlp(feat.reshape(-1, C)).reshape(H, W, D, -1)            # H, W, D, 1 + color
