@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SELFOCC_ABI_VERSION 8
+#define SELFOCC_ABI_VERSION 9
 
 int selfocc_abi_version(void);
 const char *selfocc_last_error(void);
@@ -179,6 +179,19 @@ int selfocc_msda_fwd(const float *value, const int32_t *shapes, const int32_t *s
 int selfocc_msda_fused_fwd(const float *value, const int32_t *shapes, const int32_t *starts,
                            const float *ref, int32_t ref_kind, const float *off_raw, const float *logits,
                            float *out, int32_t bs, int32_t nv, int32_t nq, int32_t heads, int32_t d,
+                           int32_t L, int32_t P, void *stream);
+
+/* Camera-loop inference form: BEVCrossAttention's re-batch -> offset / weight linears -> MSDA ->
+ * scatter-add -> divide-by-count (bevformer/attention/image_cross_attention.py:90-136) as ONE launch.
+ * The offsets and logits depend on the query only, so they are given once per query and each
+ * (query, head) loops over the cameras that see it (vis != 0), in camera order:
+ *   out[q] = sum_{cam: vis[cam][q]} msda(value[cam], ref[cam][q] + off[q] / (W_l, H_l), softmax(logits[q]))
+ *            / max(#visible cams, 1)
+ *   value (cams,nv,heads,d)  ref (cams,nq,P,2)  vis (cams,nq) u8  off_raw (nq,heads,L,P,2)
+ *   logits (nq,heads,L*P)  out (nq,heads*d)            batch size 1 (as the reference's masks), L*P <= 256 */
+int selfocc_msda_cross_fwd(const float *value, const int32_t *shapes, const int32_t *starts,
+                           const float *ref, const uint8_t *vis, const float *off_raw, const float *logits,
+                           float *out, int32_t cams, int32_t nv, int32_t nq, int32_t heads, int32_t d,
                            int32_t L, int32_t P, void *stream);
 
 /* g_value must be zero-initialised by the caller (atomically accumulated). */

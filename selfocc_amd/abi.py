@@ -6,7 +6,7 @@ its exported symbols being callable with these layouts.
 """
 import ctypes as C
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 # enums ---------------------------------------------------------------------------
 RAYS_EXPLICIT, RAYS_PIXEL_GRID = 0, 1
@@ -104,6 +104,7 @@ SYMBOLS = {
     "selfocc_render_bwd": (C.c_int, [C.POINTER(SoRenderBwdArgs), _p]),
     "selfocc_msda_fwd": (C.c_int, [_p, _p, _p, _p, _p, _p] + [_i] * 7 + [_p]),
     "selfocc_msda_fused_fwd": (C.c_int, [_p, _p, _p, _p, _i, _p, _p, _p] + [_i] * 7 + [_p]),
+    "selfocc_msda_cross_fwd": (C.c_int, [_p] * 8 + [_i] * 7 + [_p]),
     "selfocc_msda_bwd": (C.c_int, [_p] * 9 + [_i] * 7 + [_p]),
     "selfocc_msda_bwd_banded_workspace": (C.c_size_t, [_i] * 5),
     "selfocc_msda_bwd_banded": (C.c_int, [_p] * 10 + [_i] * 7 + [_p, C.c_size_t, _p]),

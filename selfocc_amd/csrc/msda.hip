@@ -348,6 +348,104 @@ __global__ __launch_bounds__(256) void msda_fused_fwd_kernel(const float *__rest
 }
 
 // ---------------------------------------------------------------------------------------
+// camera-loop forward (inference) — the whole of BEVCrossAttention's sampling stage
+// (bevformer/attention/image_cross_attention.py:90-136) in one launch.  The reference re-batches the
+// queries each camera sees into (cams, max_len) (a host sync for max_len, python double loops), runs the
+// offset / weight linears and MSDA on the padded re-batch, scatter-adds the result back per camera and
+// divides by the number of cameras that saw the query.  But the offsets and attention logits are
+// functions of the QUERY only — every camera's copy of a query produces the same ones; only the
+// reference points and the value map differ per camera.  So here a (query, head) group does the
+// softmax and the offsets once and loops over the cameras that see the query, accumulating the
+// sampled output in registers in camera order (the order of the reference's `slots +=`), and divides
+// by the visible-camera count at the end: no index lists, no padding, no atomics, no host sync,
+// and the two linears run on nq rows instead of cams * max_len.
+//   value (cams, nv, heads, D)   ref (cams, nq, P, 2)   vis (cams, nq) u8   off_raw (nq, heads, L, P, 2)
+//   logits (nq, heads, L*P)      out (nq, heads*D) = sum_{cam visible} msda_cam(q) / max(#visible, 1)
+// ---------------------------------------------------------------------------------------
+template <int D, int LOGG>
+__global__ __launch_bounds__(256) void msda_cross_fwd_kernel(const float *__restrict__ value,
+                                                             const int32_t *__restrict__ shapes,
+                                                             const int32_t *__restrict__ starts,
+                                                             const float *__restrict__ ref,
+                                                             const uint8_t *__restrict__ vis,
+                                                             const float *__restrict__ off_raw,
+                                                             const float *__restrict__ logits,
+                                                             float *__restrict__ out, int cams, MsdaDims dm) {
+    constexpr int G = 1 << LOGG;
+    constexpr int QL = D / 4, LOGQ = so_ilog2(QL);
+    constexpr int NJ = LOGG > LOGQ ? LOGG - LOGQ : 0;
+    constexpr int MAXR = 4;   // points per lane (host guarantees L * P <= MAXR * G)
+    const int LP = dm.L * dm.P;
+    const int groups_per_block = 256 / G;
+    const int n_groups = dm.nq * dm.heads;                       // < 2^31 (validated)
+    const int gid = blockIdx.x * groups_per_block + (threadIdx.x / G);
+    const int gl = threadIdx.x & (G - 1);
+    const bool live = gid < n_groups;
+    const int gq = live ? gid : 0;
+    const int q = gq / dm.heads, h = gq - q * dm.heads;
+    const int pix_stride = dm.heads * D;
+    const int s = gl & (QL - 1);
+    const float *vb = value + h * D + 4 * s;
+
+    // softmax over the group's L * P logits; raw offsets of the lane's own points, already / (W_l, H_l)
+    float lg[MAXR], ox[MAXR], oy[MAXR];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+        const int pt = gl + r * G;
+        lg[r] = (pt < LP) ? logits[(size_t)gq * LP + pt] : -INFINITY;
+        mx = fmaxf(mx, lg[r]);
+    }
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+    float den = 0.0f;
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+        const int pt = gl + r * G;
+        lg[r] = (pt < LP) ? __expf(lg[r] - mx) : 0.0f;
+        den += lg[r];
+        ox[r] = oy[r] = 0.0f;
+        if (pt < LP) {
+            const int l = so_level_of(pt, dm.P, dm.L);
+            const float2 o = *(const float2 *)(off_raw + 2 * ((size_t)gq * LP + pt));
+            ox[r] = o.x / (float)shapes[2 * l + 1];
+            oy[r] = o.y / (float)shapes[2 * l];
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) den += __shfl_xor(den, m, 64);
+    const float iden = 1.0f / den;
+
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    int count = 0;
+    for (int cam = 0; cam < cams; ++cam) {
+        const bool seen = live && vis[(size_t)cam * dm.nq + q] != 0;
+        count += seen ? 1 : 0;
+        if (!__any(seen)) continue;                      // no group of this wave sees the camera
+        const int cam_off = cam * dm.nv * pix_stride;    // < 2^31 (validated)
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) {
+            if (r * G >= LP) break;   // uniform
+            const int pt = gl + r * G;
+            MsdaPoint mp = so_point_none();
+            if (seen && pt < LP) {
+                const int l = so_level_of(pt, dm.P, dm.L);
+                const int pp = pt - l * dm.P;
+                const float2 rf = *(const float2 *)(ref + 2 * (((size_t)cam * dm.nq + q) * dm.P + pp));
+                mp = so_point_setup(rf.x + ox[r], rf.y + oy[r], lg[r] * iden, shapes[2 * l], shapes[2 * l + 1],
+                                    cam_off + starts[l] * pix_stride, pix_stride);
+            }
+            so_team_gather<D>(vb, mp, acc);
+        }
+    }
+    // mean over the cameras that saw the query (image_cross_attention.py:133-135: count clamped to >= 1)
+    const float cnt = (float)max(count, 1);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[c] = acc[c] / cnt;
+    so_group_reduce_store<NJ, LOGQ>(acc, gl >> LOGQ, live, out + (size_t)gq * D + 4 * s);
+}
+
+// ---------------------------------------------------------------------------------------
 // backward.  Phase 1: lane per sampling point (no cross-lane reduction): the 4 corner . g_out
 // dot products give grad_attw and grad_loc (coalesced per-point stores).  Phase 2: the
 // grad_value scatter is TRANSPOSED so that D consecutive lanes own the D contiguous channels
@@ -843,6 +941,50 @@ extern "C" int selfocc_msda_fused_fwd(const float *value, const int32_t *shapes,
 #define SO_LAUNCH_G(DD, LG)                                                                             \
     hipLaunchKernelGGL((msda_fused_fwd_kernel<DD, LG>), dim3((unsigned)blocks), dim3(256), 0, st, value, \
                        shapes, starts, ref, ref_kind, off_raw, logits, out, dm)
+#define SO_LAUNCH(DD)                                                                                   \
+    switch (logG) {                                                                                     \
+        case 0: SO_LAUNCH_G(DD, 0); break;                                                              \
+        case 1: SO_LAUNCH_G(DD, 1); break;                                                              \
+        case 2: SO_LAUNCH_G(DD, 2); break;                                                              \
+        case 3: SO_LAUNCH_G(DD, 3); break;                                                              \
+        case 4: SO_LAUNCH_G(DD, 4); break;                                                              \
+        case 5: SO_LAUNCH_G(DD, 5); break;                                                              \
+        default: SO_LAUNCH_G(DD, 6); break;                                                             \
+    }
+    switch (d) {
+        case 4: SO_LAUNCH(4); break;
+        case 8: SO_LAUNCH(8); break;
+        case 16: SO_LAUNCH(16); break;
+        default: SO_LAUNCH(32); break;
+    }
+#undef SO_LAUNCH
+#undef SO_LAUNCH_G
+    return so_launch_status();
+}
+
+extern "C" int selfocc_msda_cross_fwd(const float *value, const int32_t *shapes, const int32_t *starts,
+                                      const float *ref, const uint8_t *vis, const float *off_raw,
+                                      const float *logits, float *out, int32_t cams, int32_t nv, int32_t nq,
+                                      int32_t heads, int32_t d, int32_t L, int32_t P, void *stream) {
+    SO_REQUIRE(cams >= 1, "msda_cross_fwd: cams must be >= 1");
+    if (validate(value, shapes, starts, off_raw, logits, cams, nv, nq, heads, d, L, P)) return -1;
+    const long long n_groups = (long long)nq * heads;
+    if (n_groups == 0) return 0;
+    SO_REQUIRE(out != nullptr && ref != nullptr && vis != nullptr, "msda_cross_fwd: NULL pointer");
+    SO_REQUIRE(n_groups < (1LL << 31), "msda_cross_fwd: nq * heads must be < 2^31");
+    const int LP = L * P;
+    SO_REQUIRE(LP <= 256, "msda_cross_fwd: L * P must be <= 256 (got %d)", LP);
+    if (nv == 0) return (int)hipMemsetAsync(out, 0, (size_t)n_groups * d * sizeof(float), (hipStream_t)stream);
+    int G = 1, logG = 0;
+    while ((G < LP && G < 64) || G < d / 4) { G <<= 1; ++logG; }
+    const int gpb = 256 / G;
+    const long long blocks = (n_groups + gpb - 1) / gpb;
+    SO_REQUIRE(blocks < (1LL << 31), "msda_cross_fwd: grid too large");
+    MsdaDims dm{1, nv, nq, heads, L, P};
+    hipStream_t st = (hipStream_t)stream;
+#define SO_LAUNCH_G(DD, LG)                                                                             \
+    hipLaunchKernelGGL((msda_cross_fwd_kernel<DD, LG>), dim3((unsigned)blocks), dim3(256), 0, st, value, \
+                       shapes, starts, ref, vis, off_raw, logits, out, cams, dm)
 #define SO_LAUNCH(DD)                                                                                   \
     switch (logG) {                                                                                     \
         case 0: SO_LAUNCH_G(DD, 0); break;                                                              \

@@ -16,6 +16,7 @@ import torch.nn as nn
 from ...registry import MODELS, build_attention
 from ..bricks import (BaseModule, MultiScaleDeformableAttention, constant_init, xavier_init,
                       deformable_sampling)
+from ...msda import msda_cross_inference
 
 
 @MODELS.register_module()
@@ -80,6 +81,7 @@ class BEVCrossAttention(BaseModule):
         self.embed_dims, self.num_cams = embed_dims, num_cams
         self.output_proj = nn.Linear(embed_dims, embed_dims)
         self.batch_first = batch_first
+        self.camera_loop = True     # inference: selfocc_msda_cross_fwd instead of re-batch + scatter-add
         self.init_weight()
 
     def init_weight(self):
@@ -112,6 +114,12 @@ class BEVCrossAttention(BaseModule):
         bs, num_query, _ = query.size()
         num_cams = self.num_cams
         D = reference_points_cams.size(3)
+        da = self.deformable_attention
+        if (self.camera_loop and not torch.is_grad_enabled() and bs == 1 and query.is_cuda
+                and isinstance(da, BEVDeformableAttention) and da.batch_first
+                and da.num_levels * da.num_points <= 256):
+            return self._forward_camera_loop(query, value, residual, spatial_shapes, reference_points_cams,
+                                             bev_masks, level_start_index)
         plan = kwargs.get('rebatch_plan')
         if plan is None:
             plan = self.rebatch_plan(bev_masks)
@@ -133,6 +141,25 @@ class BEVCrossAttention(BaseModule):
         slots = torch.zeros_like(query)
         slots.index_add_(1, q_idx, sampled[:, cam_idx, slot])
         slots = slots / count[..., None]
+        slots = self.output_proj(slots)
+        return self.dropout(slots) + residual
+
+
+    def _forward_camera_loop(self, query, value, residual, spatial_shapes, reference_points_cams, bev_masks,
+                             level_start_index):
+        """Inference: no re-batch.  The offset / weight linears depend on the query only, so they run once
+        on the num_query rows; one HIP launch loops over the cameras that see each query and averages
+        (selfocc_msda_cross_fwd) — same arithmetic as the re-batched path, camera order preserved."""
+        da = self.deformable_attention
+        num_cams, heads, L, P = self.num_cams, da.num_heads, da.num_levels, da.num_points
+        _, l, _, _ = value.shape                                            # (cams, nv, bs, C)
+        v = da.value_proj(value.permute(2, 0, 1, 3).reshape(num_cams, l, self.embed_dims))
+        v = v.view(num_cams, l, heads, -1)
+        off = da.sampling_offsets(query[0]).view(-1, heads, L, P, 2)
+        logits = da.attention_weights(query[0]).view(-1, heads, L * P)
+        visible = bev_masks[:, 0].any(-1)                                   # (cams, Q), batch element 0 as the reference
+        slots = msda_cross_inference(v, spatial_shapes, level_start_index, reference_points_cams[:, 0], visible,
+                                     off, logits)[None]
         slots = self.output_proj(slots)
         return self.dropout(slots) + residual
 

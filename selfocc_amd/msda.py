@@ -114,3 +114,29 @@ def msda_fused_inference(value, spatial_shapes, level_start_index, reference_poi
                                        ptr(out), bs, nv, nq, heads, d, L, P, current_stream(value.device)),
           "selfocc_msda_fused_fwd")
     return out
+
+
+def msda_cross_inference(value, spatial_shapes, level_start_index, reference_points_cam, visible,
+                         sampling_offsets, attention_logits):
+    """Inference-only camera-loop op (no autograd): the sampling stage of BEVCrossAttention
+    (bevformer/attention/image_cross_attention.py:90-136) without re-batching.
+    value (cams,nv,h,d); reference_points_cam (cams,nq,P,2); visible (cams,nq) bool — the cameras that see
+    each query; sampling_offsets (nq,h,L,P,2) and attention_logits (nq,h,L*P): the raw linear outputs for
+    the UN-rebatched queries.  Returns (nq, h*d): the mean over the visible cameras."""
+    if not value.is_cuda:
+        raise RuntimeError("msda_cross_inference needs CUDA(HIP) tensors: selfocc_amd has no CPU fallback")
+    cams, nv, heads, d = value.shape
+    nq, _, L, P, _ = sampling_offsets.shape
+    value = value.contiguous().float()
+    off = sampling_offsets.contiguous().float()
+    lg = attention_logits.contiguous().float()
+    ref = reference_points_cam.contiguous().float()
+    vis = visible.to(torch.uint8).contiguous()
+    assert ref.shape == (cams, nq, P, 2) and vis.shape == (cams, nq)
+    sh = spatial_shapes.to(device=value.device, dtype=torch.int32).contiguous()
+    st = level_start_index.to(device=value.device, dtype=torch.int32).contiguous()
+    out = torch.empty(nq, heads * d, device=value.device, dtype=torch.float32)
+    check(lib().selfocc_msda_cross_fwd(ptr(value), ptr(sh), ptr(st), ptr(ref), ptr(vis), ptr(off), ptr(lg),
+                                       ptr(out), cams, nv, nq, heads, d, L, P, current_stream(value.device)),
+          "selfocc_msda_cross_fwd")
+    return out

@@ -124,3 +124,33 @@ def test_msda_fused_prologue_matches_unfused(hip, kind, P, L):
     aw = logits.softmax(-1).view(bs, nq, H, L, P)
     want = oracle.msda_fwd(value, shapes, starts, loc.contiguous(), aw.contiguous())
     assert torch.allclose(got.cpu(), want, rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("P,L,D", [(8, 4, 16), (48, 4, 16), (5, 2, 8), (70, 3, 16), (3, 1, 32)])
+def test_msda_cross_camera_loop_matches_per_camera_ops(hip, P, L, D):
+    """selfocc_msda_cross_fwd == sum over the visible cameras of the plain op (oracle-checked above)
+    / max(#visible, 1): queries seen by no camera, one camera and all cameras."""
+    from selfocc_amd.msda import msda_cross_inference
+    g = torch.Generator().manual_seed(P * 10 + L)
+    shapes = torch.tensor([[24, 50], [12, 25], [6, 13], [3, 7]][:L])
+    starts = torch.cat([torch.zeros(1, dtype=torch.int64), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    nv = int((shapes[:, 0] * shapes[:, 1]).sum())
+    cams, nq, H = 5, 203, 3
+    value = torch.randn(cams, nv, H, D, generator=g)
+    off = torch.randn(nq, H, L, P, 2, generator=g) * 3
+    logits = torch.randn(nq, H, L * P, generator=g) * 2
+    ref = torch.rand(cams, nq, P, 2, generator=g) * 1.4 - 0.2
+    vis = torch.rand(cams, nq, generator=g) < 0.4
+    vis[:, 0] = False; vis[:, 1] = True; vis[:, 2] = False; vis[3, 2] = True
+    d = torch.device("cuda:0")
+    got = msda_cross_inference(value.to(d), shapes.to(d), starts.to(d), ref.to(d), vis.to(d), off.to(d), logits.to(d)).cpu()
+    aw = logits.softmax(-1).view(nq, H, L, P)
+    norm = torch.stack([shapes[:, 1], shapes[:, 0]], -1).float()
+    want = torch.zeros(nq, H * D)
+    for c in range(cams):
+        loc = ref[c][:, None, None, :, :] + off / norm[None, None, :, None, :]
+        o = oracle.msda_fwd(value[c:c + 1], shapes, starts, loc[None], aw[None])[0]
+        want += o * vis[c][:, None]
+    want = want / vis.sum(0).clamp(min=1)[:, None]
+    assert torch.allclose(got, want, rtol=1e-4, atol=1e-5), (got - want).abs().max()
+    assert torch.all(got[0] == 0)
