@@ -153,7 +153,13 @@ class _TallLinear(torch.autograd.Function):
         dw = torch.bmm(dy[:Tp].view(G, -1, dy.shape[1]).transpose(1, 2), x[:Tp].view(G, -1, x.shape[1])).sum(0)
         if Tp < T:
             dw = dw + dy[Tp:].t() @ x[Tp:]
-        return dy @ weight, dw, dy.sum(0)
+        # bias gradient in two stages as well: torch's column reduction of a (1.65 M, N) matrix has only N
+        # outputs to parallelise over (~200 GB/s, 3.1 ms per call in profiles/r1_g_train_iteration.txt; rocBLAS
+        # gemv against a ones vector is worse: 16 ms); (G, rows, N).sum(1) has G * N
+        db = dy[:Tp].view(G, -1, dy.shape[1]).sum(1).sum(0)
+        if Tp < T:
+            db = db + dy[Tp:].sum(0)
+        return dy @ weight, dw, db
 
 
 class SDFField(BaseModule):
