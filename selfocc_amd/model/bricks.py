@@ -58,6 +58,55 @@ def build_activation_layer(cfg):
     raise NotImplementedError(typ)
 
 
+class _TallLinear(torch.autograd.Function):
+    """y = x W^T + b for x with millions of rows and a handful of output features.  The vendor
+    GEMM picked for the weight gradient dW = dy^T x of such a shape (25 x 1.65 M x 96 at the shipped
+    nuscenes_occ sizes) runs on 2 workgroups — 23 ms per call, 4 calls per iteration in the
+    round-1 profile; here the reduction over rows is split into 256 batched GEMMs + a sum."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dy = dy.contiguous()
+        T, G = x.shape[0], 256
+        R = T // G                       # rows per batched GEMM
+        Tp = R * G
+        dw = dy.new_zeros(dy.shape[1], x.shape[1])
+        db = dy.new_zeros(dy.shape[1])
+        if R > 0:
+            dyb = dy[:Tp].view(G, R, dy.shape[1])
+            dw = torch.bmm(dyb.transpose(1, 2), x[:Tp].view(G, R, x.shape[1])).sum(0)
+            # bias gradient in two stages as well: torch's column reduction of a (1.65 M, N) matrix has only
+            # N outputs to parallelise over (~200 GB/s, 3.1 ms per call in profiles/r1_g_train_iteration.txt;
+            # rocBLAS gemv against a ones vector is worse: 16 ms); (G, R, N).sum(1) has G * N
+            db = dyb.sum(1).sum(0)
+        if Tp < T:
+            dw = dw + dy[Tp:].t() @ x[Tp:]
+            db = db + dy[Tp:].sum(0)
+        return dy @ weight, dw, (db if ctx.has_bias else None)
+
+
+class TallLinear(nn.Linear):
+    """nn.Linear (same parameters / state-dict keys) whose training forward goes through ``_TallLinear``
+    when the input has many rows: the encoder's projections see 66 k - 153 k rows x 96 features, and the
+    vendor GEMM chosen for their weight gradients (K = rows, 96 x 96 .. 96 x 2304 outputs) runs on a
+    handful of workgroups (MT32x32x256: 0.3 ms x 32 calls per nuscenes_occ iteration)."""
+    min_rows = 8192
+
+    def forward(self, x):
+        rows = x.numel() // max(x.shape[-1], 1)
+        if torch.is_grad_enabled() and rows >= self.min_rows and (x.requires_grad or self.weight.requires_grad):
+            y = _TallLinear.apply(x.reshape(rows, x.shape[-1]), self.weight, self.bias)
+            return y.view(*x.shape[:-1], self.weight.shape[0])
+        return super().forward(x)
+
+
 @MODELS.register_module()
 class FFN(BaseModule):
     """mmcv.cnn.bricks.transformer.FFN: Linear -> act -> drop (x num_fcs-1) -> Linear -> drop,
@@ -71,10 +120,10 @@ class FFN(BaseModule):
         self.embed_dims, self.feedforward_channels, self.num_fcs = embed_dims, feedforward_channels, num_fcs
         layers, in_ch = [], embed_dims
         for _ in range(num_fcs - 1):
-            layers.append(nn.Sequential(nn.Linear(in_ch, feedforward_channels), build_activation_layer(act_cfg),
+            layers.append(nn.Sequential(TallLinear(in_ch, feedforward_channels), build_activation_layer(act_cfg),
                                         nn.Dropout(ffn_drop)))
             in_ch = feedforward_channels
-        layers.append(nn.Linear(feedforward_channels, embed_dims))
+        layers.append(TallLinear(feedforward_channels, embed_dims))
         layers.append(nn.Dropout(ffn_drop))
         self.layers = nn.Sequential(*layers)
         self.dropout_layer = nn.Identity()
@@ -147,11 +196,11 @@ class MultiScaleDeformableAttention(BaseModule):
         self.dropout = nn.Dropout(dropout)
         self.im2col_step, self.embed_dims = im2col_step, embed_dims
         self.num_levels, self.num_heads, self.num_points = num_levels, num_heads, num_points
-        self.sampling_offsets = nn.Linear(embed_dims, num_heads * num_levels * num_points * 2)
-        self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
+        self.sampling_offsets = TallLinear(embed_dims, num_heads * num_levels * num_points * 2)
+        self.attention_weights = TallLinear(embed_dims, num_heads * num_levels * num_points)
         value_proj_size = int(embed_dims * value_proj_ratio)
-        self.value_proj = nn.Linear(embed_dims, value_proj_size)
-        self.output_proj = nn.Linear(value_proj_size, embed_dims)
+        self.value_proj = TallLinear(embed_dims, value_proj_size)
+        self.output_proj = TallLinear(value_proj_size, embed_dims)
         self.init_weights()
 
     _scale_points = True  # mmcv scales the i-th point's offset bias by (i + 1)

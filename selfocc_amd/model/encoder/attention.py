@@ -14,7 +14,7 @@ import torch
 import torch.nn as nn
 
 from ...registry import MODELS, build_attention
-from ..bricks import (BaseModule, MultiScaleDeformableAttention, constant_init, xavier_init,
+from ..bricks import (BaseModule, MultiScaleDeformableAttention, TallLinear, constant_init, xavier_init,
                       deformable_sampling)
 from ...msda import msda_cross_inference
 
@@ -33,9 +33,9 @@ class BEVDeformableAttention(BaseModule):
         self.norm_cfg, self.batch_first = norm_cfg, batch_first
         self.im2col_step, self.embed_dims = im2col_step, embed_dims
         self.num_levels, self.num_heads, self.num_points = num_levels, num_heads, num_points
-        self.sampling_offsets = nn.Linear(embed_dims, num_heads * num_levels * num_points * 2)
-        self.attention_weights = nn.Linear(embed_dims, num_heads * num_levels * num_points)
-        self.value_proj = nn.Linear(embed_dims, int(embed_dims * value_proj_ratio))
+        self.sampling_offsets = TallLinear(embed_dims, num_heads * num_levels * num_points * 2)
+        self.attention_weights = TallLinear(embed_dims, num_heads * num_levels * num_points)
+        self.value_proj = TallLinear(embed_dims, int(embed_dims * value_proj_ratio))
         self.init_weights()
 
     def init_weights(self):
@@ -79,7 +79,7 @@ class BEVCrossAttention(BaseModule):
         self.dropout = nn.Dropout(dropout)
         self.deformable_attention = build_attention(deformable_attention)
         self.embed_dims, self.num_cams = embed_dims, num_cams
-        self.output_proj = nn.Linear(embed_dims, embed_dims)
+        self.output_proj = TallLinear(embed_dims, embed_dims)
         self.batch_first = batch_first
         self.camera_loop = True     # inference: selfocc_msda_cross_fwd instead of re-batch + scatter-add
         self.init_weight()

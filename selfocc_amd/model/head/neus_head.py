@@ -28,7 +28,7 @@ from ...occ import field_query, uniform_lattice
 from ...field import field_volume, field_volume_supported
 from ...registry import HEADS
 from ...render import SDFVolume, RaySet, RenderConfig, render_rays, render_rays_autograd
-from ..bricks import BaseModule
+from ..bricks import BaseModule, _TallLinear
 
 
 def get_rm(angle, axis, deg=False):
@@ -131,35 +131,6 @@ class Img2LiDAR(nn.Module):
         pad = torch.cat([rays.float(), torch.ones_like(rays[..., :1])], -1).reshape(1, 1, -1, 3)
         direction = torch.matmul(M[..., :3, :3].unsqueeze(2), pad.unsqueeze(-1)).squeeze(-1)
         return M[..., :3, 3], direction
-
-
-class _TallLinear(torch.autograd.Function):
-    """y = x W^T + b for x with millions of rows and a handful of output features.  The vendor
-    GEMM picked for the weight gradient dW = dy^T x of such a shape (25 x 1.65 M x 96 at the shipped
-    nuscenes_occ sizes) runs on 2 workgroups — 23 ms per call, 4 calls per iteration in the
-    round-1 profile; here the reduction over rows is split into 256 batched GEMMs + a sum."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
-        return torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, weight = ctx.saved_tensors
-        dy = dy.contiguous()
-        T, G = x.shape[0], 256
-        Tp = (T // G) * G
-        dw = torch.bmm(dy[:Tp].view(G, -1, dy.shape[1]).transpose(1, 2), x[:Tp].view(G, -1, x.shape[1])).sum(0)
-        if Tp < T:
-            dw = dw + dy[Tp:].t() @ x[Tp:]
-        # bias gradient in two stages as well: torch's column reduction of a (1.65 M, N) matrix has only N
-        # outputs to parallelise over (~200 GB/s, 3.1 ms per call in profiles/r1_g_train_iteration.txt; rocBLAS
-        # gemv against a ones vector is worse: 16 ms); (G, rows, N).sum(1) has G * N
-        db = dy[:Tp].view(G, -1, dy.shape[1]).sum(1).sum(0)
-        if Tp < T:
-            db = db + dy[Tp:].sum(0)
-        return dy @ weight, dw, db
 
 
 class SDFField(BaseModule):
