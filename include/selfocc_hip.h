@@ -207,7 +207,8 @@ int selfocc_msda_bwd(const float *value, const int32_t *shapes, const int32_t *s
  * with ds_add_f64 — no global atomics in the scatter.  Needs a HOST copy of `shapes` (L, 2) for
  * the work decomposition (L <= 8) and a 16-byte aligned device workspace of
  * selfocc_msda_bwd_banded_workspace(...) bytes (18 bytes per sampling point: a 2-byte row key and
- * a 16-byte record in band order; contents undefined before and after).  g_value must be zero-initialised by the caller.  Falls back to
+ * a 16-byte record in band order, plus 4 bytes per 64 queries of every (batch, head, level);
+ * contents undefined before and after).  g_value must be zero-initialised by the caller.  Falls back to
  * selfocc_msda_bwd when a level is wider than the LDS tile or the maps are huge relative to the
  * number of points. */
 size_t selfocc_msda_bwd_banded_workspace(int32_t bs, int32_t nq, int32_t heads, int32_t L, int32_t P);

@@ -692,6 +692,31 @@ __global__ __launch_bounds__(256) void msda_bwd_point_kernel(const float *__rest
     recs[ki] = make_float4(bl.lh, bl.lw, aw, __int_as_float((int)(((unsigned)bl.h_low << 16) | ((unsigned)bl.w_low & 0xffffu))));
 }
 
+// Row range of the keys of 64 consecutive queries of one (b, h, level): lets a band skip the key blocks
+// that cannot touch it (consecutive queries of a plane project to neighbouring image rows).
+constexpr int kRangeQueries = 64;
+
+__global__ __launch_bounds__(64) void msda_key_range_kernel(const int16_t *__restrict__ keys, int32_t *__restrict__ ranges,
+                                                            int nq, int P, int nqb) {
+    const long long blk = blockIdx.x;                         // (b, h, l) * nqb + qb
+    const long long bhl = blk / nqb;
+    const int qb = (int)(blk - bhl * nqb);
+    const int q0 = qb * kRangeQueries, q1 = min(nq, q0 + kRangeQueries);
+    const int16_t *k = keys + (bhl * nq + q0) * P;
+    const int n = (q1 - q0) * P;
+    int mn = 32767, mx = -32768;
+    for (int e = threadIdx.x; e < n; e += 64) {
+        const int v = k[e];
+        if (v != kKeyOutside) { mn = min(mn, v); mx = max(mx, v); }
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        mn = min(mn, __shfl_xor(mn, m, 64));
+        mx = max(mx, __shfl_xor(mx, m, 64));
+    }
+    if (threadIdx.x == 0) ranges[blk] = (int)(((unsigned)mn << 16) | ((unsigned)mx & 0xffffu));
+}
+
 struct MsdaBandPlan {
     int rows[8];      // rows per band of level l
     int bands[8];     // bands of level l
@@ -709,8 +734,9 @@ __global__ __launch_bounds__(kBandThreads) void msda_bwd_band_kernel(const int32
                                                                      const float *__restrict__ g_out,
                                                                      float *__restrict__ g_value,
                                                                      const int16_t *__restrict__ keys,
-                                                                     const float4 *__restrict__ recs, MsdaDims dm,
-                                                                     MsdaBandPlan plan) {
+                                                                     const float4 *__restrict__ recs,
+                                                                     const int32_t *__restrict__ ranges, int nqb,
+                                                                     MsdaDims dm, MsdaBandPlan plan) {
     constexpr int ROWS = 64 / D;        // sampling points served per atomic instruction
     constexpr int NJ = 64 / ROWS;       // row steps per batch of 64 points (= D)
     extern __shared__ __attribute__((aligned(16))) double tile[];
@@ -821,9 +847,33 @@ __global__ __launch_bounds__(kBandThreads) void msda_bwd_band_kernel(const int32
     const int4 none = make_int4((int)0x80008000, (int)0x80008000, (int)0x80008000, (int)0x80008000);
     const long long step = (long long)kBandThreads * 8;
     long long pos = (lo & ~7LL) + (long long)threadIdx.x * 8;
-    int4 cur = (pos < hi) ? *(const int4 *)(keys + pos) : none;
-    for (long long bp = (lo & ~7LL); bp < hi; bp += step) {   // uniform trip count
-        const int4 nxt = (pos + step < hi) ? *(const int4 *)(keys + pos + step) : none;
+    // can the 512 keys this wave looks at in the step that starts at p touch the band?  (row range of the
+    // 64-query blocks they belong to; wave-uniform)
+    const int32_t *rng = ranges + (((long long)b * dm.heads + h) * dm.L + l) * nqb;
+    auto relevant = [&](long long p) -> bool {
+        const long long w0 = p + (long long)wave0 * 8;                 // first key of this wave in the step
+        if (w0 >= hi) return false;
+        const long long e0 = max(w0, lo) - kbase, e1 = min(w0 + 511, hi - 1) - kbase;
+        if (e1 < e0) return false;
+        const int b0 = (int)(e0 / dm.P) / kRangeQueries, b1 = (int)(e1 / dm.P) / kRangeQueries;
+        bool hit = false;
+        for (int qb = b0; qb <= b1; ++qb) {
+            const int r = __builtin_amdgcn_readfirstlane(rng[qb]);
+            const int mn = r >> 16, mx = (int)(short)(r & 0xffff);
+            hit |= (mx >= klo) && (mn <= khi);
+        }
+        return hit;
+    };
+    const long long p0 = lo & ~7LL;
+    bool rel_cur = relevant(p0);
+    int4 cur = (rel_cur && pos < hi) ? *(const int4 *)(keys + pos) : none;
+    for (long long bp = p0; bp < hi; bp += step) {   // uniform trip count
+        const bool rel_nxt = relevant(bp + step);
+        const int4 nxt = (rel_nxt && pos + step < hi) ? *(const int4 *)(keys + pos + step) : none;
+        if (!rel_cur) {   // wave-uniform: none of this wave's keys can touch the band
+            cur = nxt; rel_cur = rel_nxt; pos += step;
+            continue;
+        }
         const unsigned long long k03 = ((unsigned long long)(unsigned)cur.y << 32) | (unsigned)cur.x;
         const unsigned long long k47 = ((unsigned long long)(unsigned)cur.w << 32) | (unsigned)cur.z;
 #pragma unroll 1
@@ -846,6 +896,7 @@ __global__ __launch_bounds__(kBandThreads) void msda_bwd_band_kernel(const int32
             if (tail1 - head1 >= 64) drain_edge(64);
         }
         cur = nxt;
+        rel_cur = rel_nxt;
         pos += step;
     }
     if (tail0 > head0) drain_full(tail0 - head0);
@@ -1035,11 +1086,17 @@ extern "C" int selfocc_msda_bwd(const float *value, const int32_t *shapes, const
 
 // ---- banded backward -------------------------------------------------------------------------
 static size_t so_band_key_bytes(long long n_pts) { return (size_t)((n_pts + 8) * 2 + 15) / 16 * 16; }
-static size_t so_band_ws_bytes(long long n_pts) { return so_band_key_bytes(n_pts) + (size_t)n_pts * 16; }
+static size_t so_band_range_bytes(int bs, int nq, int heads, int L) {
+    return ((size_t)bs * heads * L * ((nq + kRangeQueries - 1) / kRangeQueries) * 4 + 15) / 16 * 16;
+}
+static size_t so_band_ws_bytes(int bs, int nq, int heads, int L, int P) {
+    const long long n_pts = (long long)bs * nq * heads * L * P;
+    return so_band_key_bytes(n_pts) + (size_t)n_pts * 16 + so_band_range_bytes(bs, nq, heads, L);
+}
 
 extern "C" size_t selfocc_msda_bwd_banded_workspace(int32_t bs, int32_t nq, int32_t heads, int32_t L, int32_t P) {
     if (bs < 0 || nq < 0 || heads < 1 || L < 1 || P < 1) return 0;
-    return so_band_ws_bytes((long long)bs * nq * heads * L * P);
+    return so_band_ws_bytes(bs, nq, heads, L, P);
 }
 
 extern "C" int selfocc_msda_bwd_banded(const float *value, const int32_t *shapes, const int32_t *starts,
@@ -1053,8 +1110,9 @@ extern "C" int selfocc_msda_bwd_banded(const float *value, const int32_t *shapes
     SO_REQUIRE(g_out && g_value && g_loc && g_attw, "msda_bwd_banded: NULL gradient pointer");
     SO_REQUIRE(host_shapes != nullptr, "msda_bwd_banded: host_shapes is NULL (host copy of the (L, 2) level shapes)");
     SO_REQUIRE(L <= 8, "msda_bwd_banded: at most 8 levels (got %d); use selfocc_msda_bwd", L);
-    SO_REQUIRE(workspace != nullptr && workspace_bytes >= so_band_ws_bytes(n_pts),
-               "msda_bwd_banded: workspace too small (%zu bytes, need %zu)", workspace_bytes, so_band_ws_bytes(n_pts));
+    SO_REQUIRE(workspace != nullptr && workspace_bytes >= so_band_ws_bytes(bs, nq, heads, L, P),
+               "msda_bwd_banded: workspace too small (%zu bytes, need %zu)", workspace_bytes,
+               so_band_ws_bytes(bs, nq, heads, L, P));
     SO_REQUIRE(((uintptr_t)workspace & 15) == 0, "msda_bwd_banded: workspace must be 16-byte aligned");
     SO_REQUIRE((long long)nq * P < (1LL << 31), "msda_bwd_banded: nq * P must be < 2^31");
 
@@ -1093,6 +1151,10 @@ extern "C" int selfocc_msda_bwd_banded(const float *value, const int32_t *shapes
     MsdaDims dm{bs, nv, nq, heads, L, P};
     int16_t *keys = (int16_t *)workspace;
     float4 *recs = (float4 *)((char *)workspace + so_band_key_bytes(n_pts));
+    int32_t *ranges = (int32_t *)((char *)recs + (size_t)n_pts * 16);
+    const int nqb = (nq + kRangeQueries - 1) / kRangeQueries;
+    const long long rblocks = (long long)bs * heads * L * nqb;
+    SO_REQUIRE(rblocks < (1LL << 31), "msda_bwd_banded: grid too large");
     const long long pblocks = (n_pts + 255) / 256;
     SO_REQUIRE(pblocks < (1LL << 31), "msda_bwd_banded: grid too large");
     const unsigned bblocks = (unsigned)((long long)bs * heads * items);
@@ -1107,8 +1169,10 @@ extern "C" int selfocc_msda_bwd_banded(const float *value, const int32_t *shapes
         }                                                                                                    \
         hipLaunchKernelGGL((msda_bwd_point_kernel<DD>), dim3((unsigned)pblocks), dim3(256), 0, st, value,    \
                            shapes, starts, loc, attw, g_out, g_loc, g_attw, keys, recs, dm);                 \
+        hipLaunchKernelGGL(msda_key_range_kernel, dim3((unsigned)rblocks), dim3(64), 0, st, keys, ranges, nq, \
+                           P, nqb);                                                                          \
         hipLaunchKernelGGL((msda_bwd_band_kernel<DD>), dim3(bblocks), dim3(kBandThreads), shm, st, shapes,   \
-                           starts, g_out, g_value, keys, recs, dm, plan);                                    \
+                           starts, g_out, g_value, keys, recs, ranges, nqb, dm, plan);                       \
     }
     switch (d) {
         case 4: SO_LAUNCH(4); break;
