@@ -15,6 +15,7 @@
 // d L / d alpha_i = T_i (Gw_i - E_i), Gw_i = total derivative of the loss wrt weight i.
 // The volume gradient is a scatter of 8 (+ 8 * n_feat) hardware float atomics per sample.
 #include "so_device.h"
+#include <type_traits>
 
 namespace {
 
@@ -89,15 +90,38 @@ SO_DEVFN void load_feat(const void *vol, size_t vox, float f[NF > 0 ? NF : 1]) {
     }
 }
 
-template <int NF, bool BF16, int M>
+// WPR = waves per ray.  WPR == 1: a wave owns a ray and M * 64 samples (4 rays per block).  WPR == 4: the
+// block's four waves share one ray, wave w taking step (j * 4 + w) — at the shipped 256 samples per ray
+// that is M = 1, which cuts the per-sample register state 4x (the M = 4 form needed > 256 VGPRs: one wave
+// per SIMD, latency-bound); scan carries and per-ray sums cross the waves through a few floats of LDS.
+template <int NF, bool BF16, int M, int WPR>
 __global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba) {
+    static_assert(WPR == 1 || WPR == 4, "waves per ray");
     const so_render_args &a = ba.fwd;
     constexpr int NSEM = NF > 4 ? NF - 3 : 0;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int ray = blockIdx.x * 4 + wave;
+    const int ray = WPR == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
+    const int wstep = WPR == 1 ? 0 : wave;   // position of this wave inside a step group
+    __shared__ float xch[4][8];
+    // sum of v[0..N) over the waves that share the ray (block-uniform control flow when WPR == 4)
+    auto ray_sum = [&](auto &v, auto nconst) {
+        constexpr int N = decltype(nconst)::value;
+#pragma unroll
+        for (int k = 0; k < N; ++k) v[k] = wave_sum(v[k]);
+        if constexpr (WPR > 1) {
+            if (lane == 0) {
+#pragma unroll
+                for (int k = 0; k < N; ++k) xch[wave][k] = v[k];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < N; ++k) v[k] = (xch[0][k] + xch[1][k]) + (xch[2][k] + xch[3][k]);
+            __syncthreads();
+        }
+    };
     // per-wave transpose buffer of the feature-gradient scatter (phase B); odd record stride
     __shared__ __attribute__((aligned(16))) float lds_rec[NF > 0 ? 4 * 64 * (NF + 9 + (((NF + 9) & 1) ? 0 : 1)) : 4];
-    if (ray >= a.n_rays) return;  // wave-uniform
+    if (ray >= a.n_rays) return;  // wave-uniform (block-uniform when the waves share a ray)
     const int H = a.map.h.tot_len, W = a.map.w.tot_len, D = a.map.d.tot_len;
     const int S = a.n_samples;
     const RayGeomB g = load_ray(a, ray);
@@ -118,10 +142,9 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba) 
     so_cell cell[M];
     float alpha[M], fj[M], tmid[M], delta[M], Pc[M], Nc[M], sdfv[M], halfv[M];
     bool live[M], cneg[M], unclipped[M];
-    float floc = 1.0f;
 #pragma unroll
     for (int j = 0; j < M; ++j) {
-        const int i = lane * M + j;
+        const int i = (j * WPR + wstep) * 64 + lane;   // a step covers 64 CONSECUTIVE samples (one per lane)
         live[j] = i < S;
         const int ic = live[j] ? i : S - 1;
         const float t0 = edge_t(a, ray, ic, tn, tf), t1 = edge_t(a, ray, ic + 1, tn, tf);
@@ -149,28 +172,43 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba) 
         unclipped[j] = (araw > 0.0f) && (araw < 1.0f);
         alpha[j] = live[j] ? fminf(fmaxf(araw, 0.0f), 1.0f) : 0.0f;
         fj[j] = live[j] ? (1.0f - alpha[j]) + 1e-7f : 1.0f;
-        floc *= fj[j];
     }
-    // exclusive prefix product of floc over lanes (Hillis-Steele on shuffles)
-    float incl = floc;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const float o = __shfl_up(incl, d, 64);
-        if (lane >= d) incl *= o;
-    }
-    float Tl = __shfl_up(incl, 1, 64);
-    if (lane == 0) Tl = 1.0f;
+    // transmittance: exclusive prefix product over the samples in ray order = per step an exclusive scan
+    // over the lanes (Hillis-Steele on shuffles) times the product of all earlier steps
     float T[M], w[M];
-    float acc_l = 0.0f, dsum_l = 0.0f;
+    float acc_l = 0.0f, dsum_l = 0.0f, carry = 1.0f;
 #pragma unroll
     for (int j = 0; j < M; ++j) {
-        T[j] = Tl;
-        w[j] = alpha[j] * Tl;
-        Tl *= fj[j];
+        float incl = fj[j];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const float o = __shfl_up(incl, d, 64);
+            if (lane >= d) incl *= o;
+        }
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0f;
+        const float tot = __shfl(incl, 63, 64);
+        float before = carry;                     // product over all earlier steps
+        if constexpr (WPR > 1) {
+            if (lane == 0) xch[wave][0] = tot;
+            __syncthreads();
+#pragma unroll
+            for (int ww = 0; ww < WPR; ++ww) {
+                if (ww < wave) before *= xch[ww][0];
+                carry *= xch[ww][0];
+            }
+            __syncthreads();
+        } else {
+            carry *= tot;
+        }
+        T[j] = before * excl;
+        w[j] = alpha[j] * T[j];
         acc_l += w[j];
         dsum_l = fmaf(w[j], tmid[j], dsum_l);
     }
-    const float acc = wave_sum(acc_l), dsum = wave_sum(dsum_l);
+    float ad[2] = {acc_l, dsum_l};
+    ray_sum(ad, std::integral_constant<int, 2>{});
+    const float acc = ad[0], dsum = ad[1];
     const float inv_ae = 1.0f / (acc + 1e-10f);
     const float depth_raw = dsum * inv_ae;
     const float ddn = (a.flags & SO_FLAG_DEPTH_DIV_NORM) ? 1.0f / g.dn : 1.0f;
@@ -190,7 +228,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba) 
     float Gw[M];
 #pragma unroll
     for (int j = 0; j < M; ++j) {
-        const size_t so = (size_t)ray * S + (lane * M + j);
+        const size_t so = (size_t)ray * S + ((j * WPR + wstep) * 64 + lane);
         Gw[j] = (ba.g_weights && live[j]) ? ba.g_weights[so] : 0.0f;
         Gw[j] += g_depth * (tmid[j] - depth_raw) * inv_ae;
     }
@@ -227,11 +265,12 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba) 
             }
         }
         float bgk[3] = {0.0f, 0.0f, 0.0f};
+        ray_sum(rgb_l, std::integral_constant<int, 3>{});
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             if (a.bkgd_mode == SO_BKGD_CONST) bgk[k] = a.bkgd[k];
             else if (a.bkgd_mode == SO_BKGD_PER_RAY) bgk[k] = a.bkgd_rays[3 * (size_t)ray + k];
-            float r = wave_sum(rgb_l[k]);
+            float r = rgb_l[k];
             if (a.bkgd_mode != SO_BKGD_NONE) r = r + bgk[k] * (1.0f - acc);
             float gk = ba.g_rgb ? ba.g_rgb[3 * (size_t)ray + k] : 0.0f;
             if ((a.flags & SO_FLAG_CLAMP_RGB) && (r < 0.0f || r > 1.0f)) gk = 0.0f;
@@ -308,20 +347,30 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba) 
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                 const int sub = lane % GS, grp = lane / GS;
+                // Row grp serves the samples of lanes grp * GS .. + GS - 1, which are CONSECUTIVE on the ray; a
+                // run of samples inside one voxel (about two at the shipped step / voxel ratio) shares its 8
+                // corners, so the row sums the run's contributions and issues one set of atomics for it.
+                // (The rows of one instruction are GS samples apart: different voxels, no shared L2 line.)
                 for (int t = 0; t < GS; ++t) {
-                    // row grp serves the sample of lane grp * GS + t: the rows of one atomic instruction are
-                    // GS lanes (GS * M samples) apart on the ray, i.e. in different voxels — rows that share a
-                    // line serialise in the L2 atomic unit (94 vs 330 G lane-ops/s, scripts/micro/atomics2.hip)
                     const float *r = rec + (grp * GS + t) * REC;
                     const int base = __float_as_int(r[0]);
-                    const float dfc = (sub < NF) ? r[9 + sub] : 0.0f;
-                    if (sub < NF && dfc != 0.0f) {
+                    if (t > 0 && __float_as_int(r[-REC]) == base) continue;   // inside a run: already added
+                    float val[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+                    int tt = t;
+                    const float *rr = r;
+                    do {
+                        const float dfc = (sub < NF) ? rr[9 + sub] : 0.0f;
+#pragma unroll
+                        for (int kk = 0; kk < 8; ++kk) val[kk] = fmaf(rr[1 + kk], dfc, val[kk]);
+                        ++tt;
+                        rr += REC;
+                    } while (tt < GS && __float_as_int(rr[0]) == base);
+                    if (sub < NF) {
 #pragma unroll
                         for (int kk = 0; kk < 8; ++kk) {
-                            const float wgt = r[1 + kk];
-                            if (wgt != 0.0f) {
+                            if (val[kk] != 0.0f) {
                                 const int vox = base + ((kk >> 2) * W + ((kk >> 1) & 1)) * D + (kk & 1);
-                                unsafeAtomicAdd(ba.g_feat_vol + (size_t)vox * NF + sub, wgt * dfc);
+                                unsafeAtomicAdd(ba.g_feat_vol + (size_t)vox * NF + sub, val[kk]);
                             }
                         }
                     }
@@ -335,33 +384,41 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba) 
     for (int j = 0; j < M; ++j) Gw[j] += g_accum;
 
     // ---- phase C: reverse affine scan  E_i = Gw_{i+1} alpha_{i+1} + f_{i+1} E_{i+1} -----------
-    // lane-local composition over its samples, processed from the last sample to the first:
-    // E_before(first sample of lane) = A_l + B_l * E_after(last sample of lane)
-    float A_l = 0.0f, B_l = 1.0f;
+    // Each sample is the affine map x -> Gw_i alpha_i + f_i x; E_i is the composition of the maps of all
+    // later samples applied to 0.  Per step (last step first): inclusive suffix composition over the lanes,
+    // then E of lane l = (maps of lanes l+1 .. 63 of this step)(E after the step).
+    float Ev[M];
+    float E_end = 0.0f;   // E after the last sample of the current step
 #pragma unroll
     for (int j = M - 1; j >= 0; --j) {
-        // going one sample down: E_{i-1} = Gw_i alpha_i + f_i E_i  => compose (x -> Gw a + f x) after
-        A_l = fmaf(fj[j], A_l, Gw[j] * alpha[j]);
-        B_l = fj[j] * B_l;
-    }
-    // inclusive suffix composition over lanes: (A, B)_l := (A, B)_l o (A, B)_{l+1} o ...
-    float SA = A_l, SB = B_l;
+        float SA = Gw[j] * alpha[j], SB = fj[j];
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const float oa = __shfl_down(SA, d, 64), ob = __shfl_down(SB, d, 64);
-        if (lane + d < 64) { SA = fmaf(SB, oa, SA); SB = SB * ob; }
+        for (int d = 1; d < 64; d <<= 1) {
+            const float oa = __shfl_down(SA, d, 64), ob = __shfl_down(SB, d, 64);
+            if (lane + d < 64) { SA = fmaf(SB, oa, SA); SB = SB * ob; }
+        }
+        const float na = __shfl_down(SA, 1, 64), nb = __shfl_down(SB, 1, 64);
+        const float wa = __shfl(SA, 0, 64), wb = __shfl(SB, 0, 64);   // the whole step as one map
+        float E_mine = E_end;                     // E after the last sample of THIS wave's step
+        if constexpr (WPR > 1) {
+            if (lane == 0) { xch[wave][0] = wa; xch[wave][1] = wb; }
+            __syncthreads();
+#pragma unroll
+            for (int ww = WPR - 1; ww >= 0; --ww) {   // later steps are applied first
+                if (ww > wave) E_mine = fmaf(xch[ww][1], E_mine, xch[ww][0]);
+                E_end = fmaf(xch[ww][1], E_end, xch[ww][0]);
+            }
+            __syncthreads();
+        } else {
+            E_end = fmaf(wb, E_end, wa);
+        }
+        Ev[j] = (lane == 63) ? E_mine : fmaf(nb, E_mine, na);
     }
-    // E after the last sample of this lane = value of the suffix map of lane+1 at E_end = 0
-    float E_after = __shfl_down(SA, 1, 64);
-    if (lane == 63) E_after = 0.0f;
 
     float dinv_s_l = 0.0f;
-    float E = E_after;
 #pragma unroll
     for (int j = M - 1; j >= 0; --j) {
-        // E is E_i for sample i = lane*M + j
-        float dalpha = T[j] * (Gw[j] - E);
-        E = fmaf(fj[j], E, Gw[j] * alpha[j]);
+        float dalpha = T[j] * (Gw[j] - Ev[j]);
         if (!live[j]) continue;
         if (!unclipped[j]) dalpha = 0.0f;
         const float pe = Pc[j] + 1e-5f;
@@ -369,7 +426,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba) 
         const float dN = -dalpha / pe;
         const float da = dP * Pc[j] * (1.0f - Pc[j]);
         const float db = dN * Nc[j] * (1.0f - Nc[j]);
-        const size_t so = (size_t)ray * S + (lane * M + j);
+        const size_t so = (size_t)ray * S + ((j * WPR + wstep) * 64 + lane);
         float ds = (da + db) * a.inv_s;
         const float dh = (db - da) * a.inv_s;
         dinv_s_l += da * (sdfv[j] - halfv[j]) + db * (sdfv[j] + halfv[j]);
@@ -407,13 +464,19 @@ template <int NF, bool BF16>
 int launch_m(const so_render_bwd_args &ba, hipStream_t st) {
     const int S = ba.fwd.n_samples;
     const int m = (S + 63) / 64;
-    const int blocks = (ba.fwd.n_rays + 3) / 4;
-#define SO_L(MM) hipLaunchKernelGGL((render_bwd_kernel<NF, BF16, MM>), dim3(blocks), dim3(256), 0, st, ba)
-    if (m <= 1) SO_L(1);
-    else if (m <= 2) SO_L(2);
-    else if (m <= 4) SO_L(4);
-    else SO_L(8);
+    if (m >= 3) {   // four waves per ray: M = ceil(m / 4) steps per wave
+        const int blocks = ba.fwd.n_rays;
+#define SO_L(MM) hipLaunchKernelGGL((render_bwd_kernel<NF, BF16, MM, 4>), dim3(blocks), dim3(256), 0, st, ba)
+        if (m <= 4) SO_L(1);
+        else SO_L(2);
 #undef SO_L
+    } else {
+        const int blocks = (ba.fwd.n_rays + 3) / 4;
+#define SO_L(MM) hipLaunchKernelGGL((render_bwd_kernel<NF, BF16, MM, 1>), dim3(blocks), dim3(256), 0, st, ba)
+        if (m <= 1) SO_L(1);
+        else SO_L(2);
+#undef SO_L
+    }
     return so_launch_status();
 }
 

@@ -261,7 +261,7 @@ class _RenderFunction(torch.autograd.Function):
         g_sdf_vol = torch.zeros_like(vol.sdf)
         ba.g_sdf_vol = ptr(g_sdf_vol)
         g_feat = None
-        if vol.feat is not None:
+        if vol.feat is not None and ctx.needs_input_grad[1]:
             g_feat = torch.zeros(vol.feat.shape, dtype=torch.float32, device=vol.feat.device)
             ba.g_feat_vol = ptr(g_feat)
         g_inv_s = torch.zeros(1, device=vol.sdf.device)
