@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SELFOCC_ABI_VERSION 9
+#define SELFOCC_ABI_VERSION 10
 
 int selfocc_abi_version(void);
 const char *selfocc_last_error(void);
@@ -217,6 +217,22 @@ int selfocc_msda_bwd_banded(const float *value, const int32_t *shapes, const int
                             const float *g_out, float *g_value, float *g_loc, float *g_attw,
                             int32_t bs, int32_t nv, int32_t nq, int32_t heads, int32_t d,
                             int32_t L, int32_t P, void *workspace, size_t workspace_bytes, void *stream);
+
+/* Training counterpart of selfocc_msda_fused_fwd: gradients w.r.t. value and the RAW linear outputs
+ *   g_off (bs,nq,heads,L,P,2) = (d out / d loc) / (W_l, H_l)
+ *   g_logits (bs,nq,heads,L*P) = aw (g_aw - sum aw g_aw)               (softmax backward)
+ * with the softmax / sampling locations recomputed in registers (the forward saves nothing but its
+ * inputs) and grad_value through the banded LDS-f64 scatter.  host_shapes / workspace as for
+ * selfocc_msda_bwd_banded; requires selfocc_msda_banded_supported(...) == 1 and L*P <= 256.
+ * g_value must be zero-initialised by the caller. */
+int selfocc_msda_banded_supported(const int32_t *host_shapes, int32_t bs, int32_t nq, int32_t heads,
+                                  int32_t d, int32_t L, int32_t P);
+int selfocc_msda_fused_bwd(const float *value, const int32_t *shapes, const int32_t *starts,
+                           const int32_t *host_shapes, const float *ref, int32_t ref_kind,
+                           const float *off_raw, const float *logits, const float *g_out,
+                           float *g_value, float *g_off, float *g_logits, int32_t bs, int32_t nv,
+                           int32_t nq, int32_t heads, int32_t d, int32_t L, int32_t P, void *workspace,
+                           size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Dense SDF / semantic query on a regular metre lattice + Occ3D occupancy tail.

@@ -692,6 +692,155 @@ __global__ __launch_bounds__(256) void msda_bwd_point_kernel(const float *__rest
     recs[ki] = make_float4(bl.lh, bl.lw, aw, __int_as_float((int)(((unsigned)bl.h_low << 16) | ((unsigned)bl.w_low & 0xffffu))));
 }
 
+// team step I with the g_out quarter already in registers (all lanes of a team share the group)
+template <int D, int I>
+SO_DEVFN void so_bwd_team_step_g(const float *__restrict__ value, const float4 &go, int s, const int (&goff)[4],
+                                 float (&dot)[4]) {
+    constexpr int QL = D / 4;
+    float part[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int off = so_team_bcast<QL, I>(goff[k]);
+        const float4 t = *(const float4 *)(value + off + 4 * s);
+        part[k] = t.x * go.x;
+        part[k] = fmaf(t.y, go.y, part[k]);
+        part[k] = fmaf(t.z, go.z, part[k]);
+        part[k] = fmaf(t.w, go.w, part[k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float d = so_team_sum<QL>(part[k]);
+        if (s == I) dot[k] = d;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// fused backward, point part (training): the counterpart of msda_fused_fwd_kernel.  Recomputes the
+// softmax and loc = ref + off / (W_l, H_l) in registers (nothing but value / ref / off_raw / logits was
+// saved by the forward), gathers the corners by channel teams, and writes the gradients of the RAW
+// linear outputs directly:
+//     g_off   = (d out / d loc) / (W_l, H_l)
+//     g_logit = aw (g_aw - sum_group aw g_aw)                     (softmax backward, group reduction on shuffles)
+// plus the keys / records of the banded grad_value scatter.  Replaces, per call, the torch kernels for
+// softmax, off / normalizer, + ref and their three backward kernels, and the 100-400 MB loc / weight
+// tensors with their gradients.
+// ---------------------------------------------------------------------------------------
+template <int D, int LOGG>
+__global__ __launch_bounds__(256) void msda_fused_bwd_point_kernel(const float *__restrict__ value,
+                                                                   const int32_t *__restrict__ shapes,
+                                                                   const int32_t *__restrict__ starts,
+                                                                   const float *__restrict__ ref, int ref_kind,
+                                                                   const float *__restrict__ off_raw,
+                                                                   const float *__restrict__ logits,
+                                                                   const float *__restrict__ g_out,
+                                                                   float *__restrict__ g_off, float *__restrict__ g_logits,
+                                                                   int16_t *__restrict__ keys, float4 *__restrict__ recs,
+                                                                   MsdaDims dm) {
+    constexpr int G = 1 << LOGG;
+    constexpr int QL = D / 4;
+    constexpr int MAXR = 4;
+    const int LP = dm.L * dm.P;
+    const int groups_per_block = 256 / G;
+    const long long n_groups = (long long)dm.bs * dm.nq * dm.heads;
+    const long long gid = (long long)blockIdx.x * groups_per_block + (threadIdx.x / G);
+    const int gl = threadIdx.x & (G - 1);
+    const bool live = gid < n_groups;
+    const long long gq = live ? gid : 0;
+    int h, b;
+    long long bq;                                       // b * nq + q
+    so_split_group(gq, n_groups, dm.nq, dm.heads, h, b, bq);
+    const int q = (int)(bq - (long long)b * dm.nq);
+    const int pix_stride = dm.heads * D;
+    const int s = gl & (QL - 1);
+
+    float lg[MAXR];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+        const int pt = gl + r * G;
+        lg[r] = (pt < LP) ? logits[(size_t)gq * LP + pt] : -INFINITY;
+        mx = fmaxf(mx, lg[r]);
+    }
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+    float den = 0.0f;
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+        lg[r] = (gl + r * G < LP) ? __expf(lg[r] - mx) : 0.0f;
+        den += lg[r];
+    }
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) den += __shfl_xor(den, m, 64);
+    const float iden = 1.0f / den;
+
+    float4 go = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (live) go = *(const float4 *)(g_out + (size_t)gq * D + 4 * s);
+    float ga[MAXR] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float sum_l = 0.0f;
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+        if (r * G >= LP) break;   // uniform
+        const int pt = gl + r * G;
+        const bool own = live && pt < LP;
+        const int ptc = own ? pt : 0;
+        const int l = so_level_of(ptc, dm.P, dm.L);
+        const int pp = ptc - l * dm.P;
+        const int Hl = shapes[2 * l], Wl = shapes[2 * l + 1];
+        const size_t idx = (size_t)gq * LP + ptc;
+        const float2 o = *(const float2 *)(off_raw + 2 * idx);
+        size_t ri;
+        if (ref_kind == 1) ri = (size_t)bq * dm.P + pp;
+        else if (ref_kind == 2) ri = ((size_t)bq * dm.L + l) * dm.P + pp;
+        else ri = (size_t)bq * dm.L + l;
+        const float2 rf = *(const float2 *)(ref + 2 * ri);
+        const float lx = rf.x + o.x / (float)Wl, ly = rf.y + o.y / (float)Hl;
+        const float aw = lg[r] * iden;
+        const Bilin bl = so_bilinear_setup(lx, ly, Hl, Wl, pix_stride);
+        const int vbase = (int)((((long long)b * dm.nv + starts[l]) * dm.heads + h) * D);
+        int goff[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) goff[k] = own ? vbase + bl.off[k] : 0;
+        float dot[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        so_bwd_team_step_g<D, 0>(value, go, s, goff, dot);
+        if constexpr (QL > 1) so_bwd_team_step_g<D, 1>(value, go, s, goff, dot);
+        if constexpr (QL > 2) {
+            so_bwd_team_step_g<D, 2>(value, go, s, goff, dot);
+            so_bwd_team_step_g<D, 3>(value, go, s, goff, dot);
+        }
+        if constexpr (QL > 4) {
+            so_bwd_team_step_g<D, 4>(value, go, s, goff, dot);
+            so_bwd_team_step_g<D, 5>(value, go, s, goff, dot);
+            so_bwd_team_step_g<D, 6>(value, go, s, goff, dot);
+            so_bwd_team_step_g<D, 7>(value, go, s, goff, dot);
+        }
+        if (own) {
+            float gx = 0.0f, gy = 0.0f;
+            if (bl.any) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dot[k] = bl.valid[k] ? dot[k] : 0.0f;
+                ga[r] = (bl.w[0] * dot[0] + bl.w[1] * dot[1]) + (bl.w[2] * dot[2] + bl.w[3] * dot[3]);
+                const float gw = (bl.hh * (dot[1] - dot[0])) + (bl.lh * (dot[3] - dot[2]));
+                const float gh = (bl.hw * (dot[2] - dot[0])) + (bl.lw * (dot[3] - dot[1]));
+                gx = (float)Wl * gw * aw;
+                gy = (float)Hl * gh * aw;
+            }
+            // loc = ref + off / (W, H)  =>  g_off = g_loc / (W, H)
+            *(float2 *)(g_off + 2 * idx) = make_float2(gx / (float)Wl, gy / (float)Hl);
+            sum_l = fmaf(aw, ga[r], sum_l);
+            const size_t ki = ((((size_t)b * dm.heads + h) * dm.L + l) * dm.nq + q) * dm.P + pp;
+            keys[ki] = (int16_t)(bl.any ? bl.h_low : kKeyOutside);
+            recs[ki] = make_float4(bl.lh, bl.lw, aw, __int_as_float((int)(((unsigned)bl.h_low << 16) | ((unsigned)bl.w_low & 0xffffu))));
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) sum_l += __shfl_xor(sum_l, m, 64);
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+        const int pt = gl + r * G;
+        if (live && pt < LP) g_logits[(size_t)gq * LP + pt] = (lg[r] * iden) * (ga[r] - sum_l);
+    }
+}
+
 // Row range of the keys of 64 consecutive queries of one (b, h, level): lets a band skip the key blocks
 // that cannot touch it (consecutive queries of a plane project to neighbouring image rows).
 constexpr int kRangeQueries = 64;
@@ -1099,6 +1248,108 @@ extern "C" size_t selfocc_msda_bwd_banded_workspace(int32_t bs, int32_t nq, int3
     return so_band_ws_bytes(bs, nq, heads, L, P);
 }
 
+namespace {
+struct BandSetup {
+    MsdaBandPlan plan;
+    int max_tile_px;
+    bool ok;     // false: a level is wider than the LDS tile / the maps are huge relative to the points
+};
+
+// work decomposition: bands of rows that fit the LDS tile, query chunks to even out the load
+int so_band_setup(const int32_t *host_shapes, int bs, int nq, int heads, int d, int L, int P, BandSetup &bsu) {
+    MsdaBandPlan &plan = bsu.plan;
+    const int cap_px = kBandTileBytes / (8 * d);
+    long long exam = 0;
+    int items = 0;
+    bsu.max_tile_px = 0;
+    bsu.ok = L <= 8;
+    for (int l = 0; l < 8; ++l) { plan.rows[l] = 1; plan.bands[l] = 0; plan.chunks[l] = 1; plan.prefix[l] = 0; }
+    for (int l = 0; l < L && bsu.ok; ++l) {
+        const int Hl = host_shapes[2 * l], Wl = host_shapes[2 * l + 1];
+        SO_REQUIRE(Hl >= 0 && Wl >= 0 && Hl < 32767 && Wl < 32767, "msda banded: bad level shape (%d, %d)", Hl, Wl);
+        plan.prefix[l] = items;
+        if (Hl == 0 || Wl == 0) continue;
+        if (Wl > cap_px) { bsu.ok = false; break; }
+        plan.rows[l] = std::min(Hl, cap_px / Wl);
+        plan.bands[l] = (Hl + plan.rows[l] - 1) / plan.rows[l];
+        const double pts = (double)nq * P;   // points of this level per (batch, head)
+        const double hits = pts * std::min(1.0, (plan.rows[l] + 1.0) / Hl);
+        int ch = (int)(hits / 8192.0 + 0.5);
+        ch = std::max(1, std::min(ch, std::min(nq, 256)));
+        plan.chunks[l] = ch;
+        items += plan.bands[l] * ch;
+        exam += (long long)plan.bands[l] * nq * P;
+        bsu.max_tile_px = std::max(bsu.max_tile_px, plan.rows[l] * Wl);
+    }
+    for (int l = L; l <= 8; ++l) plan.prefix[std::min(l, 8)] = items;
+    plan.items = items;
+    // very large maps with few queries: scanning every band's keys would cost more than the atomics
+    if (items == 0 || exam > 256LL * L * nq * P || (long long)bs * heads * items >= (1LL << 31) ||
+        (long long)nq * P >= (1LL << 31))
+        bsu.ok = false;
+    return 0;
+}
+
+struct BandWorkspace {
+    int16_t *keys;
+    float4 *recs;
+    int32_t *ranges;
+    int nqb;
+};
+
+BandWorkspace so_band_workspace(void *workspace, int bs, int nq, int heads, int L, int P) {
+    const long long n_pts = (long long)bs * nq * heads * L * P;
+    BandWorkspace w;
+    w.keys = (int16_t *)workspace;
+    w.recs = (float4 *)((char *)workspace + so_band_key_bytes(n_pts));
+    w.ranges = (int32_t *)((char *)w.recs + (size_t)n_pts * 16);
+    w.nqb = (nq + kRangeQueries - 1) / kRangeQueries;
+    return w;
+}
+
+// key ranges + band scatter (after a point kernel filled keys / recs)
+int so_band_scatter(const int32_t *shapes, const int32_t *starts, const float *g_out, float *g_value,
+                    const BandWorkspace &w, const BandSetup &bsu, MsdaDims dm, int d, hipStream_t st) {
+    const long long rblocks = (long long)dm.bs * dm.heads * dm.L * w.nqb;
+    SO_REQUIRE(rblocks < (1LL << 31), "msda banded: grid too large");
+    const unsigned bblocks = (unsigned)((long long)dm.bs * dm.heads * bsu.plan.items);
+    const size_t shm = (size_t)bsu.max_tile_px * d * sizeof(double);
+    hipLaunchKernelGGL(msda_key_range_kernel, dim3((unsigned)rblocks), dim3(64), 0, st, w.keys, w.ranges, dm.nq, dm.P,
+                       w.nqb);
+#define SO_LAUNCH(DD)                                                                                        \
+    {                                                                                                        \
+        static bool attr_set = false;                                                                        \
+        if (!attr_set) {                                                                                     \
+            (void)hipFuncSetAttribute((const void *)msda_bwd_band_kernel<DD>,                                \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kBandTileBytes);           \
+            attr_set = true;                                                                                 \
+        }                                                                                                    \
+        hipLaunchKernelGGL((msda_bwd_band_kernel<DD>), dim3(bblocks), dim3(kBandThreads), shm, st, shapes,   \
+                           starts, g_out, g_value, w.keys, w.recs, w.ranges, w.nqb, dm, bsu.plan);           \
+    }
+    switch (d) {
+        case 4: SO_LAUNCH(4); break;
+        case 8: SO_LAUNCH(8); break;
+        case 16: SO_LAUNCH(16); break;
+        default: SO_LAUNCH(32); break;
+    }
+#undef SO_LAUNCH
+    return so_launch_status();
+}
+}  // namespace
+
+/* 1: the banded scatter applies to these shapes (selfocc_msda_fused_bwd needs it; selfocc_msda_bwd_banded falls
+ * back to selfocc_msda_bwd by itself), 0: it does not, -1: bad arguments */
+extern "C" int selfocc_msda_banded_supported(const int32_t *host_shapes, int32_t bs, int32_t nq, int32_t heads,
+                                             int32_t d, int32_t L, int32_t P) {
+    SO_REQUIRE(host_shapes != nullptr && bs >= 0 && nq >= 0 && heads >= 1 && L >= 1 && P >= 1, "msda banded: bad arguments");
+    SO_REQUIRE(d == 4 || d == 8 || d == 16 || d == 32, "msda: channels per head must be 4, 8, 16 or 32 (got %d)", d);
+    if (L > 8) return 0;
+    BandSetup bsu;
+    if (so_band_setup(host_shapes, bs, nq, heads, d, L, P, bsu)) return -1;
+    return bsu.ok ? 1 : 0;
+}
+
 extern "C" int selfocc_msda_bwd_banded(const float *value, const int32_t *shapes, const int32_t *starts,
                                        const int32_t *host_shapes, const float *loc, const float *attw,
                                        const float *g_out, float *g_value, float *g_loc, float *g_attw,
@@ -1114,65 +1365,75 @@ extern "C" int selfocc_msda_bwd_banded(const float *value, const int32_t *shapes
                "msda_bwd_banded: workspace too small (%zu bytes, need %zu)", workspace_bytes,
                so_band_ws_bytes(bs, nq, heads, L, P));
     SO_REQUIRE(((uintptr_t)workspace & 15) == 0, "msda_bwd_banded: workspace must be 16-byte aligned");
-    SO_REQUIRE((long long)nq * P < (1LL << 31), "msda_bwd_banded: nq * P must be < 2^31");
-
-    // work decomposition: bands of rows that fit the LDS tile, query chunks to even out the load
-    MsdaBandPlan plan;
-    const int cap_px = kBandTileBytes / (8 * d);
-    long long exam = 0;
-    int max_tile_px = 0, items = 0;
-    bool ok = true;
-    for (int l = 0; l < 8; ++l) { plan.rows[l] = 1; plan.bands[l] = 0; plan.chunks[l] = 1; plan.prefix[l] = 0; }
-    for (int l = 0; l < L; ++l) {
-        const int Hl = host_shapes[2 * l], Wl = host_shapes[2 * l + 1];
-        SO_REQUIRE(Hl >= 0 && Wl >= 0 && Hl < 32767 && Wl < 32767, "msda_bwd_banded: bad level shape (%d, %d)", Hl, Wl);
-        plan.prefix[l] = items;
-        if (Hl == 0 || Wl == 0) continue;
-        if (Wl > cap_px) { ok = false; break; }
-        plan.rows[l] = std::min(Hl, cap_px / Wl);
-        plan.bands[l] = (Hl + plan.rows[l] - 1) / plan.rows[l];
-        const double pts = (double)nq * P;   // points of this level per (batch, head)
-        const double hits = pts * std::min(1.0, (plan.rows[l] + 1.0) / Hl);
-        int ch = (int)(hits / 8192.0 + 0.5);
-        ch = std::max(1, std::min(ch, std::min(nq, 256)));
-        plan.chunks[l] = ch;
-        items += plan.bands[l] * ch;
-        exam += (long long)plan.bands[l] * nq * P;
-        max_tile_px = std::max(max_tile_px, plan.rows[l] * Wl);
-    }
-    for (int l = L; l <= 8; ++l) plan.prefix[l] = items;
-    plan.items = items;
-    hipStream_t st = (hipStream_t)stream;
-    // very large maps with few queries: scanning every band's keys would cost more than the atomics
-    if (!ok || items == 0 || exam > 256LL * L * nq * P || (long long)bs * heads * items >= (1LL << 31))
+    BandSetup bsu;
+    if (so_band_setup(host_shapes, bs, nq, heads, d, L, P, bsu)) return -1;
+    if (!bsu.ok)
         return selfocc_msda_bwd(value, shapes, starts, loc, attw, g_out, g_value, g_loc, g_attw, bs, nv, nq, heads,
                                 d, L, P, stream);
-
+    hipStream_t st = (hipStream_t)stream;
     MsdaDims dm{bs, nv, nq, heads, L, P};
-    int16_t *keys = (int16_t *)workspace;
-    float4 *recs = (float4 *)((char *)workspace + so_band_key_bytes(n_pts));
-    int32_t *ranges = (int32_t *)((char *)recs + (size_t)n_pts * 16);
-    const int nqb = (nq + kRangeQueries - 1) / kRangeQueries;
-    const long long rblocks = (long long)bs * heads * L * nqb;
-    SO_REQUIRE(rblocks < (1LL << 31), "msda_bwd_banded: grid too large");
+    const BandWorkspace w = so_band_workspace(workspace, bs, nq, heads, L, P);
     const long long pblocks = (n_pts + 255) / 256;
     SO_REQUIRE(pblocks < (1LL << 31), "msda_bwd_banded: grid too large");
-    const unsigned bblocks = (unsigned)((long long)bs * heads * items);
-    const size_t shm = (size_t)max_tile_px * d * sizeof(double);
 #define SO_LAUNCH(DD)                                                                                        \
-    {                                                                                                        \
-        static bool attr_set = false;                                                                        \
-        if (!attr_set) {                                                                                     \
-            (void)hipFuncSetAttribute((const void *)msda_bwd_band_kernel<DD>,                                \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kBandTileBytes);           \
-            attr_set = true;                                                                                 \
-        }                                                                                                    \
-        hipLaunchKernelGGL((msda_bwd_point_kernel<DD>), dim3((unsigned)pblocks), dim3(256), 0, st, value,    \
-                           shapes, starts, loc, attw, g_out, g_loc, g_attw, keys, recs, dm);                 \
-        hipLaunchKernelGGL(msda_key_range_kernel, dim3((unsigned)rblocks), dim3(64), 0, st, keys, ranges, nq, \
-                           P, nqb);                                                                          \
-        hipLaunchKernelGGL((msda_bwd_band_kernel<DD>), dim3(bblocks), dim3(kBandThreads), shm, st, shapes,   \
-                           starts, g_out, g_value, keys, recs, ranges, nqb, dm, plan);                       \
+    hipLaunchKernelGGL((msda_bwd_point_kernel<DD>), dim3((unsigned)pblocks), dim3(256), 0, st, value,        \
+                       shapes, starts, loc, attw, g_out, g_loc, g_attw, w.keys, w.recs, dm)
+    switch (d) {
+        case 4: SO_LAUNCH(4); break;
+        case 8: SO_LAUNCH(8); break;
+        case 16: SO_LAUNCH(16); break;
+        default: SO_LAUNCH(32); break;
+    }
+#undef SO_LAUNCH
+    return so_band_scatter(shapes, starts, g_out, g_value, w, bsu, dm, d, st);
+}
+
+extern "C" int selfocc_msda_fused_bwd(const float *value, const int32_t *shapes, const int32_t *starts,
+                                      const int32_t *host_shapes, const float *ref, int32_t ref_kind,
+                                      const float *off_raw, const float *logits, const float *g_out,
+                                      float *g_value, float *g_off, float *g_logits, int32_t bs, int32_t nv,
+                                      int32_t nq, int32_t heads, int32_t d, int32_t L, int32_t P, void *workspace,
+                                      size_t workspace_bytes, void *stream) {
+    if (validate(value, shapes, starts, off_raw, logits, bs, nv, nq, heads, d, L, P)) return -1;
+    const long long n_groups = (long long)bs * nq * heads;
+    if (n_groups == 0) return 0;
+    SO_REQUIRE(ref && g_out && g_value && g_off && g_logits, "msda_fused_bwd: NULL pointer");
+    SO_REQUIRE(ref_kind >= 0 && ref_kind <= 2, "msda_fused_bwd: ref_kind must be 0, 1 or 2");
+    SO_REQUIRE(host_shapes != nullptr, "msda_fused_bwd: host_shapes is NULL (host copy of the (L, 2) level shapes)");
+    const int LP = L * P;
+    SO_REQUIRE(LP <= 256, "msda_fused_bwd: L * P must be <= 256 (got %d); use the unfused op", LP);
+    SO_REQUIRE(workspace != nullptr && workspace_bytes >= so_band_ws_bytes(bs, nq, heads, L, P),
+               "msda_fused_bwd: workspace too small (%zu bytes, need %zu)", workspace_bytes,
+               so_band_ws_bytes(bs, nq, heads, L, P));
+    SO_REQUIRE(((uintptr_t)workspace & 15) == 0, "msda_fused_bwd: workspace must be 16-byte aligned");
+    BandSetup bsu;
+    if (so_band_setup(host_shapes, bs, nq, heads, d, L, P, bsu)) return -1;
+    SO_REQUIRE(bsu.ok, "msda_fused_bwd: the banded scatter does not apply to these shapes "
+                       "(check selfocc_msda_banded_supported and use the unfused op)");
+    hipStream_t st = (hipStream_t)stream;
+    MsdaDims dm{bs, nv, nq, heads, L, P};
+    if (nv == 0) {   // every point is outside every (empty) map: all gradients are zero
+        (void)hipMemsetAsync(g_off, 0, (size_t)n_groups * LP * 2 * sizeof(float), st);
+        return (int)hipMemsetAsync(g_logits, 0, (size_t)n_groups * LP * sizeof(float), st);
+    }
+    const BandWorkspace w = so_band_workspace(workspace, bs, nq, heads, L, P);
+    int G = 1, logG = 0;
+    while ((G < LP && G < 64) || G < d / 4) { G <<= 1; ++logG; }
+    const int gpb = 256 / G;
+    const long long blocks = (n_groups + gpb - 1) / gpb;
+    SO_REQUIRE(blocks < (1LL << 31), "msda_fused_bwd: grid too large");
+#define SO_LAUNCH_G(DD, LG)                                                                                  \
+    hipLaunchKernelGGL((msda_fused_bwd_point_kernel<DD, LG>), dim3((unsigned)blocks), dim3(256), 0, st, value, \
+                       shapes, starts, ref, ref_kind, off_raw, logits, g_out, g_off, g_logits, w.keys, w.recs, dm)
+#define SO_LAUNCH(DD)                                                                                        \
+    switch (logG) {                                                                                          \
+        case 0: SO_LAUNCH_G(DD, 0); break;                                                                   \
+        case 1: SO_LAUNCH_G(DD, 1); break;                                                                   \
+        case 2: SO_LAUNCH_G(DD, 2); break;                                                                   \
+        case 3: SO_LAUNCH_G(DD, 3); break;                                                                   \
+        case 4: SO_LAUNCH_G(DD, 4); break;                                                                   \
+        case 5: SO_LAUNCH_G(DD, 5); break;                                                                   \
+        default: SO_LAUNCH_G(DD, 6); break;                                                                  \
     }
     switch (d) {
         case 4: SO_LAUNCH(4); break;
@@ -1181,5 +1442,6 @@ extern "C" int selfocc_msda_bwd_banded(const float *value, const int32_t *shapes
         default: SO_LAUNCH(32); break;
     }
 #undef SO_LAUNCH
-    return so_launch_status();
+#undef SO_LAUNCH_G
+    return so_band_scatter(shapes, starts, g_out, g_value, w, bsu, dm, d, st);
 }

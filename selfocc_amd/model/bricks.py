@@ -9,7 +9,8 @@ import torch
 import torch.nn as nn
 
 from ..registry import MODELS
-from ..msda import MultiScaleDeformableAttnFunction, msda_fused_inference
+from ..msda import (MultiScaleDeformableAttnFunction, msda_fused_inference, MSDAFusedFunction,
+                    msda_fused_supported)
 
 
 class BaseModule(nn.Module):
@@ -138,6 +139,10 @@ class FFN(BaseModule):
         return identity + self.dropout_layer(out)
 
 
+# training path of deformable_sampling: fused prologue + MSDA in both directions (msda.MSDAFusedFunction)
+FUSED_TRAINING = True
+
+
 def deformable_sampling(module, query, value, reference_points, spatial_shapes, level_start_index,
                         per_level_reference, key_padding_mask=None):
     """Shared body of the three deformable attentions: value_proj, offset / weight linears,
@@ -163,6 +168,17 @@ def deformable_sampling(module, query, value, reference_points, spatial_shapes, 
         logits = module.attention_weights(query).view(bs, num_query, module.num_heads, LP)
         kind = {'level': 0, 'point': 1, 'level_point': 2}[per_level_reference]
         return msda_fused_inference(value, spatial_shapes, level_start_index, reference_points, kind, off, logits)
+    if FUSED_TRAINING and value.is_cuda and LP <= 256:
+        # training: the same fusion in both directions (no loc / weight tensors, no softmax / normalise kernels)
+        host = getattr(spatial_shapes, '_so_host', None)
+        if host is None:
+            host = [int(v) for v in spatial_shapes.reshape(-1).tolist()]
+        if msda_fused_supported(host, bs, num_query, module.num_heads, value.shape[-1], module.num_levels,
+                                module.num_points):
+            logits = module.attention_weights(query).view(bs, num_query, module.num_heads, LP)
+            kind = {'level': 0, 'point': 1, 'level_point': 2}[per_level_reference]
+            return MSDAFusedFunction.apply(value, spatial_shapes, level_start_index, reference_points, kind, off,
+                                           logits, host)
     aw = module.attention_weights(query).view(bs, num_query, module.num_heads,
                                               module.num_levels * module.num_points).softmax(-1)
     aw = aw.view(bs, num_query, module.num_heads, module.num_levels, module.num_points)

@@ -140,3 +140,52 @@ def msda_cross_inference(value, spatial_shapes, level_start_index, reference_poi
                                        ptr(out), cams, nv, nq, heads, d, L, P, current_stream(value.device)),
           "selfocc_msda_cross_fwd")
     return out
+
+
+class MSDAFusedFunction(torch.autograd.Function):
+    """Training form of the fused op: out = MSDA(value, ref + off / (W_l, H_l), softmax(logits)) with the
+    prologue inside the kernels in BOTH directions.  The forward saves only its inputs (no sampling_locations /
+    attention_weights tensors); the backward returns gradients w.r.t. value, the raw offsets and the raw
+    logits (``selfocc_msda_fused_bwd``).  Same math as softmax -> loc -> MultiScaleDeformableAttnFunction."""
+
+    @staticmethod
+    def forward(ctx, value, spatial_shapes, level_start_index, reference_points, ref_kind, sampling_offsets,
+                attention_logits, host_shapes):
+        out = msda_fused_inference(value, spatial_shapes, level_start_index, reference_points, ref_kind,
+                                   sampling_offsets, attention_logits)
+        sh = spatial_shapes.to(device=value.device, dtype=torch.int32).contiguous()
+        st = level_start_index.to(device=value.device, dtype=torch.int32).contiguous()
+        ctx.save_for_backward(value, sh, st, reference_points, sampling_offsets, attention_logits)
+        ctx.ref_kind, ctx.host_shapes = int(ref_kind), list(host_shapes)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        import ctypes
+        value, sh, st, ref, off, lg = ctx.saved_tensors
+        value, ref, off, lg = (t.contiguous().float() for t in (value, ref, off, lg))
+        bs, nv, heads, d = value.shape
+        _, nq, _, L, P, _ = off.shape
+        g_out = grad_output.contiguous().float()
+        g_value = torch.zeros_like(value)
+        g_off = torch.empty_like(off)
+        g_lg = torch.empty_like(lg)
+        arr = (ctypes.c_int32 * len(ctx.host_shapes))(*ctx.host_shapes)
+        nbytes = int(lib().selfocc_msda_bwd_banded_workspace(bs, nq, heads, L, P))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=value.device)
+        check(lib().selfocc_msda_fused_bwd(ptr(value), ptr(sh), ptr(st), ctypes.cast(arr, ctypes.c_void_p), ptr(ref),
+                                           ctx.ref_kind, ptr(off), ptr(lg), ptr(g_out), ptr(g_value), ptr(g_off),
+                                           ptr(g_lg), bs, nv, nq, heads, d, L, P, ptr(ws), nbytes,
+                                           current_stream(value.device)),
+              "selfocc_msda_fused_bwd")
+        return g_value, None, None, None, None, g_off, g_lg, None
+
+
+def msda_fused_supported(host_shapes, bs, nq, heads, d, L, P):
+    """True when the fused training op applies (banded scatter possible, L * P <= 256)."""
+    import ctypes
+    if L * P > 256 or L > 8 or d not in (4, 8, 16, 32):
+        return False
+    arr = (ctypes.c_int32 * len(host_shapes))(*host_shapes)
+    return lib().selfocc_msda_banded_supported(ctypes.cast(arr, ctypes.c_void_p), bs, nq, heads, d, L, P) == 1

@@ -154,3 +154,43 @@ def test_msda_cross_camera_loop_matches_per_camera_ops(hip, P, L, D):
     want = want / vis.sum(0).clamp(min=1)[:, None]
     assert torch.allclose(got, want, rtol=1e-4, atol=1e-5), (got - want).abs().max()
     assert torch.all(got[0] == 0)
+
+
+@pytest.mark.parametrize("kind,P,L,D", [(1, 8, 4, 16), (1, 48, 4, 16), (2, 12, 3, 16), (0, 4, 3, 16), (2, 70, 3, 8), (1, 5, 2, 32)])
+def test_msda_fused_training_matches_unfused_autograd(hip, kind, P, L, D):
+    """MSDAFusedFunction (prologue fused in forward AND backward) == torch softmax / loc + plain op under
+    autograd: output and the gradients w.r.t. value, raw offsets and raw logits."""
+    from selfocc_amd.msda import MSDAFusedFunction, msda_fused_supported
+    g = torch.Generator().manual_seed(kind * 100 + P + D)
+    shapes = torch.tensor([[24, 50], [12, 25], [6, 13], [3, 7]][:L])
+    starts = torch.cat([torch.zeros(1, dtype=torch.int64), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    nv = int((shapes[:, 0] * shapes[:, 1]).sum())
+    bs, nq, H = 2, 301, 3
+    host = [int(v) for v in shapes.reshape(-1)]
+    assert msda_fused_supported(host, bs, nq, H, D, L, P)
+    d = torch.device("cuda:0")
+    value = torch.randn(bs, nv, H, D, generator=g).to(d)
+    off = (torch.randn(bs, nq, H, L, P, 2, generator=g) * 3).to(d)
+    logits = (torch.randn(bs, nq, H, L * P, generator=g) * 2).to(d)
+    ref = (torch.rand(*{0: (bs, nq, L, 2), 1: (bs, nq, P, 2), 2: (bs, nq, L, P, 2)}[kind], generator=g) * 1.3 - 0.15).to(d)
+    gout = torch.randn(bs, nq, H * D, generator=g).to(d)
+
+    def run(fused):
+        v, o, lg = (t.clone().requires_grad_(True) for t in (value, off, logits))
+        if fused:
+            out = MSDAFusedFunction.apply(v, shapes.to(d), starts.to(d), ref, kind, o, lg, host)
+        else:
+            aw = lg.softmax(-1).view(bs, nq, H, L, P)
+            norm = torch.stack([shapes[:, 1], shapes[:, 0]], -1).float().to(d)
+            r = {0: ref[:, :, None, :, None, :] if kind == 0 else None, 1: ref[:, :, None, None, :, :] if kind == 1 else None,
+                 2: ref[:, :, None, :, :, :] if kind == 2 else None}[kind]
+            loc = r + o / norm[None, None, None, :, None, :]
+            out = MultiScaleDeformableAttnFunction.apply(v, shapes.to(d), starts.to(d), loc, aw, 64)
+        out.backward(gout)
+        return out.detach(), v.grad, o.grad, lg.grad
+
+    a, b = run(True), run(False)
+    assert torch.allclose(a[0], b[0], rtol=1e-4, atol=1e-5)
+    assert torch.allclose(a[1], b[1], rtol=1e-4, atol=2e-4)                      # grad value
+    assert torch.allclose(a[2], b[2], rtol=1e-3, atol=1e-4 * b[2].abs().max().item())   # grad offsets
+    assert torch.allclose(a[3], b[3], rtol=1e-3, atol=1e-4 * b[3].abs().max().item())   # grad logits
