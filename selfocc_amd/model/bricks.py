@@ -75,7 +75,8 @@ class _TallLinear(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous()
-        T, G = x.shape[0], 256
+        T = x.shape[0]
+        G = max(1, min(256, T // 2048))  # ~2 k+ rows per batched GEMM: enough workgroups, small partial-sum tensor
         R = T // G                       # rows per batched GEMM
         Tp = R * G
         dw = dy.new_zeros(dy.shape[1], x.shape[1])
