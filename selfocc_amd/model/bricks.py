@@ -85,7 +85,7 @@ class _TallLinear(torch.autograd.Function):
             dyb = dy[:Tp].view(G, R, dy.shape[1])
             dw = torch.bmm(dyb.transpose(1, 2), x[:Tp].view(G, R, x.shape[1])).sum(0)
             # bias gradient in two stages as well: torch's column reduction of a (1.65 M, N) matrix has only
-            # N outputs to parallelise over (~200 GB/s, 3.1 ms per call in profiles/r1_g_train_iteration.txt;
+            # N outputs to parallelise over (~200 GB/s, 3.1 ms per call in profiles/r1_h_train_iteration.txt;
             # rocBLAS gemv against a ones vector is worse: 16 ms); (G, R, N).sum(1) has G * N
             db = dyb.sum(1).sum(0)
         if Tp < T:
