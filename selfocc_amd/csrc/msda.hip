@@ -1075,6 +1075,25 @@ int validate(const float *value, const int32_t *shapes, const int32_t *starts, c
 
 }  // namespace
 
+// Lanes per (b, q, head) group: a power of two G >= d / 4 (whole channel teams) with rounds = ceil(LP / G)
+// <= max_rounds; among those the one that wastes the fewest lane-rounds (LP = 36 on G = 64 idles 44 % of the
+// lanes, on G = 16 x 3 rounds 25 %), larger G on ties (fewer rounds).  Used by the plain forward only: the fused
+// kernels redo their prologue every round and measured slower with more rounds.
+static void so_pick_group(int LP, int d, int max_rounds, int &G, int &logG) {
+    int best_l = 6;
+    double best_u = -1.0;
+    for (int lg = 0; lg <= 6; ++lg) {
+        const int g = 1 << lg;
+        if (g < d / 4) continue;
+        const int rounds = (LP + g - 1) / g;
+        if (rounds > max_rounds && lg < 6) continue;
+        const double u = (double)LP / ((double)rounds * g);
+        if (u >= best_u - 1e-12) { best_u = u; best_l = lg; }
+    }
+    logG = best_l;
+    G = 1 << best_l;
+}
+
 extern "C" int selfocc_msda_fwd(const float *value, const int32_t *shapes, const int32_t *starts,
                                 const float *loc, const float *attw, float *out, int32_t bs,
                                 int32_t nv, int32_t nq, int32_t heads, int32_t d, int32_t L,
@@ -1087,7 +1106,7 @@ extern "C" int selfocc_msda_fwd(const float *value, const int32_t *shapes, const
         return (int)hipMemsetAsync(out, 0, (size_t)n_groups * d * sizeof(float), (hipStream_t)stream);
     const int LP = L * P;
     int G = 1, logG = 0;
-    while ((G < LP && G < 64) || G < d / 4) { G <<= 1; ++logG; }
+    so_pick_group(LP, d, 8, G, logG);
     const int gpb = 256 / G;
     const long long blocks = (n_groups + gpb - 1) / gpb;
     SO_REQUIRE(blocks < (1LL << 31), "msda_fwd: grid too large");
@@ -1132,7 +1151,7 @@ extern "C" int selfocc_msda_fused_fwd(const float *value, const int32_t *shapes,
     const int LP = L * P;
     SO_REQUIRE(LP <= 256, "msda_fused_fwd: L * P must be <= 256 (got %d); use the unfused op", LP);
     int G = 1, logG = 0;
-    while ((G < LP && G < 64) || G < d / 4) { G <<= 1; ++logG; }
+    while ((G < LP && G < 64) || G < d / 4) { G <<= 1; ++logG; }   // fewest rounds: the fused prologue is per round
     const int gpb = 256 / G;
     const long long blocks = (n_groups + gpb - 1) / gpb;
     SO_REQUIRE(blocks < (1LL << 31), "msda_fused_fwd: grid too large");
@@ -1176,7 +1195,7 @@ extern "C" int selfocc_msda_cross_fwd(const float *value, const int32_t *shapes,
     SO_REQUIRE(LP <= 256, "msda_cross_fwd: L * P must be <= 256 (got %d)", LP);
     if (nv == 0) return (int)hipMemsetAsync(out, 0, (size_t)n_groups * d * sizeof(float), (hipStream_t)stream);
     int G = 1, logG = 0;
-    while ((G < LP && G < 64) || G < d / 4) { G <<= 1; ++logG; }
+    while ((G < LP && G < 64) || G < d / 4) { G <<= 1; ++logG; }   // fewest rounds: the fused prologue is per round
     const int gpb = 256 / G;
     const long long blocks = (n_groups + gpb - 1) / gpb;
     SO_REQUIRE(blocks < (1LL << 31), "msda_cross_fwd: grid too large");
@@ -1418,7 +1437,7 @@ extern "C" int selfocc_msda_fused_bwd(const float *value, const int32_t *shapes,
     }
     const BandWorkspace w = so_band_workspace(workspace, bs, nq, heads, L, P);
     int G = 1, logG = 0;
-    while ((G < LP && G < 64) || G < d / 4) { G <<= 1; ++logG; }
+    while ((G < LP && G < 64) || G < d / 4) { G <<= 1; ++logG; }   // fewest rounds: the fused prologue is per round
     const int gpb = 256 / G;
     const long long blocks = (n_groups + gpb - 1) / gpb;
     SO_REQUIRE(blocks < (1LL << 31), "msda_fused_bwd: grid too large");
