@@ -874,10 +874,11 @@ struct MsdaBandPlan {
     int items;        // work items per (batch, head)
 };
 
-constexpr int kBandThreads = 512;
-constexpr int kBandTileBytes = 52 * 1024;
+// two block shapes: 512 threads + 52 KB tile (two blocks per CU; fewer EDGE instances wasted per block switch) and
+// 1024 threads + 103 KB tile (one block per CU, 2x taller bands: fewer key scans when a level has many rows)
+constexpr int band_tile_bytes(int threads) { return threads == 512 ? 52 * 1024 : 103 * 1024; }
 
-template <int D>
+template <int D, int kBandThreads>
 __global__ __launch_bounds__(kBandThreads) void msda_bwd_band_kernel(const int32_t *__restrict__ shapes,
                                                                      const int32_t *__restrict__ starts,
                                                                      const float *__restrict__ g_out,
@@ -1271,13 +1272,16 @@ namespace {
 struct BandSetup {
     MsdaBandPlan plan;
     int max_tile_px;
+    int threads;   // block shape of the band kernel (512 / 1024)
     bool ok;     // false: a level is wider than the LDS tile / the maps are huge relative to the points
 };
 
 // work decomposition: bands of rows that fit the LDS tile, query chunks to even out the load
-int so_band_setup(const int32_t *host_shapes, int bs, int nq, int heads, int d, int L, int P, BandSetup &bsu) {
+int so_band_setup_shape(const int32_t *host_shapes, int bs, int nq, int heads, int d, int L, int P, int threads,
+                        BandSetup &bsu) {
     MsdaBandPlan &plan = bsu.plan;
-    const int cap_px = kBandTileBytes / (8 * d);
+    bsu.threads = threads;
+    const int cap_px = band_tile_bytes(threads) / (8 * d);
     long long exam = 0;
     int items = 0;
     bsu.max_tile_px = 0;
@@ -1309,6 +1313,20 @@ int so_band_setup(const int32_t *host_shapes, int bs, int nq, int heads, int d, 
     return 0;
 }
 
+// the small block shape unless a level then needs >= 100 bands (e.g. the 257 x 257 plane of the cross-view
+// self-attention: 257 one-row bands vs 86 three-row bands — every band scans the level's keys)
+int so_band_setup(const int32_t *host_shapes, int bs, int nq, int heads, int d, int L, int P, BandSetup &bsu) {
+    if (so_band_setup_shape(host_shapes, bs, nq, heads, d, L, P, 512, bsu)) return -1;
+    int most = 0;
+    for (int l = 0; l < std::min(L, 8); ++l) most = std::max(most, bsu.plan.bands[l]);
+    if (!bsu.ok || most >= 100) {
+        BandSetup big;
+        if (so_band_setup_shape(host_shapes, bs, nq, heads, d, L, P, 1024, big)) return -1;
+        if (big.ok) bsu = big;
+    }
+    return 0;
+}
+
 struct BandWorkspace {
     int16_t *keys;
     float4 *recs;
@@ -1335,17 +1353,19 @@ int so_band_scatter(const int32_t *shapes, const int32_t *starts, const float *g
     const size_t shm = (size_t)bsu.max_tile_px * d * sizeof(double);
     hipLaunchKernelGGL(msda_key_range_kernel, dim3((unsigned)rblocks), dim3(64), 0, st, w.keys, w.ranges, dm.nq, dm.P,
                        w.nqb);
-#define SO_LAUNCH(DD)                                                                                        \
+#define SO_LAUNCH_T(DD, TT)                                                                                  \
     {                                                                                                        \
         static bool attr_set = false;                                                                        \
         if (!attr_set) {                                                                                     \
-            (void)hipFuncSetAttribute((const void *)msda_bwd_band_kernel<DD>,                                \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kBandTileBytes);           \
+            (void)hipFuncSetAttribute((const void *)msda_bwd_band_kernel<DD, TT>,                            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, band_tile_bytes(TT));      \
             attr_set = true;                                                                                 \
         }                                                                                                    \
-        hipLaunchKernelGGL((msda_bwd_band_kernel<DD>), dim3(bblocks), dim3(kBandThreads), shm, st, shapes,   \
-                           starts, g_out, g_value, w.keys, w.recs, w.ranges, w.nqb, dm, bsu.plan);           \
+        hipLaunchKernelGGL((msda_bwd_band_kernel<DD, TT>), dim3(bblocks), dim3(TT), shm, st, shapes, starts,  \
+                           g_out, g_value, w.keys, w.recs, w.ranges, w.nqb, dm, bsu.plan);                   \
     }
+#define SO_LAUNCH(DD)                                                                                        \
+    if (bsu.threads == 512) SO_LAUNCH_T(DD, 512) else SO_LAUNCH_T(DD, 1024)
     switch (d) {
         case 4: SO_LAUNCH(4); break;
         case 8: SO_LAUNCH(8); break;
@@ -1353,6 +1373,7 @@ int so_band_scatter(const int32_t *shapes, const int32_t *starts, const float *g
         default: SO_LAUNCH(32); break;
     }
 #undef SO_LAUNCH
+#undef SO_LAUNCH_T
     return so_launch_status();
 }
 }  // namespace
