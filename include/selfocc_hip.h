@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SELFOCC_ABI_VERSION 10
+#define SELFOCC_ABI_VERSION 11
 
 int selfocc_abi_version(void);
 const char *selfocc_last_error(void);
@@ -193,6 +193,18 @@ int selfocc_msda_cross_fwd(const float *value, const int32_t *shapes, const int3
                            const float *ref, const uint8_t *vis, const float *off_raw, const float *logits,
                            float *out, int32_t cams, int32_t nv, int32_t nq, int32_t heads, int32_t d,
                            int32_t L, int32_t P, void *stream);
+
+/* Training counterpart of selfocc_msda_cross_fwd: g_out (nq, heads*d) is the gradient of the camera MEAN;
+ * returns g_value (cams,nv,heads,d; zero-initialised by the caller), g_off (nq,heads,L,P,2) and
+ * g_logits (nq,heads,L*P) — sums over the visible cameras / count.  host_shapes and workspace as for
+ * selfocc_msda_bwd_banded with bs = cams (selfocc_msda_bwd_banded_workspace(cams, nq, heads, L, P));
+ * requires selfocc_msda_banded_supported(host_shapes, cams, nq, heads, d, L, P) == 1 and L*P <= 256. */
+int selfocc_msda_cross_bwd(const float *value, const int32_t *shapes, const int32_t *starts,
+                           const int32_t *host_shapes, const float *ref, const uint8_t *vis,
+                           const float *off_raw, const float *logits, const float *g_out,
+                           float *g_value, float *g_off, float *g_logits, int32_t cams, int32_t nv,
+                           int32_t nq, int32_t heads, int32_t d, int32_t L, int32_t P, void *workspace,
+                           size_t workspace_bytes, void *stream);
 
 /* g_value must be zero-initialised by the caller (atomically accumulated). */
 int selfocc_msda_bwd(const float *value, const int32_t *shapes, const int32_t *starts,

@@ -6,7 +6,7 @@ its exported symbols being callable with these layouts.
 """
 import ctypes as C
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 # enums ---------------------------------------------------------------------------
 RAYS_EXPLICIT, RAYS_PIXEL_GRID = 0, 1
@@ -105,6 +105,7 @@ SYMBOLS = {
     "selfocc_msda_fwd": (C.c_int, [_p, _p, _p, _p, _p, _p] + [_i] * 7 + [_p]),
     "selfocc_msda_fused_fwd": (C.c_int, [_p, _p, _p, _p, _i, _p, _p, _p] + [_i] * 7 + [_p]),
     "selfocc_msda_cross_fwd": (C.c_int, [_p] * 8 + [_i] * 7 + [_p]),
+    "selfocc_msda_cross_bwd": (C.c_int, [_p] * 12 + [_i] * 7 + [_p, C.c_size_t, _p]),
     "selfocc_msda_bwd": (C.c_int, [_p] * 9 + [_i] * 7 + [_p]),
     "selfocc_msda_banded_supported": (C.c_int, [_p] + [_i] * 6),
     "selfocc_msda_fused_bwd": (C.c_int, [_p] * 5 + [_i] + [_p] * 6 + [_i] * 7 + [_p, C.c_size_t, _p]),

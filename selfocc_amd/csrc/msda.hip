@@ -28,6 +28,7 @@ namespace {
 
 struct MsdaDims {
     int bs, nv, nq, heads, L, P;
+    int go_shared;   // band kernel: g_out has one row per (query, head) shared by all batch items (camera loop)
 };
 
 struct Bilin {
@@ -841,6 +842,140 @@ __global__ __launch_bounds__(256) void msda_fused_bwd_point_kernel(const float *
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// camera-loop backward, point part (training counterpart of msda_cross_fwd_kernel):
+//   out[q] = (1 / cnt_q) sum_{cam sees q} msda_cam(q)      with shared offsets / logits per query.
+// g_off and g_logits are sums over the visible cameras (divided by cnt); keys / records are written per
+// (cam, h, level, q, p) for the visible cameras only (the key array is pre-filled with "outside"), the
+// record's weight already divided by cnt, and the band kernel reads the shared g_out row (go_shared).
+// ---------------------------------------------------------------------------------------
+template <int D, int LOGG>
+__global__ __launch_bounds__(256) void msda_cross_bwd_point_kernel(const float *__restrict__ value,
+                                                                   const int32_t *__restrict__ shapes,
+                                                                   const int32_t *__restrict__ starts,
+                                                                   const float *__restrict__ ref,
+                                                                   const uint8_t *__restrict__ vis,
+                                                                   const float *__restrict__ off_raw,
+                                                                   const float *__restrict__ logits,
+                                                                   const float *__restrict__ g_out,
+                                                                   float *__restrict__ g_off, float *__restrict__ g_logits,
+                                                                   int16_t *__restrict__ keys, float4 *__restrict__ recs,
+                                                                   int cams, MsdaDims dm) {
+    constexpr int G = 1 << LOGG;
+    constexpr int QL = D / 4;
+    constexpr int MAXR = 4;
+    const int LP = dm.L * dm.P;
+    const int groups_per_block = 256 / G;
+    const int n_groups = dm.nq * dm.heads;
+    const int gid = blockIdx.x * groups_per_block + (threadIdx.x / G);
+    const int gl = threadIdx.x & (G - 1);
+    const bool live = gid < n_groups;
+    const int gq = live ? gid : 0;
+    const int q = gq / dm.heads, h = gq - q * dm.heads;
+    const int pix_stride = dm.heads * D;
+    const int s = gl & (QL - 1);
+
+    float lg[MAXR], ox[MAXR], oy[MAXR];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+        const int pt = gl + r * G;
+        lg[r] = (pt < LP) ? logits[(size_t)gq * LP + pt] : -INFINITY;
+        mx = fmaxf(mx, lg[r]);
+    }
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+    float den = 0.0f;
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+        const int pt = gl + r * G;
+        lg[r] = (pt < LP) ? __expf(lg[r] - mx) : 0.0f;
+        den += lg[r];
+        ox[r] = oy[r] = 0.0f;
+        if (pt < LP) {
+            const int l = so_level_of(pt, dm.P, dm.L);
+            const float2 o = *(const float2 *)(off_raw + 2 * ((size_t)gq * LP + pt));
+            ox[r] = o.x / (float)shapes[2 * l + 1];
+            oy[r] = o.y / (float)shapes[2 * l];
+        }
+    }
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) den += __shfl_xor(den, m, 64);
+    const float iden = 1.0f / den;
+
+    int count = 0;
+    for (int cam = 0; cam < cams; ++cam) count += (live && vis[(size_t)cam * dm.nq + q] != 0) ? 1 : 0;
+    const float cnt = (float)max(count, 1);
+
+    float4 go = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (live) go = *(const float4 *)(g_out + (size_t)gq * D + 4 * s);
+    float ga[MAXR] = {0.0f, 0.0f, 0.0f, 0.0f}, gxs[MAXR] = {0.0f, 0.0f, 0.0f, 0.0f}, gys[MAXR] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int cam = 0; cam < cams; ++cam) {
+        const bool seen = live && vis[(size_t)cam * dm.nq + q] != 0;
+        if (!__any(seen)) continue;                      // no group of this wave sees the camera
+#pragma unroll
+        for (int r = 0; r < MAXR; ++r) {
+            if (r * G >= LP) break;   // uniform
+            const int pt = gl + r * G;
+            const bool own = seen && pt < LP;
+            const int ptc = own ? pt : 0;
+            const int l = so_level_of(ptc, dm.P, dm.L);
+            const int pp = ptc - l * dm.P;
+            const int Hl = shapes[2 * l], Wl = shapes[2 * l + 1];
+            const float2 rf = *(const float2 *)(ref + 2 * (((size_t)cam * dm.nq + q) * dm.P + pp));
+            const float aw = lg[r] * iden;
+            const Bilin bl = so_bilinear_setup(rf.x + ox[r], rf.y + oy[r], Hl, Wl, pix_stride);
+            const int vbase = (int)((((long long)cam * dm.nv + starts[l]) * dm.heads + h) * D);
+            int goff[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) goff[k] = own ? vbase + bl.off[k] : 0;
+            float dot[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+            so_bwd_team_step_g<D, 0>(value, go, s, goff, dot);
+            if constexpr (QL > 1) so_bwd_team_step_g<D, 1>(value, go, s, goff, dot);
+            if constexpr (QL > 2) {
+                so_bwd_team_step_g<D, 2>(value, go, s, goff, dot);
+                so_bwd_team_step_g<D, 3>(value, go, s, goff, dot);
+            }
+            if constexpr (QL > 4) {
+                so_bwd_team_step_g<D, 4>(value, go, s, goff, dot);
+                so_bwd_team_step_g<D, 5>(value, go, s, goff, dot);
+                so_bwd_team_step_g<D, 6>(value, go, s, goff, dot);
+                so_bwd_team_step_g<D, 7>(value, go, s, goff, dot);
+            }
+            if (own && bl.any) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dot[k] = bl.valid[k] ? dot[k] : 0.0f;
+                ga[r] += (bl.w[0] * dot[0] + bl.w[1] * dot[1]) + (bl.w[2] * dot[2] + bl.w[3] * dot[3]);
+                const float gw = (bl.hh * (dot[1] - dot[0])) + (bl.lh * (dot[3] - dot[2]));
+                const float gh = (bl.hw * (dot[2] - dot[0])) + (bl.lw * (dot[3] - dot[1]));
+                gxs[r] += ((float)Wl * gw * aw) / (float)Wl;
+                gys[r] += ((float)Hl * gh * aw) / (float)Hl;
+                const size_t ki = ((((size_t)cam * dm.heads + h) * dm.L + l) * dm.nq + q) * dm.P + pp;
+                keys[ki] = (int16_t)bl.h_low;
+                recs[ki] = make_float4(bl.lh, bl.lw, aw / cnt,
+                                       __int_as_float((int)(((unsigned)bl.h_low << 16) | ((unsigned)bl.w_low & 0xffffu))));
+            }
+        }
+    }
+    float sum_l = 0.0f;
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+        ga[r] = ga[r] / cnt;
+        sum_l = fmaf(lg[r] * iden, ga[r], sum_l);
+    }
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) sum_l += __shfl_xor(sum_l, m, 64);
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) {
+        const int pt = gl + r * G;
+        if (live && pt < LP) {
+            const size_t idx = (size_t)gq * LP + pt;
+            g_logits[idx] = (lg[r] * iden) * (ga[r] - sum_l);
+            *(float2 *)(g_off + 2 * idx) = make_float2(gxs[r] / cnt, gys[r] / cnt);
+        }
+    }
+}
+
 // Row range of the keys of 64 consecutive queries of one (b, h, level): lets a band skip the key blocks
 // that cannot touch it (consecutive queries of a plane project to neighbouring image rows).
 constexpr int kRangeQueries = 64;
@@ -953,7 +1088,7 @@ __global__ __launch_bounds__(kBandThreads) void msda_bwd_band_kernel(const int32
                 w4 = make_float4((rv && c0) ? (wy * hw) * aw : 0.0f, (rv && c1) ? (wy * lw) * aw : 0.0f, 0.0f, 0.0f);
                 p4 = make_int4((r0 + x0) * D, (r0 + x1) * D, 0, 0);
             }
-            gq32 = (int)(((long long)b * dm.nq + q) * dm.heads + h);
+            gq32 = dm.go_shared ? q * dm.heads + h : (int)(((long long)b * dm.nq + q) * dm.heads + h);
         }
         recW[threadIdx.x] = w4;
         recP[threadIdx.x] = p4;
@@ -1111,7 +1246,7 @@ extern "C" int selfocc_msda_fwd(const float *value, const int32_t *shapes, const
     const int gpb = 256 / G;
     const long long blocks = (n_groups + gpb - 1) / gpb;
     SO_REQUIRE(blocks < (1LL << 31), "msda_fwd: grid too large");
-    MsdaDims dm{bs, nv, nq, heads, L, P};
+    MsdaDims dm{bs, nv, nq, heads, L, P, 0};
     hipStream_t st = (hipStream_t)stream;
 #define SO_LAUNCH_G(DD, LG)                                                                       \
     hipLaunchKernelGGL((msda_fwd_kernel<DD, LG>), dim3((unsigned)blocks), dim3(256), 0, st, value, \
@@ -1156,7 +1291,7 @@ extern "C" int selfocc_msda_fused_fwd(const float *value, const int32_t *shapes,
     const int gpb = 256 / G;
     const long long blocks = (n_groups + gpb - 1) / gpb;
     SO_REQUIRE(blocks < (1LL << 31), "msda_fused_fwd: grid too large");
-    MsdaDims dm{bs, nv, nq, heads, L, P};
+    MsdaDims dm{bs, nv, nq, heads, L, P, 0};
     hipStream_t st = (hipStream_t)stream;
 #define SO_LAUNCH_G(DD, LG)                                                                             \
     hipLaunchKernelGGL((msda_fused_fwd_kernel<DD, LG>), dim3((unsigned)blocks), dim3(256), 0, st, value, \
@@ -1200,7 +1335,7 @@ extern "C" int selfocc_msda_cross_fwd(const float *value, const int32_t *shapes,
     const int gpb = 256 / G;
     const long long blocks = (n_groups + gpb - 1) / gpb;
     SO_REQUIRE(blocks < (1LL << 31), "msda_cross_fwd: grid too large");
-    MsdaDims dm{1, nv, nq, heads, L, P};
+    MsdaDims dm{1, nv, nq, heads, L, P, 0};
     hipStream_t st = (hipStream_t)stream;
 #define SO_LAUNCH_G(DD, LG)                                                                             \
     hipLaunchKernelGGL((msda_cross_fwd_kernel<DD, LG>), dim3((unsigned)blocks), dim3(256), 0, st, value, \
@@ -1237,7 +1372,7 @@ extern "C" int selfocc_msda_bwd(const float *value, const int32_t *shapes, const
     SO_REQUIRE(g_out && g_value && g_loc && g_attw, "msda_bwd: NULL gradient pointer");
     const long long blocks = (n_pts + 255) / 256;
     SO_REQUIRE(blocks < (1LL << 31), "msda_bwd: grid too large");
-    MsdaDims dm{bs, nv, nq, heads, L, P};
+    MsdaDims dm{bs, nv, nq, heads, L, P, 0};
     hipStream_t st = (hipStream_t)stream;
 #define SO_LAUNCH(DD)                                                                             \
     hipLaunchKernelGGL((msda_bwd_kernel<DD>), dim3((unsigned)blocks), dim3(256), 0, st, value,    \
@@ -1411,7 +1546,7 @@ extern "C" int selfocc_msda_bwd_banded(const float *value, const int32_t *shapes
         return selfocc_msda_bwd(value, shapes, starts, loc, attw, g_out, g_value, g_loc, g_attw, bs, nv, nq, heads,
                                 d, L, P, stream);
     hipStream_t st = (hipStream_t)stream;
-    MsdaDims dm{bs, nv, nq, heads, L, P};
+    MsdaDims dm{bs, nv, nq, heads, L, P, 0};
     const BandWorkspace w = so_band_workspace(workspace, bs, nq, heads, L, P);
     const long long pblocks = (n_pts + 255) / 256;
     SO_REQUIRE(pblocks < (1LL << 31), "msda_bwd_banded: grid too large");
@@ -1451,7 +1586,7 @@ extern "C" int selfocc_msda_fused_bwd(const float *value, const int32_t *shapes,
     SO_REQUIRE(bsu.ok, "msda_fused_bwd: the banded scatter does not apply to these shapes "
                        "(check selfocc_msda_banded_supported and use the unfused op)");
     hipStream_t st = (hipStream_t)stream;
-    MsdaDims dm{bs, nv, nq, heads, L, P};
+    MsdaDims dm{bs, nv, nq, heads, L, P, 0};
     if (nv == 0) {   // every point is outside every (empty) map: all gradients are zero
         (void)hipMemsetAsync(g_off, 0, (size_t)n_groups * LP * 2 * sizeof(float), st);
         return (int)hipMemsetAsync(g_logits, 0, (size_t)n_groups * LP * sizeof(float), st);
@@ -1465,6 +1600,69 @@ extern "C" int selfocc_msda_fused_bwd(const float *value, const int32_t *shapes,
 #define SO_LAUNCH_G(DD, LG)                                                                                  \
     hipLaunchKernelGGL((msda_fused_bwd_point_kernel<DD, LG>), dim3((unsigned)blocks), dim3(256), 0, st, value, \
                        shapes, starts, ref, ref_kind, off_raw, logits, g_out, g_off, g_logits, w.keys, w.recs, dm)
+#define SO_LAUNCH(DD)                                                                                        \
+    switch (logG) {                                                                                          \
+        case 0: SO_LAUNCH_G(DD, 0); break;                                                                   \
+        case 1: SO_LAUNCH_G(DD, 1); break;                                                                   \
+        case 2: SO_LAUNCH_G(DD, 2); break;                                                                   \
+        case 3: SO_LAUNCH_G(DD, 3); break;                                                                   \
+        case 4: SO_LAUNCH_G(DD, 4); break;                                                                   \
+        case 5: SO_LAUNCH_G(DD, 5); break;                                                                   \
+        default: SO_LAUNCH_G(DD, 6); break;                                                                  \
+    }
+    switch (d) {
+        case 4: SO_LAUNCH(4); break;
+        case 8: SO_LAUNCH(8); break;
+        case 16: SO_LAUNCH(16); break;
+        default: SO_LAUNCH(32); break;
+    }
+#undef SO_LAUNCH
+#undef SO_LAUNCH_G
+    return so_band_scatter(shapes, starts, g_out, g_value, w, bsu, dm, d, st);
+}
+
+
+extern "C" int selfocc_msda_cross_bwd(const float *value, const int32_t *shapes, const int32_t *starts,
+                                      const int32_t *host_shapes, const float *ref, const uint8_t *vis,
+                                      const float *off_raw, const float *logits, const float *g_out,
+                                      float *g_value, float *g_off, float *g_logits, int32_t cams, int32_t nv,
+                                      int32_t nq, int32_t heads, int32_t d, int32_t L, int32_t P, void *workspace,
+                                      size_t workspace_bytes, void *stream) {
+    SO_REQUIRE(cams >= 1, "msda_cross_bwd: cams must be >= 1");
+    if (validate(value, shapes, starts, off_raw, logits, cams, nv, nq, heads, d, L, P)) return -1;
+    const long long n_groups = (long long)nq * heads;
+    if (n_groups == 0) return 0;
+    SO_REQUIRE(ref && vis && g_out && g_value && g_off && g_logits, "msda_cross_bwd: NULL pointer");
+    SO_REQUIRE(n_groups < (1LL << 31), "msda_cross_bwd: nq * heads must be < 2^31");
+    SO_REQUIRE(host_shapes != nullptr, "msda_cross_bwd: host_shapes is NULL (host copy of the (L, 2) level shapes)");
+    const int LP = L * P;
+    SO_REQUIRE(LP <= 256, "msda_cross_bwd: L * P must be <= 256 (got %d)", LP);
+    SO_REQUIRE(workspace != nullptr && workspace_bytes >= so_band_ws_bytes(cams, nq, heads, L, P),
+               "msda_cross_bwd: workspace too small (%zu bytes, need %zu)", workspace_bytes,
+               so_band_ws_bytes(cams, nq, heads, L, P));
+    SO_REQUIRE(((uintptr_t)workspace & 15) == 0, "msda_cross_bwd: workspace must be 16-byte aligned");
+    BandSetup bsu;
+    if (so_band_setup(host_shapes, cams, nq, heads, d, L, P, bsu)) return -1;
+    SO_REQUIRE(bsu.ok, "msda_cross_bwd: the banded scatter does not apply to these shapes "
+                       "(check selfocc_msda_banded_supported with bs = cams)");
+    hipStream_t st = (hipStream_t)stream;
+    const long long n_pts = (long long)cams * nq * heads * LP;
+    if (nv == 0) {
+        (void)hipMemsetAsync(g_off, 0, (size_t)n_groups * LP * 2 * sizeof(float), st);
+        return (int)hipMemsetAsync(g_logits, 0, (size_t)n_groups * LP * sizeof(float), st);
+    }
+    MsdaDims dm{cams, nv, nq, heads, L, P, 1};
+    const BandWorkspace w = so_band_workspace(workspace, cams, nq, heads, L, P);
+    // every (camera, query) the kernel does not visit stays "outside"
+    (void)hipMemsetD16Async((hipDeviceptr_t)w.keys, (unsigned short)0x8000, (size_t)n_pts, st);
+    int G = 1, logG = 0;
+    while ((G < LP && G < 64) || G < d / 4) { G <<= 1; ++logG; }
+    const int gpb = 256 / G;
+    const long long blocks = (n_groups + gpb - 1) / gpb;
+    SO_REQUIRE(blocks < (1LL << 31), "msda_cross_bwd: grid too large");
+#define SO_LAUNCH_G(DD, LG)                                                                                  \
+    hipLaunchKernelGGL((msda_cross_bwd_point_kernel<DD, LG>), dim3((unsigned)blocks), dim3(256), 0, st, value, \
+                       shapes, starts, ref, vis, off_raw, logits, g_out, g_off, g_logits, w.keys, w.recs, cams, dm)
 #define SO_LAUNCH(DD)                                                                                        \
     switch (logG) {                                                                                          \
         case 0: SO_LAUNCH_G(DD, 0); break;                                                                   \

@@ -16,7 +16,7 @@ import torch.nn as nn
 from ...registry import MODELS, build_attention
 from ..bricks import (BaseModule, MultiScaleDeformableAttention, TallLinear, constant_init, xavier_init,
                       deformable_sampling)
-from ...msda import msda_cross_inference
+from ...msda import msda_cross_inference, MSDACrossFunction, msda_fused_supported
 
 
 @MODELS.register_module()
@@ -115,11 +115,19 @@ class BEVCrossAttention(BaseModule):
         num_cams = self.num_cams
         D = reference_points_cams.size(3)
         da = self.deformable_attention
-        if (self.camera_loop and not torch.is_grad_enabled() and bs == 1 and query.is_cuda
-                and isinstance(da, BEVDeformableAttention) and da.batch_first
-                and da.num_levels * da.num_points <= 256):
-            return self._forward_camera_loop(query, value, residual, spatial_shapes, reference_points_cams,
-                                             bev_masks, level_start_index)
+        if (self.camera_loop and bs == 1 and query.is_cuda and isinstance(da, BEVDeformableAttention)
+                and da.batch_first and da.num_levels * da.num_points <= 256):
+            host = None
+            if torch.is_grad_enabled():
+                host = getattr(spatial_shapes, '_so_host', None)
+                if host is None:
+                    host = [int(v) for v in spatial_shapes.reshape(-1).tolist()]
+                if not msda_fused_supported(host, num_cams, num_query, da.num_heads, self.embed_dims // da.num_heads,
+                                            da.num_levels, da.num_points):
+                    host = False
+            if host is not False:
+                return self._forward_camera_loop(query, value, residual, spatial_shapes, reference_points_cams,
+                                                 bev_masks, level_start_index, host)
         plan = kwargs.get('rebatch_plan')
         if plan is None:
             plan = self.rebatch_plan(bev_masks)
@@ -146,8 +154,8 @@ class BEVCrossAttention(BaseModule):
 
 
     def _forward_camera_loop(self, query, value, residual, spatial_shapes, reference_points_cams, bev_masks,
-                             level_start_index):
-        """Inference: no re-batch.  The offset / weight linears depend on the query only, so they run once
+                             level_start_index, host_shapes=None):
+        """No re-batch (inference: plain op; training: MSDACrossFunction under autograd).  The offset / weight linears depend on the query only, so they run once
         on the num_query rows; one HIP launch loops over the cameras that see each query and averages
         (selfocc_msda_cross_fwd) — same arithmetic as the re-batched path, camera order preserved."""
         da = self.deformable_attention
@@ -158,8 +166,12 @@ class BEVCrossAttention(BaseModule):
         off = da.sampling_offsets(query[0]).view(-1, heads, L, P, 2)
         logits = da.attention_weights(query[0]).view(-1, heads, L * P)
         visible = bev_masks[:, 0].any(-1)                                   # (cams, Q), batch element 0 as the reference
-        slots = msda_cross_inference(v, spatial_shapes, level_start_index, reference_points_cams[:, 0], visible,
-                                     off, logits)[None]
+        if host_shapes is None:
+            slots = msda_cross_inference(v, spatial_shapes, level_start_index, reference_points_cams[:, 0], visible,
+                                         off, logits)[None]
+        else:
+            slots = MSDACrossFunction.apply(v, spatial_shapes, level_start_index, reference_points_cams[:, 0], visible,
+                                            off, logits, host_shapes)[None]
         slots = self.output_proj(slots)
         return self.dropout(slots) + residual
 

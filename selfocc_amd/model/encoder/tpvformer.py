@@ -277,9 +277,9 @@ class TPVFormerEncoder(_EncoderBase):
             reference_points_cams.append(cam)
             tpv_masks.append(mask)
         ref_cross_view = self.cross_view_ref_points.clone().unsqueeze(0).expand(bs, -1, -1, -1, -1)
-        # geometry only: shared by all layers.  Inference needs no plan (camera-loop kernel, no host sync);
-        # a layer that cannot take that path builds its own.
-        plans = [BEVCrossAttention.rebatch_plan(m) for m in tpv_masks] if torch.is_grad_enabled() else None
+        # the camera-loop kernels need no re-batch plan (no host sync); a layer that cannot take that path
+        # (batch > 1, shapes the banded scatter does not cover) builds its own
+        plans = None
         for layer in self.layers:
             tpv_query = layer(tpv_query, key, value, tpv_pos=tpv_pos, ref_2d=ref_cross_view,
                               spatial_shapes=spatial_shapes, level_start_index=level_start_index,
@@ -325,7 +325,7 @@ class BEVFormerEncoder(_EncoderBase):
         bs = bev_query.shape[0]
         cam, mask = point_sampling(self.ref_3d.unsqueeze(0).repeat(bs, 1, 1, 1), img_metas)
         ref_2d = self.ref_2d.unsqueeze(0).repeat(bs, 1, 1, 1).reshape(bs, -1, 1, 2)
-        plan = BEVCrossAttention.rebatch_plan(mask) if torch.is_grad_enabled() else None
+        plan = None   # see TPVFormerEncoder.forward_layers
         for layer in self.layers:
             bev_query = layer(bev_query, key, value, bev_pos=bev_pos, ref_2d=ref_2d, spatial_shapes=spatial_shapes,
                               level_start_index=level_start_index, reference_points_cams=cam, bev_masks=mask,

@@ -189,3 +189,44 @@ def msda_fused_supported(host_shapes, bs, nq, heads, d, L, P):
         return False
     arr = (ctypes.c_int32 * len(host_shapes))(*host_shapes)
     return lib().selfocc_msda_banded_supported(ctypes.cast(arr, ctypes.c_void_p), bs, nq, heads, d, L, P) == 1
+
+
+class MSDACrossFunction(torch.autograd.Function):
+    """Training form of ``msda_cross_inference``: the camera-loop sampling stage of BEVCrossAttention under
+    autograd.  Differentiable inputs: value (cams,nv,h,d), sampling_offsets (nq,h,L,P,2), attention_logits
+    (nq,h,L*P); the reference points and the visibility mask are geometry (no gradient)."""
+
+    @staticmethod
+    def forward(ctx, value, spatial_shapes, level_start_index, reference_points_cam, visible, sampling_offsets,
+                attention_logits, host_shapes):
+        out = msda_cross_inference(value, spatial_shapes, level_start_index, reference_points_cam, visible,
+                                   sampling_offsets, attention_logits)
+        sh = spatial_shapes.to(device=value.device, dtype=torch.int32).contiguous()
+        st = level_start_index.to(device=value.device, dtype=torch.int32).contiguous()
+        ctx.save_for_backward(value, sh, st, reference_points_cam, visible.to(torch.uint8), sampling_offsets,
+                              attention_logits)
+        ctx.host_shapes = list(host_shapes)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        import ctypes
+        value, sh, st, ref, vis, off, lg = ctx.saved_tensors
+        value, ref, off, lg = (t.contiguous().float() for t in (value, ref, off, lg))
+        vis = vis.contiguous()
+        cams, nv, heads, d = value.shape
+        nq, _, L, P, _ = off.shape
+        g_out = grad_output.contiguous().float()
+        g_value = torch.zeros_like(value)
+        g_off = torch.empty_like(off)
+        g_lg = torch.empty_like(lg)
+        arr = (ctypes.c_int32 * len(ctx.host_shapes))(*ctx.host_shapes)
+        nbytes = int(lib().selfocc_msda_bwd_banded_workspace(cams, nq, heads, L, P))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=value.device)
+        check(lib().selfocc_msda_cross_bwd(ptr(value), ptr(sh), ptr(st), ctypes.cast(arr, ctypes.c_void_p), ptr(ref),
+                                           ptr(vis), ptr(off), ptr(lg), ptr(g_out), ptr(g_value), ptr(g_off),
+                                           ptr(g_lg), cams, nv, nq, heads, d, L, P, ptr(ws), nbytes,
+                                           current_stream(value.device)),
+              "selfocc_msda_cross_bwd")
+        return g_value, None, None, None, None, g_off, g_lg, None

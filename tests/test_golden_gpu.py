@@ -95,6 +95,7 @@ def test_encoder_backward_runs(hip):
     cfg = json.load(open(os.path.join(G, "encoder_cfg.json")))
     enc = MODELS.build(dict(type='TPVFormerEncoder', **copy.deepcopy(cfg['encoder']))).to(D0)
     enc.init_weights()
+    enc.eval()   # no dropout: the two paths compared below must see the same network
     lifter = MODELS.build(dict(type='TPVQueryLifter', **cfg['lifter'])).to(D0)
     feats = [torch.tensor(enc_np['feat0']).to(D0).requires_grad_(True), torch.tensor(enc_np['feat1']).to(D0)]
     metas = [dict(lidar2img=enc_np['lidar2img'], img_shape=tuple(cfg['img_shape']))]
@@ -103,3 +104,21 @@ def test_encoder_backward_runs(hip):
     assert torch.isfinite(feats[0].grad).all() and feats[0].grad.abs().sum() > 0
     for n, p in enc.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), n
+    # the camera-loop training path (default) and the re-batch path give the same gradients
+    from selfocc_amd.model.encoder.attention import BEVCrossAttention
+    g_loop = {n: p.grad.clone() for n, p in enc.named_parameters()}
+    g_feat = feats[0].grad.clone()
+    for m in enc.modules():
+        if isinstance(m, BEVCrossAttention):
+            assert m.camera_loop
+            m.camera_loop = False
+    enc.zero_grad(); feats[0].grad = None
+    out = enc(lifter(feats)['representation'], ms_img_feats=feats, metas=metas)['representation']
+    sum(o.square().mean() for o in out).backward()
+    # gradients here are ~1e-8 on activations of order 1 (LayerNorm / softmax cancellations): the two float32
+    # evaluation orders agree to a few per cent of each tensor's scale (measured 0.9 % / 2 %); the kernels
+    # themselves are checked at 1e-3 / 1e-4 in tests/test_msda_gpu.py
+    assert torch.allclose(feats[0].grad, g_feat, rtol=0, atol=5e-2 * g_feat.abs().max().item())
+    for n, p in enc.named_parameters():
+        scale = max(g_loop[n].abs().max().item(), 1e-12)
+        assert torch.allclose(p.grad, g_loop[n], rtol=0, atol=8e-2 * scale), n

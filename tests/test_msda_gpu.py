@@ -194,3 +194,48 @@ def test_msda_fused_training_matches_unfused_autograd(hip, kind, P, L, D):
     assert torch.allclose(a[1], b[1], rtol=1e-4, atol=2e-4)                      # grad value
     assert torch.allclose(a[2], b[2], rtol=1e-3, atol=1e-4 * b[2].abs().max().item())   # grad offsets
     assert torch.allclose(a[3], b[3], rtol=1e-3, atol=1e-4 * b[3].abs().max().item())   # grad logits
+
+
+@pytest.mark.parametrize("P,L,D", [(8, 4, 16), (48, 4, 16), (5, 2, 8), (3, 1, 32)])
+def test_msda_cross_training_matches_per_camera_autograd(hip, P, L, D):
+    """MSDACrossFunction (camera loop, fused prologue, both directions) == mean over the visible cameras of
+    the plain op under torch autograd: output and gradients w.r.t. value, raw offsets, raw logits."""
+    from selfocc_amd.msda import MSDACrossFunction, msda_fused_supported
+    g = torch.Generator().manual_seed(P * 7 + L)
+    shapes = torch.tensor([[24, 50], [12, 25], [6, 13], [3, 7]][:L])
+    starts = torch.cat([torch.zeros(1, dtype=torch.int64), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    nv = int((shapes[:, 0] * shapes[:, 1]).sum())
+    cams, nq, H = 4, 260, 3
+    host = [int(v) for v in shapes.reshape(-1)]
+    assert msda_fused_supported(host, cams, nq, H, D, L, P)
+    d = torch.device("cuda:0")
+    value = torch.randn(cams, nv, H, D, generator=g).to(d)
+    off = (torch.randn(nq, H, L, P, 2, generator=g) * 3).to(d)
+    logits = (torch.randn(nq, H, L * P, generator=g) * 2).to(d)
+    ref = (torch.rand(cams, nq, P, 2, generator=g) * 1.4 - 0.2).to(d)
+    vis = torch.rand(cams, nq, generator=g) < 0.45
+    vis[:, 0] = False; vis[:, 1] = True
+    vis = vis.to(d)
+    gout = torch.randn(nq, H * D, generator=g).to(d)
+
+    def run(fused):
+        v, o, lg = (t.clone().requires_grad_(True) for t in (value, off, logits))
+        if fused:
+            out = MSDACrossFunction.apply(v, shapes.to(d), starts.to(d), ref, vis, o, lg, host)
+        else:
+            aw = lg.softmax(-1).view(1, nq, H, L, P)
+            norm = torch.stack([shapes[:, 1], shapes[:, 0]], -1).float().to(d)
+            out = torch.zeros(nq, H * D, device=d)
+            for c in range(cams):
+                loc = ref[c][None, :, None, None, :, :] + o[None] / norm[None, None, None, :, None, :]
+                oc = MultiScaleDeformableAttnFunction.apply(v[c:c + 1], shapes.to(d), starts.to(d), loc, aw, 64)[0]
+                out = out + oc * vis[c][:, None]
+            out = out / vis.sum(0).clamp(min=1)[:, None]
+        out.backward(gout)
+        return out.detach(), v.grad, o.grad, lg.grad
+
+    a, b = run(True), run(False)
+    assert torch.allclose(a[0], b[0], rtol=1e-4, atol=1e-5)
+    assert torch.allclose(a[1], b[1], rtol=1e-4, atol=2e-4)
+    assert torch.allclose(a[2], b[2], rtol=1e-3, atol=1e-4 * b[2].abs().max().item())
+    assert torch.allclose(a[3], b[3], rtol=1e-3, atol=1e-4 * b[3].abs().max().item())
