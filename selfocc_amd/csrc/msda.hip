@@ -980,16 +980,18 @@ __global__ __launch_bounds__(256) void msda_cross_bwd_point_kernel(const float *
 // that cannot touch it (consecutive queries of a plane project to neighbouring image rows).
 constexpr int kRangeQueries = 64;
 
-__global__ __launch_bounds__(64) void msda_key_range_kernel(const int16_t *__restrict__ keys, int32_t *__restrict__ ranges,
-                                                            int nq, int P, int nqb) {
-    const long long blk = blockIdx.x;                         // (b, h, l) * nqb + qb
+__global__ __launch_bounds__(256) void msda_key_range_kernel(const int16_t *__restrict__ keys, int32_t *__restrict__ ranges,
+                                                             int nq, int P, int nqb, long long n_ranges) {
+    const long long blk = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave per range: (b, h, l) * nqb + qb
+    if (blk >= n_ranges) return;
+    const int lane = threadIdx.x & 63;
     const long long bhl = blk / nqb;
     const int qb = (int)(blk - bhl * nqb);
     const int q0 = qb * kRangeQueries, q1 = min(nq, q0 + kRangeQueries);
     const int16_t *k = keys + (bhl * nq + q0) * P;
     const int n = (q1 - q0) * P;
     int mn = 32767, mx = -32768;
-    for (int e = threadIdx.x; e < n; e += 64) {
+    for (int e = lane; e < n; e += 64) {
         const int v = k[e];
         if (v != kKeyOutside) { mn = min(mn, v); mx = max(mx, v); }
     }
@@ -998,7 +1000,7 @@ __global__ __launch_bounds__(64) void msda_key_range_kernel(const int16_t *__res
         mn = min(mn, __shfl_xor(mn, m, 64));
         mx = max(mx, __shfl_xor(mx, m, 64));
     }
-    if (threadIdx.x == 0) ranges[blk] = (int)(((unsigned)mn << 16) | ((unsigned)mx & 0xffffu));
+    if (lane == 0) ranges[blk] = (int)(((unsigned)mn << 16) | ((unsigned)mx & 0xffffu));
 }
 
 struct MsdaBandPlan {
@@ -1486,8 +1488,8 @@ int so_band_scatter(const int32_t *shapes, const int32_t *starts, const float *g
     SO_REQUIRE(rblocks < (1LL << 31), "msda banded: grid too large");
     const unsigned bblocks = (unsigned)((long long)dm.bs * dm.heads * bsu.plan.items);
     const size_t shm = (size_t)bsu.max_tile_px * d * sizeof(double);
-    hipLaunchKernelGGL(msda_key_range_kernel, dim3((unsigned)rblocks), dim3(64), 0, st, w.keys, w.ranges, dm.nq, dm.P,
-                       w.nqb);
+    hipLaunchKernelGGL(msda_key_range_kernel, dim3((unsigned)((rblocks + 3) / 4)), dim3(256), 0, st, w.keys, w.ranges,
+                       dm.nq, dm.P, w.nqb, rblocks);
 #define SO_LAUNCH_T(DD, TT)                                                                                  \
     {                                                                                                        \
         static bool attr_set = false;                                                                        \
