@@ -83,14 +83,18 @@ class _TallLinear(torch.autograd.Function):
         db = dy.new_zeros(dy.shape[1])
         if R > 0:
             dyb = dy[:Tp].view(G, R, dy.shape[1])
-            dw = torch.bmm(dyb.transpose(1, 2), x[:Tp].view(G, R, x.shape[1])).sum(0)
+            dw = torch.bmm(dyb.transpose(1, 2), x[:Tp].view(G, R, x.shape[1]))
+            dw = dw[0] if G == 1 else dw.sum(0)
             # bias gradient in two stages as well: torch's column reduction of a (1.65 M, N) matrix has only
             # N outputs to parallelise over (~200 GB/s, 3.1 ms per call in profiles/r1_h_train_iteration.txt;
             # rocBLAS gemv against a ones vector is worse: 16 ms); (G, R, N).sum(1) has G * N
-            db = dyb.sum(1).sum(0)
+            db = dyb.sum(1).sum(0) if T > 300000 else None
+        if db is None:
+            db = dy.sum(0)               # moderate row counts: one column reduction is fine
+        elif Tp < T:
+            db = db + dy[Tp:].sum(0)
         if Tp < T:
             dw = dw + dy[Tp:].t() @ x[Tp:]
-            db = db + dy[Tp:].sum(0)
         return dy @ weight, dw, (db if ctx.has_bias else None)
 
 
