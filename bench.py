@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--exact", action="store_true", help="canonical IEEE path (bit-exact with the oracle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--no-hotpath", action="store_true",
+                    help="skip the whole-path stage timings (scripts/bench_hotpath_*.py) reported under \"hot_path\"")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -202,6 +204,25 @@ def main():
                         "sample": f"first {done} rays of the same cfg2 frame (chunks of 90000), C={args.channels}, "
                                   f"torch CPU F.grid_sample + NeuS compositing, {spent:.1f} s"}
 
+    hot_path = None
+    if rank == 0 and world == 1 and not args.no_hotpath and not args.no_extras:
+        # the rest of the hot path at the reference's shipped shapes (no image backbone), outside the timed
+        # region and in their own processes: lifter + encoder + field volume + render of one nuscenes_depth
+        # evaluation frame, and one nuscenes_occ training iteration (forward, five losses, backward)
+        import subprocess
+        torch.cuda.empty_cache()
+        hot_path = {}
+        here = os.path.dirname(os.path.abspath(__file__))
+        for key, script in (("eval_frame_nuscenes_depth_ms", "bench_hotpath_eval.py"),
+                            ("train_iteration_nuscenes_occ_ms", "bench_hotpath_train.py")):
+            try:
+                r = subprocess.run([sys.executable, os.path.join(here, "scripts", script)], capture_output=True,
+                                   text=True, timeout=240)
+                last = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+                hot_path[key] = json.loads(last[-1]) if last else {"error": (r.stderr or "no output")[-300:]}
+            except Exception as e:   # never let the side measurement break the bench line
+                hot_path[key] = {"error": repr(e)[:300]}
+
     if rank == 0:
         line = {
             "metric": "rendered rays/sec (6-cam 450x800, 128 samples/ray)",
@@ -216,6 +237,8 @@ def main():
         }
         if extras:
             line["extras"] = extras
+        if hot_path:
+            line["hot_path"] = hot_path
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
