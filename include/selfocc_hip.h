@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SELFOCC_ABI_VERSION 11
+#define SELFOCC_ABI_VERSION 12
 
 int selfocc_abi_version(void);
 const char *selfocc_last_error(void);
@@ -280,6 +280,16 @@ int selfocc_field_volume_fwd(const float *hw, const float *zh, const float *wz, 
                              int32_t D, int32_t C, const float *w_hidden, const float *b_hidden,
                              int32_t n_hidden, const float *w_out, const float *b_out, int32_t out_dim,
                              float *sdf, void *feat, int32_t feat_dtype, int32_t feat_stride, void *stream);
+
+/* Backward of selfocc_field_volume_fwd (C = 96, one hidden layer, float32 feature volume): g_sdf (H*W*D) and
+ * g_feat (H*W*D, feat_stride) -> gradients of the three planes and of the two linear layers (all seven
+ * outputs zero-initialised by the caller, accumulated).  Nothing of the forward is needed: the kernel
+ * recomputes the activations per 32-voxel tile.  g_sdf / g_feat may be NULL (treated as zero). */
+int selfocc_field_volume_bwd(const float *hw, const float *zh, const float *wz, int32_t H, int32_t W,
+                             int32_t D, int32_t C, const float *w_hidden, const float *b_hidden,
+                             const float *w_out, int32_t out_dim, const float *g_sdf, const float *g_feat,
+                             int32_t feat_stride, float *g_hw, float *g_zh, float *g_wz, float *g_w_hidden,
+                             float *g_b_hidden, float *g_w_out, float *g_b_out, void *stream);
 
 /* Occ3D evaluation tail, eval_iou.py:211-250: trilinear resample (F.grid_sample,
  * align_corners=True, zero padding — bit-exact with torch's CPU kernel) of the dense SDF

@@ -6,7 +6,7 @@ its exported symbols being callable with these layouts.
 """
 import ctypes as C
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 # enums ---------------------------------------------------------------------------
 RAYS_EXPLICIT, RAYS_PIXEL_GRID = 0, 1
@@ -112,6 +112,7 @@ SYMBOLS = {
     "selfocc_msda_bwd_banded_workspace": (C.c_size_t, [_i] * 5),
     "selfocc_msda_bwd_banded": (C.c_int, [_p] * 10 + [_i] * 7 + [_p, C.c_size_t, _p]),
     "selfocc_field_query": (C.c_int, [C.POINTER(SoQueryArgs), _p]),
+    "selfocc_field_volume_bwd": (C.c_int, [_p] * 3 + [_i] * 4 + [_p, _p, _p, _i, _p, _p, _i] + [_p] * 7 + [_p]),
     "selfocc_field_volume_fwd": (C.c_int, [_p] * 3 + [_i] * 4 + [_p, _p, _i, _p, _p, _i, _p, _p, _i, _i, _p]),
     "selfocc_occ_resample": (C.c_int, [C.POINTER(SoOccArgs), _p]),
     "selfocc_iou_counts": (C.c_int, [_p, _p, _p, C.c_int64, _p, _i, _i, _p, _p]),

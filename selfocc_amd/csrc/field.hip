@@ -161,6 +161,299 @@ __global__ __launch_bounds__(field_waves(C) * 64) void field_volume_kernel(Field
     }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// backward of the fused volume MLP (training), C = 96, one hidden layer.  Nothing of the forward is kept:
+// per 32-voxel tile the wave recomputes a = Softplus(x) and y = W1 a + b1, then runs the four gradient GEMMs on
+// the same MFMA operand scheme (528 MFMAs per tile, all operands from registers / LDS):
+//     dZ = dOut W2                (K = 32 outputs)          dY = dZ * sigmoid(y)
+//     dW2 += z^T dOut             (K = the tile's 32 rows)  dW1 += a^T dY
+//     dA = dY W1                                            dX = dA * sigmoid(x)
+// and scatters dX to the three plane gradients: g_zh / g_wz one 128-byte row segment per voxel, g_hw summed
+// over the tile's rows that share (h, w) first (registers + one shuffle).  The weight / bias gradients stay
+// in accumulators for all tiles of the wave and are added to global memory once at the end.
+// One wave per SIMD (the 192 accumulator registers of dW1 / dW2 need the full register file); LDS = the
+// hidden weight in B-operand order (row stride 97: conflict-free as B[k][n] for the forward AND as B[n][k]
+// for dA), W2 in [o][n] order, and two 32 x 100 transpose tiles per wave.
+// ---------------------------------------------------------------------------------------
+struct FieldBwdArgs {
+    const float *hw, *zh, *wz;
+    int H, W, D;
+    const float *w1, *b1, *w2;      // (96, 96), (96), (out_dim, 96)
+    int out_dim;
+    const float *g_sdf;             // (M) or NULL
+    const float *g_feat;            // (M, feat_stride) or NULL
+    int feat_stride;
+    float *g_hw, *g_zh, *g_wz;      // zero-initialised, accumulated
+    float *g_w1, *g_b1, *g_w2, *g_b2;
+    long long M;
+    int n_tiles;
+};
+
+constexpr int kFB_C = 96, kFB_KS = 48, kFB_LD = 97, kFB_TS = 100, kFB_WAVES = 4;
+
+SO_DEVFN int so_crow(int v, int half) { return (v & 3) + 8 * (v >> 2) + 4 * half; }   // C-layout row of register v
+
+__global__ __launch_bounds__(kFB_WAVES * 64) void field_volume_bwd_kernel(FieldBwdArgs a) {
+    constexpr int C = kFB_C, KS = kFB_KS, LD = kFB_LD, TS = kFB_TS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *w1s = smem;                          // [kk = ks * 2 + half][n], k = half * 48 + ks     96 x 97
+    float *w2k = w1s + C * LD;                  // [oo = os * 2 + ohalf][n], o = ohalf * 16 + os    32 x 97
+    float *tiles = w2k + 32 * LD;               // per wave: T1 (a), T2 (z, then dY)               2 x 32 x 100
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, half = lane >> 5;
+    for (int e = threadIdx.x; e < C * C; e += kFB_WAVES * 64) {
+        const int k = e % C, n = e / C;                       // coalesced read of w1 (n, k)
+        w1s[((k % KS) * 2 + k / KS) * LD + n] = a.w1[e];
+    }
+    for (int e = threadIdx.x; e < 32 * C; e += kFB_WAVES * 64) {
+        const int n = e % C, o = e / C;
+        w2k[((o % 16) * 2 + o / 16) * LD + n] = o < a.out_dim ? a.w2[(size_t)o * C + n] : 0.0f;
+    }
+    __syncthreads();
+    float *T1 = tiles + (size_t)wave * 2 * 32 * TS, *T2 = T1 + 32 * TS;
+
+    f32x16 dW1[3][3], dW2[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) dW2[r][v] = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) dW1[r][c][v] = 0.0f;
+    }
+    float db1[3] = {0.0f, 0.0f, 0.0f};
+    float db2[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) db2[k] = 0.0f;
+    float bias1[3];
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) bias1[ct] = a.b1[ct * 32 + i];
+
+    for (int tile = blockIdx.x * kFB_WAVES + wave; tile < a.n_tiles; tile += gridDim.x * kFB_WAVES) {
+        const long long m0 = (long long)tile * 32;
+        // ---- S1: a = Softplus(x), A layout (row i, columns half * 48 ..) -> registers and T1 ---------------
+        const long long m = m0 + i;
+        const bool mlive = m < a.M;
+        const long long mc = mlive ? m : a.M - 1;
+        const int d = (int)(mc % a.D);
+        const int hwi = (int)(mc / a.D);
+        const int w = hwi % a.W, h = hwi / a.W;
+        float av[KS];
+        {
+            const float4 *p0 = (const float4 *)(a.hw + (size_t)hwi * C + half * KS);
+            const float4 *p1 = (const float4 *)(a.zh + ((size_t)d * a.H + h) * C + half * KS);
+            const float4 *p2 = (const float4 *)(a.wz + ((size_t)w * a.D + d) * C + half * KS);
+            float4 *t1 = (float4 *)(T1 + i * TS + half * KS);
+#pragma unroll
+            for (int q = 0; q < KS / 4; ++q) {
+                const float4 x0 = p0[q], x1 = p1[q], x2 = p2[q];
+                float4 s4;
+                s4.x = so_softplus((x0.x + x1.x) + x2.x);
+                s4.y = so_softplus((x0.y + x1.y) + x2.y);
+                s4.z = so_softplus((x0.z + x1.z) + x2.z);
+                s4.w = so_softplus((x0.w + x1.w) + x2.w);
+                av[4 * q + 0] = s4.x; av[4 * q + 1] = s4.y; av[4 * q + 2] = s4.z; av[4 * q + 3] = s4.w;
+                t1[q] = s4;
+                // the 192 weight-gradient accumulators leave ~300 registers: keep at most 4 x 3 loads in flight
+                if ((q & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- S2: y = W1 a + b1 (C layout); z = Softplus(y) -> T2 --------------------------------------------
+        f32x16 acc[3];
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[ct][v] = 0.0f;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const float *brow = w1s + (ks * 2 + half) * LD + i;
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct)
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks], brow[ct * 32], acc[ct], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) T2[so_crow(v, half) * TS + ct * 32 + i] = so_softplus(acc[ct][v] + bias1[ct]);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- S3: dOut, A layout: lane (row i, half) holds outputs half * 16 .. + 16 ------------------------
+        float dav[16];
+#pragma unroll
+        for (int os = 0; os < 16; ++os) {
+            const int o = half * 16 + os;
+            float g = 0.0f;
+            if (mlive && o < a.out_dim) {
+                if (o == 0) g = a.g_sdf ? a.g_sdf[m] : 0.0f;
+                else g = a.g_feat ? a.g_feat[(size_t)m * a.feat_stride + (o - 1)] : 0.0f;
+            }
+            dav[os] = g;
+            db2[os] += g;
+        }
+        // ---- S4 / S5: dZ = dOut W2 ; dY = dZ sigmoid(y) ----------------------------------------------------
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[ct][v] = 0.0f;
+#pragma unroll
+        for (int os = 0; os < 16; ++os) {
+            const float *brow = w2k + (os * 2 + half) * LD + i;
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct)
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(dav[os], brow[ct * 32], acc[ct], 0, 0, 0);
+        }
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) {
+            float sum = 0.0f;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const float z = T2[so_crow(v, half) * TS + ct * 32 + i];   // this lane's own element (written in S2)
+                acc[ct][v] = acc[ct][v] * (1.0f - __expf(-z));           // sigmoid(y) = 1 - exp(-softplus(y))
+                sum += acc[ct][v];
+            }
+            db1[ct] += sum;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- S6: dW2 += z^T dOut : rows n (3 tiles), columns o, K = the 32 rows of the tile ----------------
+#pragma unroll
+        for (int ms = 0; ms < 16; ++ms) {
+            const long long mr = m0 + 2 * ms + half;               // B' operand: dOut[mr][o = i]
+            float g = 0.0f;
+            if (mr < a.M && i < a.out_dim) {
+                if (i == 0) g = a.g_sdf ? a.g_sdf[mr] : 0.0f;
+                else g = a.g_feat ? a.g_feat[(size_t)mr * a.feat_stride + (i - 1)] : 0.0f;
+            }
+            const float *zrow = T2 + (2 * ms + half) * TS + i;     // A' operand: z[mr][n = rt * 32 + i]
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt)
+                dW2[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(zrow[rt * 32], g, dW2[rt], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- S7: dY -> T2 ----------------------------------------------------------------------------------
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) T2[so_crow(v, half) * TS + ct * 32 + i] = acc[ct][v];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- S8: dW1 += a^T dY : rows k (3 tiles), columns n (3 tiles) -------------------------------------
+#pragma unroll
+        for (int ms = 0; ms < 16; ++ms) {
+            const float *arow = T1 + (2 * ms + half) * TS + i;
+            const float *yrow = T2 + (2 * ms + half) * TS + i;
+            float bv[3];
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) bv[ct] = yrow[ct * 32];
+#pragma unroll
+            for (int rt = 0; rt < 3; ++rt) {
+                const float avv = arow[rt * 32];
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct)
+                    dW1[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(avv, bv[ct], dW1[rt][ct], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- S9: dA = dY W1 : A = dY in A layout (from T2), B[n][k] = W1[n][k] (w1s read the other way) ----
+        {
+            const float4 *yr = (const float4 *)(T2 + i * TS + half * KS);
+#pragma unroll
+            for (int q = 0; q < KS / 4; ++q) {
+                const float4 t = yr[q];
+                av[4 * q + 0] = t.x; av[4 * q + 1] = t.y; av[4 * q + 2] = t.z; av[4 * q + 3] = t.w;
+            }
+        }
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[ct][v] = 0.0f;
+        {
+            int krow[3];                                           // w1s row of column k = ct * 32 + i
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) {
+                const int k = ct * 32 + i;
+                krow[ct] = ((k % KS) * 2 + k / KS) * LD;
+            }
+#pragma unroll
+            for (int ns = 0; ns < KS; ++ns) {
+                const int n = half * KS + ns;
+#pragma unroll
+                for (int ct = 0; ct < 3; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ns], w1s[krow[ct] + n], acc[ct], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- S10 / S11: dX = dA sigmoid(x) (C layout) -> plane gradients -----------------------------------
+        const int hwi0 = (int)(m0 / a.D);
+        const int d0 = (int)(m0 - (long long)hwi0 * a.D);
+        const int w0 = hwi0 % a.W, h0 = hwi0 / a.W;
+        // host guarantees D >= 11 and W >= 4: d0 + r < 4 D (no divisions), at most one wrap of w per tile
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) {
+            const int k = ct * 32 + i;
+            float seg[3] = {0.0f, 0.0f, 0.0f};                      // sums over the rows of (h, w) column hwi0 + 0 / 1 / 2
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int r = so_crow(v, half);
+                if (m0 + r >= a.M) continue;
+                const float ar = T1[r * TS + k];
+                const float dx = acc[ct][v] * (1.0f - __expf(-ar));
+                const int t = d0 + r;
+                const int sgi = (t >= a.D) + (t >= 2 * a.D) + (t >= 3 * a.D);
+                const int dr = t - sgi * a.D;
+                int wr = w0 + sgi, hr = h0;
+                if (wr >= a.W) { wr -= a.W; hr += 1; }
+                unsafeAtomicAdd(a.g_zh + ((size_t)dr * a.H + hr) * C + k, dx);
+                unsafeAtomicAdd(a.g_wz + ((size_t)wr * a.D + dr) * C + k, dx);
+                if (sgi < 3) {
+                    seg[0] += sgi == 0 ? dx : 0.0f;
+                    seg[1] += sgi == 1 ? dx : 0.0f;
+                    seg[2] += sgi == 2 ? dx : 0.0f;
+                } else {
+                    unsafeAtomicAdd(a.g_hw + (size_t)(hwi0 + sgi) * C + k, dx);   // 4th+ column of the tile
+                }
+            }
+#pragma unroll
+            for (int sg = 0; sg < 3; ++sg) {
+                const float tot = seg[sg] + __shfl_xor(seg[sg], 32, 64);
+                if (half == 0 && tot != 0.0f && (long long)(hwi0 + sg) * a.D < a.M)
+                    unsafeAtomicAdd(a.g_hw + (size_t)(hwi0 + sg) * C + k, tot);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // ---- the wave's weight / bias gradients -> global (once) -------------------------------------------------
+#pragma unroll
+    for (int rt = 0; rt < 3; ++rt) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int rr = rt * 32 + so_crow(v, half);
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct)            // dW1[k = rr][n = ct * 32 + i] -> g_w1 (n, k)
+                unsafeAtomicAdd(a.g_w1 + (size_t)(ct * 32 + i) * C + rr, dW1[rt][ct][v]);
+            if (i < a.out_dim) unsafeAtomicAdd(a.g_w2 + (size_t)i * C + rr, dW2[rt][v]);   // dW2[n = rr][o = i]
+        }
+    }
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) {
+        const float tot = db1[ct] + __shfl_xor(db1[ct], 32, 64);
+        if (half == 0) unsafeAtomicAdd(a.g_b1 + ct * 32 + i, tot);
+    }
+#pragma unroll
+    for (int os = 0; os < 16; ++os) {
+        float t = db2[os];
+#pragma unroll
+        for (int msk = 1; msk < 32; msk <<= 1) t += __shfl_xor(t, msk, 64);
+        const int o = half * 16 + os;
+        if (i == 0 && o < a.out_dim) unsafeAtomicAdd(a.g_b2 + o, t);
+    }
+}
+
 }  // namespace
 
 extern "C" int selfocc_field_volume_fwd(const float *hw, const float *zh, const float *wz, int32_t H, int32_t W,
@@ -202,5 +495,36 @@ extern "C" int selfocc_field_volume_fwd(const float *hw, const float *zh, const 
     else if (C == 96) { if (bf) SO_LAUNCH(96, true) else SO_LAUNCH(96, false) }
     else { if (bf) SO_LAUNCH(128, true) else SO_LAUNCH(128, false) }
 #undef SO_LAUNCH
+    return so_launch_status();
+}
+
+
+extern "C" int selfocc_field_volume_bwd(const float *hw, const float *zh, const float *wz, int32_t H, int32_t W,
+                                        int32_t D, int32_t C, const float *w_hidden, const float *b_hidden,
+                                        const float *w_out, int32_t out_dim, const float *g_sdf, const float *g_feat,
+                                        int32_t feat_stride, float *g_hw, float *g_zh, float *g_wz, float *g_w_hidden,
+                                        float *g_b_hidden, float *g_w_out, float *g_b_out, void *stream) {
+    SO_REQUIRE(H >= 1 && W >= 1 && D >= 1, "field_volume_bwd: bad volume size (%d, %d, %d)", H, W, D);
+    SO_REQUIRE(C == 96, "field_volume_bwd: embed_dims must be 96 (got %d); use the autograd path", C);
+    SO_REQUIRE(D >= 11 && W >= 4, "field_volume_bwd: needs D >= 11 and W >= 4 (got D = %d, W = %d); use the autograd path", D, W);
+    SO_REQUIRE(out_dim >= 1 && out_dim <= 32, "field_volume_bwd: 1 + color_dims must be <= 32 (got %d)", out_dim);
+    SO_REQUIRE(hw && zh && wz && w_hidden && b_hidden && w_out, "field_volume_bwd: NULL input pointer");
+    SO_REQUIRE(g_hw && g_zh && g_wz && g_w_hidden && g_b_hidden && g_w_out && g_b_out,
+               "field_volume_bwd: NULL gradient pointer");
+    SO_REQUIRE(g_feat == nullptr || feat_stride >= out_dim - 1, "field_volume_bwd: feat_stride %d < %d colour channels",
+               feat_stride, out_dim - 1);
+    const long long M = (long long)H * W * D;
+    SO_REQUIRE(M < (1LL << 31) * 32, "field_volume_bwd: volume too large");
+    FieldBwdArgs a{hw, zh, wz, H, W, D, w_hidden, b_hidden, w_out, out_dim, g_sdf, g_feat, feat_stride,
+                   g_hw, g_zh, g_wz, g_w_hidden, g_b_hidden, g_w_out, g_b_out, M, (int)((M + 31) / 32)};
+    const size_t shm = ((size_t)kFB_C * kFB_LD + 32 * kFB_LD + (size_t)kFB_WAVES * 2 * 32 * kFB_TS) * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void *)field_volume_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024 - 256);
+        attr_set = true;
+    }
+    const int blocks = std::min((a.n_tiles + kFB_WAVES - 1) / kFB_WAVES, 256);
+    hipLaunchKernelGGL(field_volume_bwd_kernel, dim3(blocks), dim3(kFB_WAVES * 64), shm, (hipStream_t)stream, a);
     return so_launch_status();
 }

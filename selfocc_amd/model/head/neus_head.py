@@ -25,7 +25,7 @@ import torch.nn as nn
 from ... import abi
 from ...mapping import GridMeterMapping
 from ...occ import field_query, uniform_lattice
-from ...field import field_volume, field_volume_supported
+from ...field import field_volume, field_volume_supported, field_volume_train_supported, FieldVolumeFunction
 from ...registry import HEADS
 from ...render import SDFVolume, RaySet, RenderConfig, render_rays, render_rays_autograd
 from ..bricks import BaseModule, _TallLinear
@@ -181,6 +181,13 @@ class SDFField(BaseModule):
                     # inference: plane sum + MLP + layout in one MFMA kernel, no (H*W*D, C) intermediate
                     sdf, feat_vol = field_volume(hw, zh, wz, (H, W, D), linears, F, self.feat_dtype)
                     self.volume = SDFVolume(self.mapping, sdf, feat_vol, self.n_rgb, self.n_sem)
+                    return self.volume
+                if (self.fused_volume and torch.is_grad_enabled() and hw.is_cuda
+                        and field_volume_train_supported(C, len(linears), 1 + self.color_dims, F, self.feat_dtype, (H, W, D))):
+                    # training: the same fusion under autograd (fused backward recomputes the activations)
+                    sdf, feat_vol = FieldVolumeFunction.apply(hw, zh, wz, linears[0].weight, linears[0].bias,
+                                                              linears[1].weight, linears[1].bias, (H, W, D), F)
+                    self.volume = SDFVolume(self.mapping, sdf, feat_vol if F > 0 else None, self.n_rgb, self.n_sem)
                     return self.volume
                 feat = hw.reshape(H, W, 1, C) + zh.reshape(D, H, 1, C).permute(1, 2, 0, 3) + \
                     wz.reshape(W, D, 1, C).permute(2, 0, 1, 3)                       # H, W, D, C
