@@ -8,18 +8,19 @@
 //   out[b,q,h*D+c] = sum_{l,p} A[b,q,h,l,p] * bilinear(V_l[b, :, h, c], loc[b,q,h,l,p])
 //   h_im = loc_y * H_l - 0.5, w_im = loc_x * W_l - 0.5, zero padding outside the map.
 //
-// Hardware mapping (not mmcv's thread-per-output-channel): ONE LANE PER SAMPLING POINT.
-//   * the L*P points of one (b, q, head) are consecutive in memory, so the loc / attw
-//     streams (the compulsory HBM traffic, ~80 % of the bytes) are read fully coalesced,
-//     once, with no 16x redundant coordinate math across the channel lanes;
-//   * a lane fetches its 4 corners as D/4 x float4 (one 64-B segment per corner at
-//     D = 16) and keeps D partial sums in registers;
-//   * the G = 2^k lanes of a (b, q, head) group combine with a reduce-scatter over
-//     wavefront shuffles (D/2 + D/4 + ... exchanges instead of D * log2 G), after which
-//     D lanes hold one output channel each and store one coalesced segment;
-//   * backward needs no cross-lane reduction at all: grad_loc / grad_attw are per
-//     point (lane-local, coalesced stores) and grad_value is scattered with hardware
-//     float atomics (global_atomic_add_f32).
+// Hardware mapping (not mmcv's thread-per-output-channel): A LANE OWNS A SAMPLING POINT, A TEAM GATHERS IT.
+//   * the L*P points of one (b, q, head) are consecutive in memory, so the loc / attw (or raw offset /
+//     logit) streams — ~80 % of the compulsory bytes — are read fully coalesced, once, and the bilinear
+//     set-up is done once per point, not once per channel lane;
+//   * d/4 adjacent lanes (a channel team) walk through their d/4 points together, each lane fetching its own
+//     16-byte quarter of every corner: a wave-level load touches 16 corner segments instead of 64 (the L1 tag
+//     rate, not bytes, bounds the gather); the point record travels through the team with DPP quad permutes;
+//   * the teams of a group combine with a static reduce-scatter over wavefront shuffles;
+//   * fused forms do the reference's prologue (softmax, loc = ref + off / (W, H)) in registers, in inference
+//     and training; the camera-loop forms replace BEVCrossAttention's re-batch / scatter-add / mean;
+//   * backward: a point kernel (grad_loc / grad_attw or the raw-output gradients; keys + records in band
+//     order) and a banded, output-stationary scatter of grad_value through ds_add_f64 in LDS — no global atomics
+//     in the scatter (selfocc_msda_bwd keeps the global-atomic form for callers without host shapes / workspace).
 #include "so_device.h"
 #include <algorithm>
 #include <type_traits>
