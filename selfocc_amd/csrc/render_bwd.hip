@@ -120,7 +120,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba) 
         }
     };
     // per-wave transpose buffer of the feature-gradient scatter (phase B); odd record stride
-    __shared__ __attribute__((aligned(16))) float lds_rec[NF > 0 ? 4 * 64 * (NF + 9 + (((NF + 9) & 1) ? 0 : 1)) : 4];
+    __shared__ __attribute__((aligned(16))) float lds_rec[4 * 64 * (NF > 0 ? (NF + 9 + (((NF + 9) & 1) ? 0 : 1)) : 9)];
     if (ray >= a.n_rays) return;  // wave-uniform (block-uniform when the waves share a ray)
     const int H = a.map.h.tot_len, W = a.map.w.tot_len, D = a.map.d.tot_len;
     const int S = a.n_samples;
@@ -416,42 +416,76 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba) 
     }
 
     float dinv_s_l = 0.0f;
+    // SDF-volume records: {cell, 8 corner coefficients} per lane, in this wave's own slab of lds_rec (the same
+    // slab as its feature records: with one wave per ray the waves of a block are not in step)
+    float *srec = lds_rec + wave * (64 * (NF > 0 ? (NF + 9 + (((NF + 9) & 1) ? 0 : 1)) : 9));
 #pragma unroll
     for (int j = M - 1; j >= 0; --j) {
         float dalpha = T[j] * (Gw[j] - Ev[j]);
-        if (!live[j]) continue;
-        if (!unclipped[j]) dalpha = 0.0f;
-        const float pe = Pc[j] + 1e-5f;
-        const float dP = dalpha * (Nc[j] / (pe * pe));
-        const float dN = -dalpha / pe;
-        const float da = dP * Pc[j] * (1.0f - Pc[j]);
-        const float db = dN * Nc[j] * (1.0f - Nc[j]);
-        const size_t so = (size_t)ray * S + ((j * WPR + wstep) * 64 + lane);
-        float ds = (da + db) * a.inv_s;
-        const float dh = (db - da) * a.inv_s;
-        dinv_s_l += da * (sdfv[j] - halfv[j]) + db * (sdfv[j] + halfv[j]);
-        const float dc = cneg[j] ? dh * (delta[j] * 0.5f) : 0.0f;
-        float dgx = dc * g.dx, dgy = dc * g.dy, dgz = dc * g.dz;
-        if (ba.g_sdf) ds += ba.g_sdf[so];
-        if (ba.g_grad) { dgx += ba.g_grad[3 * so]; dgy += ba.g_grad[3 * so + 1]; dgz += ba.g_grad[3 * so + 2]; }
-        if (ba.g_sdf_vol) {
-            // sdf = sum_k W_k v_k ; grad_axis = slope_axis * sum_k dW_k/d axis * v_k
-            const so_cell &c = cell[j];
-            const float fd[2] = {c.fd0, c.fd1}, fw[2] = {c.fw0, c.fw1}, fh[2] = {c.fh0, c.fh1};
-            const float qx = dgx * c.sw, qy = dgy * c.sh, qz = dgz * c.sd;  // metre x<->w, y<->h, z<->d
+        float coefs[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        if (live[j]) {
+            if (!unclipped[j]) dalpha = 0.0f;
+            const float pe = Pc[j] + 1e-5f;
+            const float dP = dalpha * (Nc[j] / (pe * pe));
+            const float dN = -dalpha / pe;
+            const float da = dP * Pc[j] * (1.0f - Pc[j]);
+            const float db = dN * Nc[j] * (1.0f - Nc[j]);
+            const size_t so = (size_t)ray * S + ((j * WPR + wstep) * 64 + lane);
+            float ds = (da + db) * a.inv_s;
+            const float dh = (db - da) * a.inv_s;
+            dinv_s_l += da * (sdfv[j] - halfv[j]) + db * (sdfv[j] + halfv[j]);
+            const float dc = cneg[j] ? dh * (delta[j] * 0.5f) : 0.0f;
+            float dgx = dc * g.dx, dgy = dc * g.dy, dgz = dc * g.dz;
+            if (ba.g_sdf) ds += ba.g_sdf[so];
+            if (ba.g_grad) { dgx += ba.g_grad[3 * so]; dgy += ba.g_grad[3 * so + 1]; dgz += ba.g_grad[3 * so + 2]; }
+            if (ba.g_sdf_vol) {
+                // sdf = sum_k W_k v_k ; grad_axis = slope_axis * sum_k dW_k/d axis * v_k
+                const so_cell &c = cell[j];
+                const float fd[2] = {c.fd0, c.fd1}, fw[2] = {c.fw0, c.fw1}, fh[2] = {c.fh0, c.fh1};
+                const float qx = dgx * c.sw, qy = dgy * c.sh, qz = dgz * c.sd;  // metre x<->w, y<->h, z<->d
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                const int kd = kk & 1, kw = (kk >> 1) & 1, kh = kk >> 2;
-                const int h = c.h0 + kh, ww = c.w0 + kw, d = c.d0 + kd;
-                const bool in = (h >= 0) && (h < H) && (ww >= 0) && (ww < W) && (d >= 0) && (d < D);
-                if (!in) continue;
-                const float Wk = (fd[kd] * fw[kw]) * fh[kh];
-                const float dWd = (kd ? 1.0f : -1.0f) * (fw[kw] * fh[kh]);
-                const float dWw = (kw ? 1.0f : -1.0f) * (fd[kd] * fh[kh]);
-                const float dWh = (kh ? 1.0f : -1.0f) * (fd[kd] * fw[kw]);
-                const float coef = fmaf(Wk, ds, fmaf(dWd, qz, fmaf(dWw, qx, dWh * qy)));
-                unsafeAtomicAdd(ba.g_sdf_vol + ((size_t)h * W + ww) * D + d, coef);
+                for (int kk = 0; kk < 8; ++kk) {
+                    const int kd = kk & 1, kw = (kk >> 1) & 1, kh = kk >> 2;
+                    const int h = c.h0 + kh, ww = c.w0 + kw, d = c.d0 + kd;
+                    const bool in = (h >= 0) && (h < H) && (ww >= 0) && (ww < W) && (d >= 0) && (d < D);
+                    const float Wk = (fd[kd] * fw[kw]) * fh[kh];
+                    const float dWd = (kd ? 1.0f : -1.0f) * (fw[kw] * fh[kh]);
+                    const float dWw = (kw ? 1.0f : -1.0f) * (fd[kd] * fh[kh]);
+                    const float dWh = (kh ? 1.0f : -1.0f) * (fd[kd] * fw[kw]);
+                    coefs[kk] = in ? fmaf(Wk, ds, fmaf(dWd, qz, fmaf(dWw, qx, dWh * qy))) : 0.0f;
+                }
             }
+        }
+        if (ba.g_sdf_vol) {   // wave-uniform
+            // Scalar per-lane atomics would be one 64-byte fabric write each (8 per sample: as much traffic as
+            // the whole feature scatter).  Instead 8-lane rows (one corner per lane) walk the samples in ray
+            // order and add the coefficients of a run of samples inside one voxel before one atomic per corner.
+            float *mine = srec + lane * 9;
+            mine[0] = __int_as_float((cell[j].h0 * W + cell[j].w0) * D + cell[j].d0);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) mine[1 + kk] = coefs[kk];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const int sub = lane & 7, grp = lane >> 3;
+            const int voff = ((sub >> 2) * W + ((sub >> 1) & 1)) * D + (sub & 1);
+            for (int t = 0; t < 8; ++t) {
+                const float *r = srec + (grp * 8 + t) * 9;
+                const int base = __float_as_int(r[0]);
+                if (t > 0 && __float_as_int(r[-9]) == base) continue;   // inside a run: already added
+                float val = 0.0f;
+                int tt = t;
+                const float *rr = r;
+                do {
+                    val += rr[1 + sub];
+                    ++tt;
+                    rr += 9;
+                } while (tt < 8 && __float_as_int(rr[0]) == base);
+                // a coefficient is non-zero only for a corner inside the volume, so base + voff is a valid voxel
+                if (val != 0.0f) unsafeAtomicAdd(ba.g_sdf_vol + (base + voff), val);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
     if (ba.g_inv_s) {
