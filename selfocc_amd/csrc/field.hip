@@ -318,19 +318,19 @@ __global__ __launch_bounds__(kFB_WAVES * 64) void field_volume_bwd_kernel(FieldB
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        // ---- S6: dW2 += z^T dOut : rows n (3 tiles), columns o, K = the 32 rows of the tile ----------------
+        // ---- S6: dW2 += dOut^T z : rows o, columns n (3 tiles), K = the 32 rows of the tile ----------------
 #pragma unroll
         for (int ms = 0; ms < 16; ++ms) {
-            const long long mr = m0 + 2 * ms + half;               // B' operand: dOut[mr][o = i]
+            const long long mr = m0 + 2 * ms + half;               // A' operand: dOut[mr][o = i]
             float g = 0.0f;
             if (mr < a.M && i < a.out_dim) {
                 if (i == 0) g = a.g_sdf ? a.g_sdf[mr] : 0.0f;
                 else g = a.g_feat ? a.g_feat[(size_t)mr * a.feat_stride + (i - 1)] : 0.0f;
             }
-            const float *zrow = T2 + (2 * ms + half) * TS + i;     // A' operand: z[mr][n = rt * 32 + i]
+            const float *zrow = T2 + (2 * ms + half) * TS + i;     // B' operand: z[mr][n = ct * 32 + i]
 #pragma unroll
-            for (int rt = 0; rt < 3; ++rt)
-                dW2[rt] = __builtin_amdgcn_mfma_f32_32x32x2f32(zrow[rt * 32], g, dW2[rt], 0, 0, 0);
+            for (int ct = 0; ct < 3; ++ct)                          // rows o, columns n: row-contiguous in g_w2 (o, n)
+                dW2[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(g, zrow[ct * 32], dW2[ct], 0, 0, 0);
         }
         __builtin_amdgcn_wave_barrier();
         // ---- S7: dY -> T2 ----------------------------------------------------------------------------------
@@ -341,7 +341,7 @@ __global__ __launch_bounds__(kFB_WAVES * 64) void field_volume_bwd_kernel(FieldB
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        // ---- S8: dW1 += a^T dY : rows k (3 tiles), columns n (3 tiles) -------------------------------------
+        // ---- S8: dW1 += dY^T a : rows n (3 tiles), columns k (3 tiles) -------------------------------------
 #pragma unroll
         for (int ms = 0; ms < 16; ++ms) {
             const float *arow = T1 + (2 * ms + half) * TS + i;
@@ -350,11 +350,11 @@ __global__ __launch_bounds__(kFB_WAVES * 64) void field_volume_bwd_kernel(FieldB
 #pragma unroll
             for (int ct = 0; ct < 3; ++ct) bv[ct] = yrow[ct * 32];
 #pragma unroll
-            for (int rt = 0; rt < 3; ++rt) {
-                const float avv = arow[rt * 32];
+            for (int ct = 0; ct < 3; ++ct) {                        // rows n (from dY), columns k (from a):
+                const float avv = arow[ct * 32];                    // row-contiguous in g_w1 (n, k)
 #pragma unroll
-                for (int ct = 0; ct < 3; ++ct)
-                    dW1[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(avv, bv[ct], dW1[rt][ct], 0, 0, 0);
+                for (int rt = 0; rt < 3; ++rt)
+                    dW1[rt][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[rt], avv, dW1[rt][ct], 0, 0, 0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -429,14 +429,14 @@ __global__ __launch_bounds__(kFB_WAVES * 64) void field_volume_bwd_kernel(FieldB
 
     // ---- the wave's weight / bias gradients -> global (once) -------------------------------------------------
 #pragma unroll
-    for (int rt = 0; rt < 3; ++rt) {
+    for (int v = 0; v < 16; ++v) {
+        const int cr = so_crow(v, half);
 #pragma unroll
-        for (int v = 0; v < 16; ++v) {
-            const int rr = rt * 32 + so_crow(v, half);
+        for (int ct = 0; ct < 3; ++ct) {
 #pragma unroll
-            for (int ct = 0; ct < 3; ++ct)            // dW1[k = rr][n = ct * 32 + i] -> g_w1 (n, k)
-                unsafeAtomicAdd(a.g_w1 + (size_t)(ct * 32 + i) * C + rr, dW1[rt][ct][v]);
-            if (i < a.out_dim) unsafeAtomicAdd(a.g_w2 + (size_t)i * C + rr, dW2[rt][v]);   // dW2[n = rr][o = i]
+            for (int rt = 0; rt < 3; ++rt)            // dW1[n = rt * 32 + cr][k = ct * 32 + i] -> g_w1 (n, k): 128-byte rows
+                unsafeAtomicAdd(a.g_w1 + (size_t)(rt * 32 + cr) * C + ct * 32 + i, dW1[rt][ct][v]);
+            if (cr < a.out_dim) unsafeAtomicAdd(a.g_w2 + (size_t)cr * C + ct * 32 + i, dW2[ct][v]);   // dW2[o = cr][n]
         }
     }
 #pragma unroll
