@@ -49,3 +49,26 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, fn)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M), os.path.join(dirpath, fn)
                 assert 'liboracle' not in txt and 'oracle_render_fwd' not in txt, os.path.join(dirpath, fn)
+
+
+def test_banded_support_query_is_pure_host_logic():
+    """selfocc_msda_banded_supported / _workspace run without a GPU: decomposition decisions only."""
+    from selfocc_amd._lib import lib
+    l = lib()
+
+    def sup(shapes, bs, nq, heads, d, P):
+        L = len(shapes)
+        arr = (C.c_int32 * (2 * L))(*[v for hw in shapes for v in hw])
+        return l.selfocc_msda_banded_supported(C.cast(arr, C.c_void_p), bs, nq, heads, d, L, P)
+
+    fpn = [(96, 200), (48, 100), (24, 50), (12, 25)]
+    assert sup(fpn, 6, 22016, 6, 16, 8) == 1                      # nuscenes_occ cross-attention
+    assert sup([(257, 257), (25, 257), (257, 25)], 1, 78899, 6, 16, 12) == 1   # cross-view self-attention
+    assert sup([(8, 5000)], 1, 1000, 2, 16, 4) == 0               # a level wider than the LDS tile (103 KB / 128 B = 824 px)
+    assert sup([(30000, 400)], 1, 10, 1, 16, 1) == 0              # 15 000 bands: scanning every band's keys costs more than atomics
+    assert sup(fpn * 3, 1, 100, 2, 16, 2) == 0                    # more than 8 levels
+    assert sup(fpn, 6, 22016, 6, 6, 8) < 0                        # bad channel count: argument error
+    assert b"channels per head" in l.selfocc_last_error()
+    n = 6 * 22016 * 6 * 4 * 8
+    ws = l.selfocc_msda_bwd_banded_workspace(6, 22016, 6, 4, 8)
+    assert ws >= 18 * n and ws % 16 == 0
