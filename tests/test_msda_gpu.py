@@ -239,3 +239,39 @@ def test_msda_cross_training_matches_per_camera_autograd(hip, P, L, D):
     assert torch.allclose(a[1], b[1], rtol=1e-4, atol=2e-4)
     assert torch.allclose(a[2], b[2], rtol=1e-3, atol=1e-4 * b[2].abs().max().item())
     assert torch.allclose(a[3], b[3], rtol=1e-3, atol=1e-4 * b[3].abs().max().item())
+
+
+def test_msda_backward_full_size_banded_vs_atomic(hip):
+    """nuscenes_occ hw-plane cross-attention at FULL size (6 cams x 22016 queries x 6 heads x 4 levels x 8 points =
+    25.4 M points, FPN maps 96x200 .. 12x25): the banded LDS-f64 backward and the global-atomic backward agree;
+    grad_attw / grad_loc (no atomics in either) to float rounding, grad_value to the float-atomic noise."""
+    import selfocc_amd.msda as M
+    d = torch.device("cuda:0")
+    g = torch.Generator(device=d).manual_seed(3)
+    bs, nq, H, D, P = 6, 22016, 6, 16, 8
+    shapes = torch.tensor([[96, 200], [48, 100], [24, 50], [12, 25]])
+    starts = torch.cat([torch.zeros(1, dtype=torch.int64), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    nv = int((shapes[:, 0] * shapes[:, 1]).sum()); L = 4
+    value = torch.randn(bs, nv, H, D, device=d, generator=g)
+    side = int(nq ** 0.5) + 1
+    qi = torch.arange(nq, device=d)
+    base = torch.stack([(qi % side) / side, (qi // side) / side], -1)
+    loc = base[None, :, None, None, None, :] + torch.randn(bs, nq, H, L, P, 2, device=d, generator=g) * 0.03
+    attw = torch.softmax(torch.randn(bs, nq, H, L * P, device=d, generator=g), -1).view(bs, nq, H, L, P)
+    gout = torch.randn(bs, nq, H * D, device=d, generator=g)
+    res = {}
+    for mode in ("banded", "atomic"):
+        M.BACKWARD_MODE = mode
+        try:
+            v, lc, aw = (t.clone().requires_grad_(True) for t in (value, loc, attw))
+            out = MultiScaleDeformableAttnFunction.apply(v, shapes.to(d), starts.to(d), lc, aw, 64)
+            out.backward(gout)
+            res[mode] = (v.grad, lc.grad, aw.grad)
+        finally:
+            M.BACKWARD_MODE = "banded"
+    (gv_b, gl_b, ga_b), (gv_a, gl_a, ga_a) = res["banded"], res["atomic"]
+    assert torch.allclose(ga_b, ga_a, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(gl_b, gl_a, rtol=1e-3, atol=1e-3)
+    scale = gv_a.abs().max().item()
+    assert (gv_b - gv_a).abs().max().item() < 2e-4 * scale          # ~2300 float adds per element on the 12x25 level
+    assert torch.isfinite(gv_b).all() and gv_b.abs().sum() > 0
