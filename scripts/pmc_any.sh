@@ -16,7 +16,7 @@ for f in sorted(glob.glob("$R/gpurun_out/pmc_$TAG/p*/p_counter_collection.csv"))
     for r in csv.DictReader(open(f)):
         n = r['Kernel_Name']
         if re.search(r"$KRE", n):
-            agg[n.split('(')[0][-60:]][r['Counter_Name']].append(float(r['Counter_Value']))
+            agg[(__import__('re').search(r'(\w+_kernel\w*)', n) or [n, n])[1]][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in agg.items():
     print(k)
     for c, v in d.items():
