@@ -157,7 +157,11 @@ def deformable_sampling(module, query, value, reference_points, spatial_shapes, 
     (BEVDeformableAttention, bevformer/attention/image_cross_attention.py:323-328)."""
     bs, num_query, _ = query.shape
     _, num_value, _ = value.shape
-    assert int((spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum()) == num_value
+    host_shapes = getattr(spatial_shapes, '_so_host', None)
+    if host_shapes is not None:      # no device read-back (a stream sync per call) when the caller knows the shapes
+        assert sum(host_shapes[0::2][i] * host_shapes[1::2][i] for i in range(len(host_shapes) // 2)) == num_value
+    else:
+        assert int((spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum()) == num_value
     value = module.value_proj(value)
     if key_padding_mask is not None:
         value = value.masked_fill(key_padding_mask[..., None], 0.0)

@@ -35,6 +35,37 @@ def _normalise(meter, lo0, hi0, lo1, hi1):
     return meter
 
 
+_PLANE_SHAPES = {}
+
+
+def _plane_shapes(H, W, Z, device):
+    """(spatial_shapes, level_start_index) of the three TPV planes as 'levels' of the cross-view attention;
+    cached per (size, device) — a host list -> device tensor copy is a synchronising call."""
+    key = (H, W, Z, str(device))
+    hit = _PLANE_SHAPES.get(key)
+    if hit is None:
+        ss = torch.tensor([[H, W], [Z, H], [W, Z]], device=device)
+        ss._so_host = [H, W, Z, H, W, Z]
+        lsi = torch.tensor([0, H * W, H * W + Z * H], device=device)
+        hit = _PLANE_SHAPES[key] = (ss, lsi)
+    return hit
+
+
+_LEVEL_SHAPES = {}
+
+
+def _level_shapes(shapes, device):
+    """(spatial_shapes, level_start_index) of the FPN levels, cached per (shapes, device): the same every frame."""
+    key = (shapes, str(device))
+    hit = _LEVEL_SHAPES.get(key)
+    if hit is None:
+        ss = torch.as_tensor(shapes, dtype=torch.long, device=device)
+        ss._so_host = [int(v) for hw in shapes for v in hw]   # host copy for the MSDA backward decomposition
+        lsi = torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1]))
+        hit = _LEVEL_SHAPES[key] = (ss, lsi)
+    return hit
+
+
 @MODELS.register_module()
 class TPVPositionalEncoding(BaseModule):
     def __init__(self, num_freqs, embed_dims, tpv_meters, tot_range, init_cfg=None):
@@ -131,9 +162,7 @@ class TPVFormerLayer(_FormerLayerBase):
         split = lambda t: t if self.multi_plane_ffn_norm else torch.split(t, sizes, 1)
         for op in self.operation_order:
             if op == 'self_attn':   # cross-view hybrid attention: the 3 planes are the 3 "levels"
-                ss = torch.tensor([[H, W], [Z, H], [W, Z]], device=device)
-                ss._so_host = [H, W, Z, H, W, Z]
-                lsi = torch.tensor([0, H * W, H * W + Z * H], device=device)
+                ss, lsi = _plane_shapes(H, W, Z, device)     # constants: uploaded once, not once per layer call
                 q = torch.cat(query, dim=1)
                 q = self.attentions[attn_i](q, q, q, torch.cat(identity, dim=1) if self.pre_norm else None,
                                             query_pos=torch.cat(tpv_pos, dim=1), reference_points=ref_2d,
@@ -225,9 +254,7 @@ class _EncoderBase(BaseModule):
             shapes.append((h, w))
             flat.append(feat)
         flat = torch.cat(flat, 2).permute(0, 2, 1, 3)
-        spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=device)
-        spatial_shapes._so_host = [int(v) for hw in shapes for v in hw]   # host copy for the MSDA backward plan
-        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+        spatial_shapes, level_start_index = _level_shapes(tuple(shapes), device)
         return flat, spatial_shapes, level_start_index
 
 

@@ -162,6 +162,15 @@ class SDFField(BaseModule):
     def inv_s(self):
         return torch.exp(self.variance * 10.0).clip(1e-6, 1e6)
 
+    def inv_s_host(self):
+        """inv_s as a python float for the render launch.  Reading it back is a stream sync, so the value is
+        cached until the parameter changes (evaluation: once; training: once per optimiser step)."""
+        v = self.variance
+        key = (v._version, v.data_ptr())
+        if getattr(self, '_inv_s_cache', (None, None))[0] != key:
+            self._inv_s_cache = (key, float(self.inv_s().detach()))
+        return self._inv_s_cache[1]
+
     def _mlp(self, x):
         """density_net applied to (rows, C); Linear layers through _TallLinear (same parameters)."""
         for m in self.density_net:
@@ -349,7 +358,7 @@ class NeuSHead(BaseModule):
         device = vol.sdf.device
         rays, pix, num_cams, num_rays = self._rays(metas, device)
         cfg = self._render_cfg(False)
-        cfg.inv_s = float(self.model.field.inv_s())
+        cfg.inv_s = self.model.field.inv_s_host()
         vol = SDFVolume(vol.mapping, vol.sdf.detach(), None if vol.feat is None else vol.feat.detach(), vol.n_rgb, vol.n_sem)
         bk = torch.rand(rays.n_rays, 3, device=device) if cfg.bkgd_mode == abi.BKGD_PER_RAY else None
         out = render_rays(vol, rays, cfg, bkgd_rays=bk)
@@ -377,8 +386,9 @@ class NeuSHead(BaseModule):
             t_rand = torch.rand((N,) if cfg.jitter_mode == abi.JITTER_SINGLE else (N, S + 1), device=device)
         bk = torch.rand(N, 3, device=device) if cfg.bkgd_mode == abi.BKGD_PER_RAY else None
         inv_s = field.inv_s()
+        cfg.inv_s_host = field.inv_s_host()       # cached until the optimiser changes the parameter
         out = render_rays_autograd(vol, inv_s, rays, cfg, want_grad_samples=True, t_rand=t_rand, bkgd_rays=bk)
-        self.last_inv_s = float(inv_s.detach())
+        self.last_inv_s = cfg.inv_s_host
 
         shp = (1, num_cams, num_rays)
         depth, acc, fars = out['depth'].reshape(shp), out['acc'].reshape(shp), out['fars'].reshape(shp)

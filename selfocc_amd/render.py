@@ -105,6 +105,7 @@ class RenderConfig:
     aabb: tuple                       # (xmin, ymin, zmin, xmax, ymax, zmax)
     n_samples: int = 128
     inv_s: float = 20.0
+    inv_s_host: object = None         # optional host copy of the differentiable inv_s tensor (render_rays_autograd)
     near_plane: float = 0.0
     sample_pos: int = abi.SAMPLE_AT_START
     jitter_mode: int = abi.JITTER_NONE
@@ -228,7 +229,9 @@ class _RenderFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, sdf_vol, feat_vol, inv_s, mapping, n_rgb, n_sem, rays, cfg, t_rand, bkgd_rays, want_grad_samples):
         vol = SDFVolume(mapping, sdf_vol, feat_vol, n_rgb, n_sem)
-        cfg_run = RenderConfig(**{**cfg.__dict__, 'inv_s': float(inv_s.detach().reshape(-1)[0])})
+        # cfg.inv_s_host: the caller already holds the value of inv_s on the host (saves a stream sync per step)
+        host = getattr(cfg, 'inv_s_host', None)
+        cfg_run = RenderConfig(**{**cfg.__dict__, 'inv_s': float(inv_s.detach().reshape(-1)[0]) if host is None else float(host)})
         out = render_rays(vol, rays, cfg_run, per_sample=True, want_grad_samples=want_grad_samples,
                           t_rand=t_rand, bkgd_rays=bkgd_rays)
         ctx.vol, ctx.rays, ctx.cfg, ctx.t_rand, ctx.bkgd_rays = vol, rays, cfg_run, t_rand, bkgd_rays
