@@ -12,17 +12,18 @@ _META_CACHE = {}
 
 def _stack_meta(img_metas, key, like):
     """Per-frame camera matrices as one device tensor.  The encoder projects three planes with the same
-    matrices: the upload (a synchronising host -> device copy) happens once per frame, keyed on the identity of
-    the metas' arrays (bevformer/utils.py:119-126 converts them on every call)."""
+    matrices: the upload (a synchronising host -> device copy) happens once per frame, keyed on the matrices'
+    contents (bevformer/utils.py:119-126 converts them on every call)."""
     vals = [m[key] for m in img_metas]
     if isinstance(vals[0], (np.ndarray, list)):
-        ck = (key, tuple(id(v) for v in vals), str(like.device), like.dtype)
+        arr = np.asarray(vals)
+        ck = (key, arr.shape, arr.dtype.str, arr.tobytes(), str(like.device), like.dtype)   # < 1 KB of matrices
         hit = _META_CACHE.get(ck)
-        if hit is not None and all(a is b for a, b in zip(hit[0], vals)):
-            return hit[1]
-        t = like.new_tensor(np.asarray(vals))
-        _META_CACHE.clear()                    # one frame at a time; also keeps the arrays alive only for it
-        _META_CACHE[ck] = (vals, t)
+        if hit is not None:
+            return hit
+        t = like.new_tensor(arr)
+        _META_CACHE.clear()                    # one frame at a time
+        _META_CACHE[ck] = t
         return t
     return torch.stack(vals, dim=0).to(like)
 
