@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SELFOCC_ABI_VERSION 12
+#define SELFOCC_ABI_VERSION 13
 
 int selfocc_abi_version(void);
 const char *selfocc_last_error(void);
@@ -322,6 +322,17 @@ int selfocc_occ_resample(const so_occ_args *args, void *stream);
 int selfocc_iou_counts(const int32_t *pred, const int32_t *target, const uint8_t *mask,
                        int64_t n, const int32_t *class_indices, int32_t n_cls,
                        int32_t empty_label, unsigned long long *counts, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * SSIM term of the photometric losses (class SSIM, loss/reproj_loss_mono_multi_new_combine.py:26-66;
+ * also loss/rgb_loss_ms.py): reflection pad 1, 3x3 means, out = clamp((1 - SSIM) / 2, 0, 1), (N, C, H, W).
+ * x / y are addressed through element strides (n, c, h, w) — the call sites pass channel-last views; out,
+ * g_out, g_x, g_y are contiguous.  g_x or g_y may be NULL.  H, W >= 2. */
+int selfocc_ssim_fwd(const float *x, const float *y, const int64_t *x_strides, const int64_t *y_strides,
+                     int32_t N, int32_t C, int32_t H, int32_t W, float *out, void *stream);
+int selfocc_ssim_bwd(const float *x, const float *y, const int64_t *x_strides, const int64_t *y_strides,
+                     int32_t N, int32_t C, int32_t H, int32_t W, const float *g_out, float *g_x, float *g_y,
+                     void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Fused temporal reprojection photometric term.  Replaces the per-sample part of

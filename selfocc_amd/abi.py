@@ -6,7 +6,7 @@ its exported symbols being callable with these layouts.
 """
 import ctypes as C
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 # enums ---------------------------------------------------------------------------
 RAYS_EXPLICIT, RAYS_PIXEL_GRID = 0, 1
@@ -116,6 +116,8 @@ SYMBOLS = {
     "selfocc_field_volume_fwd": (C.c_int, [_p] * 3 + [_i] * 4 + [_p, _p, _i, _p, _p, _i, _p, _p, _i, _i, _p]),
     "selfocc_occ_resample": (C.c_int, [C.POINTER(SoOccArgs), _p]),
     "selfocc_iou_counts": (C.c_int, [_p, _p, _p, C.c_int64, _p, _i, _i, _p, _p]),
+    "selfocc_ssim_fwd": (C.c_int, [_p] * 4 + [_i] * 4 + [_p, _p]),
+    "selfocc_ssim_bwd": (C.c_int, [_p] * 4 + [_i] * 4 + [_p, _p, _p, _p]),
     "selfocc_reproj_fwd": (C.c_int, [C.POINTER(SoReprojArgs), _p]),
     "selfocc_reproj_bwd": (C.c_int, [C.POINTER(SoReprojArgs), _p, _p, _p, _p]),
 }
