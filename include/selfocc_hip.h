@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SELFOCC_ABI_VERSION 13
+#define SELFOCC_ABI_VERSION 14
 
 int selfocc_abi_version(void);
 const char *selfocc_last_error(void);
@@ -72,9 +72,17 @@ enum { SO_JITTER_NONE = 0, SO_JITTER_SINGLE = 1, SO_JITTER_PER_BIN = 2 };
 enum {
     SO_FLAG_DEPTH_DIV_NORM = 1, /* depth /= ||K^-1 (u,v,1)|| (z-depth, as the fork does) */
     SO_FLAG_CLAMP_RGB = 2,      /* eval: clamp rgb to [0,1]                              */
-    SO_FLAG_EXACT = 4           /* canonical IEEE operation order (bit-exact with oracle/):
-                                   slower; default is the fast path (rcp/exp2 hardware ops,
-                                   per-ray affine grid coordinates), same results to ~1e-6  */
+    SO_FLAG_EXACT = 4,          /* canonical IEEE operation order (bit-exact with oracle/): slower.
+                                   Default is the fast path: per-ray affine grid coordinates (cells
+                                   re-derived canonically within a few ulp of a voxel face, so the
+                                   SAME cell as the canonical path is always used), hardware exp2 /
+                                   rcp, a cancellation-free form of the NeuS alpha.  Parity of the
+                                   fast path with the canonical one is stated and measured in
+                                   DESIGN.md section 4 / tests/test_render_gpu.py (depth within 1e-4
+                                   relative on > 99.9 % of the rays that accumulate > 0.05)         */
+    SO_FLAG_NO_SKIP = 8,        /* fast path: do not skip saturated free-space samples (A/B switch;
+                                   the skip is exact, see sdf_brick)                               */
+    SO_FLAG_NO_FACE_SAFE = 16   /* fast path: never re-derive cells near voxel faces (A/B switch)  */
 };
 enum { SO_DTYPE_F32 = 0, SO_DTYPE_BF16 = 1 };
 
@@ -125,10 +133,15 @@ typedef struct so_render_args {
     float *sdf;       /* (n_rays, n_samples)                                           */
     float *grad;      /* (n_rays, n_samples, 3)  d sdf / d (x, y, z) in metres         */
     /* --- optional workspace --------------------------------------------------------- */
-    float *sdf_brick; /* [H][W][D][8] scratch or NULL.  When given, the fast path first
-                         re-packs sdf_vol so that the 8 corners of every cell are one 32-B
-                         record (2 x 16-B loads per sample instead of 4 x 8-B gathers) — the
-                         re-pack kernel is launched by selfocc_render_fwd on the same stream */
+    float *sdf_brick; /* scratch of H*W*D*33 bytes (16-B aligned) or NULL.  When given, the fast
+                         path first re-packs sdf_vol so that the 8 corners of every cell are one
+                         32-B record (2 x 16-B loads per sample instead of 4 x 8-B gathers),
+                         followed by one "free-space skip" byte per cell: the largest ray step for
+                         which every sample inside the cell has both NeuS sigmoids saturated to
+                         exactly 1.0f (alpha is then the constant 1e-5 / (1 + 1e-5) in the
+                         canonical float32 order too), so SDF-only per-ray launches composite
+                         such samples without interpolating.  The re-pack kernel is launched by
+                         selfocc_render_fwd on the same stream before the march.              */
 } so_render_args;
 
 int selfocc_render_fwd(const so_render_args *args, void *stream);
@@ -265,6 +278,15 @@ typedef struct so_query_args {
 } so_query_args;
 
 int selfocc_field_query(const so_query_args *args, void *stream);
+
+/* Backward of selfocc_field_query with respect to the volume(s) (the reference differentiates
+ * get_uniform_sdf through F.grid_sample: model/head/neus_head/neus_head.py:532-538 feeds
+ * `uniform_sdf` to SoftSparsityLoss, loss/sparsity_loss.py:67-81):
+ *   g_sdf (n) -> g_sdf_vol [H][W][D];  g_logits (n, n_sem) -> g_feat_vol [H][W][D][feat_stride] float32
+ * (channels n_rgb .. n_rgb + n_sem - 1).  Either pair may be NULL.  The volume gradients are
+ * ACCUMULATED (atomic adds): zero-initialise them.  Outputs of `args` (sdf, sem_*) are ignored. */
+int selfocc_field_query_bwd(const so_query_args *args, const float *g_sdf, const float *g_logits,
+                            float *g_sdf_vol, float *g_feat_vol, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Tri-plane -> dense volume: the head's pre_compute_density_color(representation)

@@ -52,6 +52,22 @@ def render_fwd(vol, rays, cfg, **kw):
     return out
 
 
+def render_fwd_f64(vol, rays, cfg):
+    """float64 evaluation of the canonical formulas (depth, acc) — the yardstick for the float32
+    oracle's own rounding noise (oracle_render.c: one_ray_f64); SDF-only semantics."""
+    import torch
+    from selfocc_amd import abi
+    from selfocc_amd.render import marshal_render_args
+    a, _out, _keep = marshal_render_args(vol, rays, cfg)
+    n = rays.n_rays
+    depth, acc = torch.empty(n, dtype=torch.float64), torch.empty(n, dtype=torch.float64)
+    fn = lib().oracle_render_fwd_f64
+    fn.restype, fn.argtypes = C.c_int, [C.POINTER(abi.SoRenderArgs), C.c_void_p, C.c_void_p]
+    rc = fn(a, depth.data_ptr(), acc.data_ptr())
+    assert rc == 0, f"oracle_render_fwd_f64 rc={rc}"
+    return {'depth': depth, 'acc': acc}
+
+
 def meter2grid(mapping, xyz, normalize=False):
     import torch
     from selfocc_amd import abi

@@ -315,6 +315,90 @@ int oracle_render_fwd(const so_render_args *a) {
     return 0;
 }
 
+/* ---- float64 evaluation of the SAME formulas (depth / acc only) ---------------------------------
+ * Not a second oracle: the parity bar is the float32 canonical order above (what the reference's
+ * float32 torch ops compute).  This is the yardstick for that bar: NeuS's alpha subtracts two
+ * sigmoids that differ by ~1e-5 in free space, so the canonical float32 result itself carries
+ * rounding noise; tests report |f32 oracle - f64| next to |HIP - f32 oracle| so that a reader can see
+ * how much of a difference is arithmetic noise of the reference's own precision.  Single-segment
+ * linear axes only (every shipped config). */
+static void one_ray_f64(const so_render_args *a, int ray, double *depth_out, double *acc_out) {
+    const int H = a->map.h.tot_len, W = a->map.w.tot_len, D = a->map.d.tot_len;
+    const int S = a->n_samples;
+    double o[3], dir[3], dn;
+    if (a->ray_mode == SO_RAYS_PIXEL_GRID) {
+        int per_cam = a->nx * a->ny;
+        int cam = ray / per_cam, rem = ray % per_cam;
+        int iy = rem / a->nx, ix = rem % a->nx;
+        const float *M = a->img2lidar + 16 * cam;
+        double u = (double)((float)ix * a->sx + a->ox), v = (double)((float)iy * a->sy + a->oy);
+        for (int r = 0; r < 3; ++r) {
+            o[r] = M[4 * r + 3];
+            dir[r] = (double)M[4 * r + 0] * u + (double)M[4 * r + 1] * v + (double)M[4 * r + 2];
+        }
+        dn = sqrt(dir[0] * dir[0] + dir[1] * dir[1] + dir[2] * dir[2]);
+        for (int r = 0; r < 3; ++r) dir[r] /= dn;
+    } else {
+        for (int r = 0; r < 3; ++r) { o[r] = a->origins[3 * (size_t)ray + r]; dir[r] = a->dirs[3 * (size_t)ray + r]; }
+        dn = a->dir_norm ? a->dir_norm[ray] : 1.0;
+    }
+    double tn = -INFINITY, tf = INFINITY;
+    for (int r = 0; r < 3; ++r) {
+        double frac = 1.0 / (dir[r] + 1e-6);
+        double ta = (a->aabb[r] - o[r]) * frac, tb = (a->aabb[3 + r] - o[r]) * frac;
+        tn = fmax(tn, fmin(ta, tb));
+        tf = fmin(tf, fmax(ta, tb));
+    }
+    tn = fmax(tn, a->near_plane);
+    tf = fmax(tf, tn + 1e-6);
+    const so_axis *ax[3] = {&a->map.w, &a->map.h, &a->map.d}; /* metre x, y, z */
+    double trans = 1.0, acc = 0.0, dsum = 0.0;
+    for (int i = 0; i < S; ++i) {
+        double b0 = (double)i / S, b1 = (double)(i + 1) / S;
+        double t0 = b0 * tf + (1.0 - b0) * tn, t1 = b1 * tf + (1.0 - b1) * tn;
+        double tpos = (a->sample_pos == SO_SAMPLE_AT_START) ? t0 : 0.5 * (t0 + t1);
+        double g[3], slope[3];
+        for (int r = 0; r < 3; ++r) {
+            const so_axis *A = ax[r];
+            slope[r] = (double)A->size0 / A->range0;
+            g[r] = (o[r] + dir[r] * tpos - A->start) * slope[r] + A->off0 + A->off1;
+        }
+        double fw = floor(g[0]), fh = floor(g[1]), fd = floor(g[2]);
+        int iw = (int)fw, ih = (int)fh, id = (int)fd;
+        double ww[2] = {fw + 1 - g[0], g[0] - fw}, wh[2] = {fh + 1 - g[1], g[1] - fh}, wd[2] = {fd + 1 - g[2], g[2] - fd};
+        double sdf = 0, gd = 0, gw = 0, gh = 0;
+        for (int k = 0; k < 8; ++k) {
+            int kd = k & 1, kw = (k >> 1) & 1, kh = k >> 2;
+            int h = ih + kh, w = iw + kw, d = id + kd;
+            double v = in_bounds(h, w, d, H, W, D) ? a->sdf_vol[((size_t)h * W + w) * D + d] : 0.0;
+            sdf += v * wd[kd] * ww[kw] * wh[kh];
+            gd += (kd ? v : -v) * ww[kw] * wh[kh];
+            gw += (kw ? v : -v) * wd[kd] * wh[kh];
+            gh += (kh ? v : -v) * wd[kd] * ww[kw];
+        }
+        double cosv = dir[0] * gw * slope[0] + dir[1] * gh * slope[1] + dir[2] * gd * slope[2];
+        double half = fmin(cosv, 0.0) * (t1 - t0) * 0.5;
+        double pa = 1.0 / (1.0 + exp(-(sdf - half) * a->inv_s)), pb = 1.0 / (1.0 + exp(-(sdf + half) * a->inv_s));
+        double alpha = fmin(fmax((pa - pb + 1e-5) / (pa + 1e-5), 0.0), 1.0);
+        double w = alpha * trans;
+        trans *= (1.0 - alpha) + 1e-7;
+        acc += w;
+        dsum += w * 0.5 * (t0 + t1);
+    }
+    double depth = dsum / (acc + 1e-10);
+    if (a->flags & SO_FLAG_DEPTH_DIV_NORM) depth /= dn;
+    *depth_out = depth;
+    *acc_out = acc;
+}
+
+int oracle_render_fwd_f64(const so_render_args *a, double *depth, double *acc) {
+    if (a->map.h.size1 != 0.0f || a->map.w.size1 != 0.0f || a->map.d.size1 != 0.0f) return -1;
+    if (a->jitter_mode != SO_JITTER_NONE) return -1;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int ray = 0; ray < a->n_rays; ++ray) one_ray_f64(a, ray, depth + ray, acc + ray);
+    return 0;
+}
+
 /* Stand-alone pieces exposed for pinning against the imported reference / torch ops. */
 void oracle_meter2grid(const so_mapping *M, const float *xyz, int n, int normalize, float *hwd) {
     for (int i = 0; i < n; ++i) {

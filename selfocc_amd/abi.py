@@ -6,14 +6,14 @@ its exported symbols being callable with these layouts.
 """
 import ctypes as C
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 # enums ---------------------------------------------------------------------------
 RAYS_EXPLICIT, RAYS_PIXEL_GRID = 0, 1
 SAMPLE_AT_START, SAMPLE_AT_MID = 0, 1
 BKGD_NONE, BKGD_CONST, BKGD_PER_RAY = 0, 1, 2
 JITTER_NONE, JITTER_SINGLE, JITTER_PER_BIN = 0, 1, 2
-FLAG_DEPTH_DIV_NORM, FLAG_CLAMP_RGB, FLAG_EXACT = 1, 2, 4
+FLAG_DEPTH_DIV_NORM, FLAG_CLAMP_RGB, FLAG_EXACT, FLAG_NO_SKIP, FLAG_NO_FACE_SAFE = 1, 2, 4, 8, 16
 DTYPE_F32, DTYPE_BF16 = 0, 1
 
 _f, _i, _p = C.c_float, C.c_int32, C.c_void_p
@@ -112,6 +112,7 @@ SYMBOLS = {
     "selfocc_msda_bwd_banded_workspace": (C.c_size_t, [_i] * 5),
     "selfocc_msda_bwd_banded": (C.c_int, [_p] * 10 + [_i] * 7 + [_p, C.c_size_t, _p]),
     "selfocc_field_query": (C.c_int, [C.POINTER(SoQueryArgs), _p]),
+    "selfocc_field_query_bwd": (C.c_int, [C.POINTER(SoQueryArgs), _p, _p, _p, _p, _p]),
     "selfocc_field_volume_bwd": (C.c_int, [_p] * 3 + [_i] * 4 + [_p, _p, _p, _i, _p, _p, _i] + [_p] * 7 + [_p]),
     "selfocc_field_volume_fwd": (C.c_int, [_p] * 3 + [_i] * 4 + [_p, _p, _i, _p, _p, _i, _p, _p, _i, _i, _p]),
     "selfocc_occ_resample": (C.c_int, [C.POINTER(SoOccArgs), _p]),

@@ -67,6 +67,31 @@ __global__ __launch_bounds__(256) void field_query_kernel(so_query_args a) {
     }
 }
 
+// Backward of field_query_kernel with respect to the volume(s): the transpose of the trilinear gather.
+// One lane per query point, 8 (x n_sem) float atomics; the lattice is small (640 k points at the shipped
+// sizes) and neighbouring points hit neighbouring voxels, so the adds of a wave land in a few cache lines.
+__global__ __launch_bounds__(256) void field_query_bwd_kernel(so_query_args a, const float *__restrict__ g_sdf,
+                                                              const float *__restrict__ g_logits,
+                                                              float *__restrict__ g_sdf_vol, float *__restrict__ g_feat_vol) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const int H = a.map.h.tot_len, W = a.map.w.tot_len, D = a.map.d.tot_len;
+    const so_cell c = so_locate(a.map, a.xyz[3 * (size_t)i], a.xyz[3 * (size_t)i + 1], a.xyz[3 * (size_t)i + 2]);
+    const float fd[2] = {c.fd0, c.fd1}, fw[2] = {c.fw0, c.fw1}, fh[2] = {c.fh0, c.fh1};
+    const float gs = (g_sdf && g_sdf_vol) ? g_sdf[i] : 0.0f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int h = c.h0 + (k >> 2), w = c.w0 + ((k >> 1) & 1), d = c.d0 + (k & 1);
+        if (h < 0 || h >= H || w < 0 || w >= W || d < 0 || d >= D) continue;   // zero padding: no gradient
+        const float wk = (fd[k & 1] * fw[(k >> 1) & 1]) * fh[k >> 2];
+        const size_t vox = ((size_t)h * W + w) * D + d;
+        if (g_sdf && g_sdf_vol) atomicAdd(g_sdf_vol + vox, gs * wk);
+        if (g_logits && g_feat_vol)
+            for (int q = 0; q < a.n_sem; ++q)
+                atomicAdd(g_feat_vol + vox * a.feat_stride + a.n_rgb + q, g_logits[(size_t)i * a.n_sem + q] * wk);
+    }
+}
+
 __global__ __launch_bounds__(256) void occ_resample_kernel(so_occ_args a) {
     const int n = a.n0 * a.n1 * a.n2;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -150,6 +175,25 @@ extern "C" int selfocc_field_query(const so_query_args *args, void *stream) {
         SO_REQUIRE(a.feat_dtype == SO_DTYPE_F32 || a.feat_dtype == SO_DTYPE_BF16, "bad feat_dtype");
     }
     hipLaunchKernelGGL(field_query_kernel, dim3((a.n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    return so_launch_status();
+}
+
+extern "C" int selfocc_field_query_bwd(const so_query_args *args, const float *g_sdf, const float *g_logits,
+                                       float *g_sdf_vol, float *g_feat_vol, void *stream) {
+    SO_REQUIRE(args != nullptr, "args is NULL");
+    const so_query_args &a = *args;
+    if (so_validate_mapping(a.map)) return -1;
+    SO_REQUIRE(a.n >= 0, "n must be >= 0");
+    if (a.n == 0) return 0;
+    SO_REQUIRE(a.xyz != nullptr, "xyz is NULL");
+    SO_REQUIRE((g_sdf == nullptr) == (g_sdf_vol == nullptr), "g_sdf and g_sdf_vol go together");
+    SO_REQUIRE((g_logits == nullptr) == (g_feat_vol == nullptr), "g_logits and g_feat_vol go together");
+    if (g_logits) {
+        SO_REQUIRE(a.n_sem > 0 && a.feat_stride >= a.n_rgb + a.n_sem, "semantic gradient needs n_sem > 0 and a valid feat_stride");
+    }
+    if (!g_sdf && !g_logits) return 0;
+    hipLaunchKernelGGL(field_query_bwd_kernel, dim3((a.n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a, g_sdf,
+                       g_logits, g_sdf_vol, g_feat_vol);
     return so_launch_status();
 }
 

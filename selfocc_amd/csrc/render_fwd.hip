@@ -11,8 +11,8 @@
 // an 8x8 pixel tile so that, at every march step, the 64 gathers of a wave fall into a
 // handful of neighbouring voxels (L1/L2 hits; the volume itself is read from HBM once).
 // The transmittance recurrence is then a per-lane scalar chain — no cross-lane scan is
-// needed on this path (the wave-per-ray variant with a DPP scan lives in
-// render_train.hip, where the per-sample outputs must be written coalesced).
+// needed on this path (render_bwd.hip, which must reverse the recurrence, is the kernel
+// that scans across lanes).
 #include "so_device.h"
 
 #ifdef SO_STAGE_STATS
@@ -301,6 +301,41 @@ SO_DEVFN AxisK so_axis_affine(const so_axis &A) {
 
 SO_DEVFN float so_fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 SO_DEVFN float so_fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+SO_DEVFN int so_floor_i(float x) {   // (int)floorf(x) in one instruction
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
+// NeuS alpha = (sig(a) - sig(b) + 1e-5) / (sig(a) + 1e-5), a = (sdf - half) s, b = (sdf + half) s, half <= 0,
+// rewritten with ea = exp(-a), eb = exp(-b) >= ea so that no two nearly equal sigmoids are subtracted:
+//     alpha = ((eb - ea) / (1 + eb) + 1e-5 (1 + ea)) / (1 + 1e-5 (1 + ea))
+// (two reciprocals instead of three; exact algebra).  xs = sdf * s * log2(e), hs = half * s * log2(e) <= 0.
+// The exponents are clamped at 60: 2^60 keeps every term finite and alpha is 1 to ~1e-13 there already.
+SO_DEVFN float so_alpha_fast(float xs, float hs) {
+    const float ea = so_fast_exp2(fminf(hs - xs, 60.0f)), eb = so_fast_exp2(fminf(-hs - xs, 60.0f));
+    const float p = 1.0f + ea;
+    const float num = fmaf(eb - ea, so_fast_rcp(1.0f + eb), 1e-5f * p);
+    const float den = fmaf(1e-5f, p, 1.0f);
+    return fminf(num * so_fast_rcp(den), 1.0f);
+}
+
+// ---- free-space skip codes --------------------------------------------------------------------
+// A sample whose two sigmoid arguments both exceed 17.5 has exp(-arg) < 2^-25, so 1 + exp(-arg) == 1.0f and
+// BOTH sigmoids are exactly 1.0f in float32, in the canonical order as well: alpha is the constant
+// kAlphaFree = (0 + 1e-5f) / (1 + 1e-5f), no matter what the SDF value or gradient is.  Inside one voxel cell
+// the trilinear SDF is >= the smallest corner m and |cos| <= |grad| <= G (per-axis maxima of the edge
+// differences), so every sample of a ray with step dt inside the cell is such a sample whenever
+//     (m - G dt / 2) inv_s >= 17.5   <=>   dt <= 2 (m - 17.5 / inv_s) / G =: allow_dt(cell).
+// The brick re-pack pass stores allow_dt per cell as one byte in units of so_skip_unit() (rounded down, the ray's
+// own dt is rounded up), and a wave whose 64 lanes all sit in such cells composites the constant alpha without
+// touching the corners: same results, ~1/4 of the vector instructions of a full step.
+constexpr float kSkipArg = 17.5f;
+constexpr float kAlphaFree = 1e-5f / (1.0f + 1e-5f);
+SO_DEVFN float so_skip_unit(const float aabb[6], int n_samples) {   // metres per code step: box diagonal / S / 255
+    const float ex = aabb[3] - aabb[0], ey = aabb[4] - aabb[1], ez = aabb[5] - aabb[2];
+    return sqrtf(ex * ex + ey * ey + ez * ez) / ((float)n_samples * 255.0f);
+}
 
 
 // ---- LDS staging of the wavefront's voxel neighbourhood -----------------------------------
@@ -432,15 +467,19 @@ struct FastStep {
     unsigned cell;                // linear index of the low corner
     bool all_interior;            // wave-uniform: no lane needs padding at this step
     float v[8];                   // SDF corners (d fastest)
+    unsigned code;                // free-space skip code of the cell (0 = never skip)
     bool boxed, pref;             // wave-uniform: LDS staging applies / block already loaded
     int hmin, wmin, dmin;         // staged block origin
     so_f4v blk[NF >= 4 ? NF / 4 : 1];
 };
 
-template <int NF, bool BF16, bool PER_SAMPLE, bool STAGED = false>
-SO_DEVFN void so_march_fast(const so_render_args &a, int ray, const RayGeom &g, bool store = true,
+// `geom()` returns the lane's ray; it is called once up front and again inside the (rare) canonical cell
+// fallback, so that origin / direction / far need not stay in registers across the march loop.
+template <int NF, bool BF16, bool PER_SAMPLE, bool STAGED = false, class GeomFn>
+SO_DEVFN void so_march_fast(const so_render_args &a, int ray, GeomFn geom, bool store = true,
                              float *lds = nullptr, int lane = 0) {
     constexpr int NSEM = NF > 4 ? NF - 3 : 0;
+    const RayGeom g = geom(a);
     const int H = a.map.h.tot_len, W = a.map.w.tot_len, D = a.map.d.tot_len;
     const int S = a.n_samples;
     float tnear, tfar;
@@ -457,6 +496,7 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, const RayGeom &g, 
     const float G0d = fmaf(g.oz, kd.k1, kd.k0) + Gdd * t_off;
     const float s2 = a.inv_s * 1.44269504088896341f;  // exp(-x s) = exp2(-x s log2 e)
     const float hdt = 0.5f * dt;
+    const float hdt_s2 = hdt * s2;
 
     float T = 1.0f, acc = 0.0f, dsum = 0.0f;
     float rgb[3] = {0.0f, 0.0f, 0.0f};
@@ -468,9 +508,23 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, const RayGeom &g, 
     const __amdgpu_buffer_rsrc_t rs = so_make_rsrc(vol, (size_t)H * W * D * 4);
     const unsigned sD = (unsigned)D * 4u, sWD = (unsigned)W * D * 4u;
     const bool use_brick = a.sdf_brick != nullptr;                       // uniform
-    const __amdgpu_buffer_rsrc_t rb = so_make_rsrc(a.sdf_brick, use_brick ? (size_t)H * W * D * 32 : 0);
+    const unsigned n_cells = (unsigned)(H * W * D);
+    // brick workspace = 32-B corner records of every cell, then one skip-code byte per cell
+    const __amdgpu_buffer_rsrc_t rb = so_make_rsrc(a.sdf_brick, use_brick ? (size_t)n_cells * 33 : 0);
     const unsigned lane_vox = (unsigned)(((lane >> 4) * W + ((lane >> 2) & 3)) * D + (lane & 3));  // block voxel of this lane
     const __amdgpu_buffer_rsrc_t rf = so_make_rsrc(a.feat_vol, NF > 0 ? (size_t)H * W * D * NF * (BF16 ? 2 : 4) : 0);
+    // free-space skipping (see so_skip_unit): SDF-only launches that write no per-sample tensors
+    constexpr bool CAN_SKIP = (NF == 0) && !PER_SAMPLE;
+    const bool use_skip = CAN_SKIP && use_brick && !(a.flags & SO_FLAG_NO_SKIP);          // uniform
+    // the ray's own step, rounded UP to skip-code units (>= 1; > 255 never skips)
+    const int rcode = use_skip ? max((int)ceilf(dt / so_skip_unit(a.aabb, S)), 1) : 0x7fffffff;
+    // Cell selection.  g(t) above differs from the canonical divide chain by <= ~1.5 ulp of the coordinate; a
+    // sample within face_m of a voxel face could therefore land in the neighbouring cell, where the trilinear
+    // GRADIENT (hence alpha) differs.  Such lanes (~2e-4 of all samples) recompute their position in the
+    // canonical order, so the fast path picks the same cell as the canonical path / the reference, always.
+    const bool face_safe = !(a.flags & SO_FLAG_NO_FACE_SAFE);                                  // uniform
+    const int maxdim = max(H, max(W, D));
+    const float face_m = 3.0f * 1.1920929e-7f * (float)(1u << (32 - __builtin_clz((unsigned)maxdim)));
 
     constexpr bool PIPE = NF < 8;   // see the loop below
     // ---- stage 1: geometry of step i + every global load it needs, issued one step ahead ------
@@ -478,9 +532,41 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, const RayGeom &g, 
         st.fi = (float)i;
         const float step = st.fi * dt;
         const float gh = fmaf(Gdh, step, G0h), gw = fmaf(Gdw, step, G0w), gd = fmaf(Gdd, step, G0d);
-        const float flh = floorf(gh), flw = floorf(gw), fld = floorf(gd);
-        st.fh = gh - flh; st.fw = gw - flw; st.fd = gd - fld;
-        const int h0 = (int)flh, w0 = (int)flw, d0 = (int)fld;
+        st.fh = __builtin_amdgcn_fractf(gh); st.fw = __builtin_amdgcn_fractf(gw); st.fd = __builtin_amdgcn_fractf(gd);
+        int h0 = so_floor_i(gh), w0 = so_floor_i(gw), d0 = so_floor_i(gd);
+        if (face_safe) {
+            const float mf = fmaxf(fmaxf(fabsf(st.fh - 0.5f), fabsf(st.fw - 0.5f)), fabsf(st.fd - 0.5f));
+            const bool near_face = mf > 0.5f - face_m;
+            if (__any(near_face)) {
+                if (near_face) {   // canonical position: the operation order of so_march_exact / the oracle
+                    // The launch arguments are re-read from the kernarg segment through a pointer the optimiser
+                    // cannot see through (both kernels take so_render_args as their FIRST parameter): otherwise
+                    // every mapping / camera constant of this rare branch is hoisted out of the march loop and
+                    // held in ~40 SGPRs for its whole duration.
+                    typedef const __attribute__((address_space(4))) uint32_t *so_kernarg_ptr;
+                    so_kernarg_ptr ka = (so_kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+                    asm volatile("" : "+s"(ka));
+                    so_render_args ac;                       // only the fields used below are actually loaded (s_load)
+                    static_assert(sizeof(ac) % 4 == 0, "so_render_args is dword-sized");
+#pragma unroll
+                    for (unsigned k = 0; k < sizeof(ac) / 4; ++k) ((uint32_t *)&ac)[k] = ka[k];
+                    const RayGeom gc = geom(ac);
+                    float tn, tf;
+                    so_collide(ac, gc, tn, tf);
+                    const float t_start = so_edge(ac, ray, i, tn, tf);
+                    float px, py, pz;
+                    if (ac.sample_pos == SO_SAMPLE_AT_START) {
+                        px = gc.ox + gc.dx * t_start; py = gc.oy + gc.dy * t_start; pz = gc.oz + gc.dz * t_start;
+                    } else {
+                        const float tt = t_start + so_edge(ac, ray, i + 1, tn, tf);
+                        px = gc.ox + (gc.dx * tt) / 2.0f; py = gc.oy + (gc.dy * tt) / 2.0f; pz = gc.oz + (gc.dz * tt) / 2.0f;
+                    }
+                    const so_cell c = so_locate(ac.map, px, py, pz);
+                    h0 = c.h0; w0 = c.w0; d0 = c.d0;
+                    st.fh = c.fh1; st.fw = c.fw1; st.fd = c.fd1;
+                }
+            }
+        }
         st.h0 = h0; st.w0 = w0; st.d0 = d0;
         // a wave whose 64 cells are all strictly inside the volume (the common case) needs no
         // clamps / padding selects and addresses its 4 (h, w) columns as ONE 32-bit lane offset +
@@ -489,10 +575,14 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, const RayGeom &g, 
                               ((unsigned)d0 < (unsigned)(D - 1));
         st.all_interior = __all(interior);
         st.cell = (unsigned)((h0 * W + w0) * D + d0);
+        st.code = 0u;
         if (st.all_interior) {
             if (use_brick) {   // 8 corners = one 32-B record: 2 wide loads instead of 4 gathers
                 const unsigned vo = st.cell * 32u;
                 const so_f4v lo = so_bload4(rb, vo, 0u), hi = so_bload4(rb, vo + 16u, 0u);
+                if constexpr (CAN_SKIP) {
+                    if (use_skip) st.code = __builtin_amdgcn_raw_buffer_load_b8(rb, st.cell, n_cells * 32u, 0);
+                }
                 st.v[0] = lo.x; st.v[1] = lo.y; st.v[2] = lo.z; st.v[3] = lo.w;
                 st.v[4] = hi.x; st.v[5] = hi.y; st.v[6] = hi.z; st.v[7] = hi.w;
             } else {
@@ -536,29 +626,32 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, const RayGeom &g, 
     auto consume = [&](const int i, FastStep<NF> &st) __attribute__((always_inline)) {
         const float fh = st.fh, fw = st.fw, fd = st.fd, fi = st.fi;
         const float *v = st.v;
-        // nested lerps: d, then w, then h; gradients in voxel units reuse the differences
-        const float dd0 = v[1] - v[0], dd1 = v[3] - v[2], dd2 = v[5] - v[4], dd3 = v[7] - v[6];
-        const float c0 = fmaf(fd, dd0, v[0]), c1 = fmaf(fd, dd1, v[2]);
-        const float c2 = fmaf(fd, dd2, v[4]), c3 = fmaf(fd, dd3, v[6]);
-        const float dw0 = c1 - c0, dw1 = c3 - c2;
-        const float b0 = fmaf(fw, dw0, c0), b1 = fmaf(fw, dw1, c2);
-        const float dh0 = b1 - b0;
-        const float sdf = fmaf(fh, dh0, b0);
-        const float gvw = fmaf(fh, dw1 - dw0, dw0);
-        const float e0 = fmaf(fw, dd1 - dd0, dd0), e1 = fmaf(fw, dd3 - dd2, dd2);
-        const float gvd = fmaf(fh, e1 - e0, e0);
-        const float gvh = dh0;
+        float w, sdf = 0.0f, gvw = 0.0f, gvd = 0.0f, gvh = 0.0f;
+        bool skip = false;
+        if constexpr (CAN_SKIP) skip = __all((int)st.code >= rcode);   // every lane in saturated free space
+        if (skip) {
+            w = kAlphaFree * T;
+            T = T * ((1.0f - kAlphaFree) + 1e-7f);
+        } else {
+            // nested lerps: d, then w, then h; gradients in voxel units reuse the differences
+            const float dd0 = v[1] - v[0], dd1 = v[3] - v[2], dd2 = v[5] - v[4], dd3 = v[7] - v[6];
+            const float c0 = fmaf(fd, dd0, v[0]), c1 = fmaf(fd, dd1, v[2]);
+            const float c2 = fmaf(fd, dd2, v[4]), c3 = fmaf(fd, dd3, v[6]);
+            const float dw0 = c1 - c0, dw1 = c3 - c2;
+            const float b0 = fmaf(fw, dw0, c0), b1 = fmaf(fw, dw1, c2);
+            const float dh0 = b1 - b0;
+            sdf = fmaf(fh, dh0, b0);
+            gvw = fmaf(fh, dw1 - dw0, dw0);
+            const float e0 = fmaf(fw, dd1 - dd0, dd0), e1 = fmaf(fw, dd3 - dd2, dd2);
+            gvd = fmaf(fh, e1 - e0, e0);
+            gvh = dh0;
 
-        // NeuS alpha; cos = dir . grad_metres = sum_axis gv_axis * (dir_axis * slope_axis)
-        const float cosv = fmaf(gvd, Gdd, fmaf(gvw, Gdw, gvh * Gdh));
-        const float half = fminf(cosv, 0.0f) * hdt;
-        const float ea = so_fast_exp2((half - sdf) * s2);   // exp(-(sdf - half) s)
-        const float eb = so_fast_exp2(-(sdf + half) * s2);  // exp(-(sdf + half) s)
-        const float prev_cdf = so_fast_rcp(1.0f + ea), next_cdf = so_fast_rcp(1.0f + eb);
-        float alpha = ((prev_cdf - next_cdf) + 1e-5f) * so_fast_rcp(prev_cdf + 1e-5f);
-        alpha = fminf(fmaxf(alpha, 0.0f), 1.0f);
-        const float w = alpha * T;
-        T = T * ((1.0f - alpha) + 1e-7f);
+            // NeuS alpha; cos = dir . grad_metres = sum_axis gv_axis * (dir_axis * slope_axis)
+            const float cosv = fmaf(gvd, Gdd, fmaf(gvw, Gdw, gvh * Gdh));
+            const float alpha = so_alpha_fast(sdf * s2, fminf(cosv, 0.0f) * hdt_s2);
+            w = alpha * T;
+            T = T * ((1.0f - alpha) + 1e-7f);
+        }
 
         const float t_mid = fmaf(fi, dt, tnear + hdt);
         acc = acc + w;
@@ -677,26 +770,49 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, const RayGeom &g, 
     }
 }
 
-template <int NF, bool BF16, bool PER_SAMPLE, bool FAST>
-SO_DEVFN void so_march(const so_render_args &a, int ray, const RayGeom &g) {
-    if constexpr (FAST) so_march_fast<NF, BF16, PER_SAMPLE>(a, ray, g);
-    else so_march_exact<NF, BF16, PER_SAMPLE>(a, ray, g);
+template <int NF, bool BF16, bool PER_SAMPLE, bool FAST, class GeomFn>
+SO_DEVFN void so_march(const so_render_args &a, int ray, GeomFn geom) {
+    if constexpr (FAST) so_march_fast<NF, BF16, PER_SAMPLE>(a, ray, geom);
+    else so_march_exact<NF, BF16, PER_SAMPLE>(a, ray, geom(a));
 }
 
 
 // re-pack of the SDF volume for the fast path: brick[cell] = the 8 corners of cell (h, w, d),
-// d fastest, clamped at the upper faces (only interior cells are ever read)
+// d fastest, clamped at the upper faces (only interior cells are ever read); codes[cell] = the
+// free-space skip code of the cell (see so_skip_unit), 0 when skipping is off
 __global__ __launch_bounds__(256) void sdf_brickify_kernel(const float *__restrict__ vol, float *__restrict__ brick,
-                                                           int H, int W, int D) {
+                                                           int H, int W, int D, so_render_args a, int with_codes) {
     const int cell = blockIdx.x * blockDim.x + threadIdx.x;
     if (cell >= H * W * D) return;
     const int d = cell % D, w = (cell / D) % W, h = cell / (D * W);
     const int h1 = min(h + 1, H - 1), w1 = min(w + 1, W - 1), d1 = min(d + 1, D - 1);
     const float *r00 = vol + ((size_t)h * W + w) * D, *r01 = vol + ((size_t)h * W + w1) * D;
     const float *r10 = vol + ((size_t)h1 * W + w) * D, *r11 = vol + ((size_t)h1 * W + w1) * D;
+    const float v0 = r00[d], v1 = r00[d1], v2 = r01[d], v3 = r01[d1];
+    const float v4 = r10[d], v5 = r10[d1], v6 = r11[d], v7 = r11[d1];
     float4 *o = (float4 *)(brick + (size_t)cell * 8);
-    o[0] = make_float4(r00[d], r00[d1], r01[d], r01[d1]);
-    o[1] = make_float4(r10[d], r10[d1], r11[d], r11[d1]);
+    o[0] = make_float4(v0, v1, v2, v3);
+    o[1] = make_float4(v4, v5, v6, v7);
+    uint8_t *codes = (uint8_t *)(brick + (size_t)H * W * D * 8);
+    unsigned code = 0u;
+    if (with_codes) {
+        const float m = fminf(fminf(fminf(v0, v1), fminf(v2, v3)), fminf(fminf(v4, v5), fminf(v6, v7)));
+        // per-axis bound of the metre gradient anywhere in the cell: the partial derivative of a trilinear
+        // function is a bilinear blend of the 4 edge differences along that axis
+        const float gd = fmaxf(fmaxf(fabsf(v1 - v0), fabsf(v3 - v2)), fmaxf(fabsf(v5 - v4), fabsf(v7 - v6))) *
+                         (a.map.d.size0 / a.map.d.range0);
+        const float gw = fmaxf(fmaxf(fabsf(v2 - v0), fabsf(v3 - v1)), fmaxf(fabsf(v6 - v4), fabsf(v7 - v5))) *
+                         (a.map.w.size0 / a.map.w.range0);
+        const float gh = fmaxf(fmaxf(fabsf(v4 - v0), fabsf(v5 - v1)), fmaxf(fabsf(v6 - v2), fabsf(v7 - v3))) *
+                         (a.map.h.size0 / a.map.h.range0);
+        const float G = sqrtf((gd * gd + gw * gw) + gh * gh) * 1.001f + 1e-20f;
+        const float slack = m - kSkipArg / a.inv_s;                       // metres above the saturation level
+        if (slack > 0.0f && a.inv_s > 0.0f) {
+            const float allow = 2.0f * slack / G / so_skip_unit(a.aabb, a.n_samples);   // in code units
+            code = (unsigned)fminf(floorf(allow * 0.999f), 255.0f);
+        }
+    }
+    codes[cell] = (uint8_t)code;
 }
 
 // explicit rays: one ray per thread, linear order
@@ -707,13 +823,16 @@ template <int NF, bool BF16, bool PER_SAMPLE, bool FAST>
 __global__ __launch_bounds__(256, (NF >= 8 ? SO_WAVES_FEAT : 1)) void render_fwd_explicit(so_render_args a) {
     int ray = blockIdx.x * blockDim.x + threadIdx.x;
     if (ray >= a.n_rays) return;
-    RayGeom g;
-    g.ox = a.origins[3 * (size_t)ray]; g.oy = a.origins[3 * (size_t)ray + 1];
-    g.oz = a.origins[3 * (size_t)ray + 2];
-    g.dx = a.dirs[3 * (size_t)ray]; g.dy = a.dirs[3 * (size_t)ray + 1];
-    g.dz = a.dirs[3 * (size_t)ray + 2];
-    g.dn = a.dir_norm ? a.dir_norm[ray] : 1.0f;
-    so_march<NF, BF16, PER_SAMPLE, FAST>(a, ray, g);
+    auto geom = [&](const so_render_args &a) __attribute__((always_inline)) {
+        RayGeom g;
+        g.ox = a.origins[3 * (size_t)ray]; g.oy = a.origins[3 * (size_t)ray + 1];
+        g.oz = a.origins[3 * (size_t)ray + 2];
+        g.dx = a.dirs[3 * (size_t)ray]; g.dy = a.dirs[3 * (size_t)ray + 1];
+        g.dz = a.dirs[3 * (size_t)ray + 2];
+        g.dn = a.dir_norm ? a.dir_norm[ray] : 1.0f;
+        return g;
+    };
+    so_march<NF, BF16, PER_SAMPLE, FAST>(a, ray, geom);
 }
 
 // pixel-grid rays: block = 16x16 pixel tile of one camera, each wave an 8x8 sub-tile
@@ -735,13 +854,13 @@ __global__ __launch_bounds__(256, (NF >= 8 ? SO_WAVES_FEAT : 1)) void render_fwd
         const bool real = (ix < a.nx) && (iy < a.ny);
         ix = min(ix, a.nx - 1); iy = min(iy, a.ny - 1);
         int ray = (cam * a.ny + iy) * a.nx + ix;
-        RayGeom g = so_pixel_ray(a, cam, ix, iy);
-        so_march_fast<NF, BF16, PER_SAMPLE, true>(a, ray, g, real, s_stage + wave * StageGeom<NF>::kWaveDwords, lane);
+        auto geom = [&](const so_render_args &a) __attribute__((always_inline)) { return so_pixel_ray(a, cam, ix, iy); };
+        so_march_fast<NF, BF16, PER_SAMPLE, true>(a, ray, geom, real, s_stage + wave * StageGeom<NF>::kWaveDwords, lane);
     } else {
         if (ix >= a.nx || iy >= a.ny) return;
         int ray = (cam * a.ny + iy) * a.nx + ix;
-        RayGeom g = so_pixel_ray(a, cam, ix, iy);
-        so_march<NF, BF16, PER_SAMPLE, FAST>(a, ray, g);
+        auto geom = [&](const so_render_args &a) __attribute__((always_inline)) { return so_pixel_ray(a, cam, ix, iy); };
+        so_march<NF, BF16, PER_SAMPLE, FAST>(a, ray, geom);
     }
 }
 
@@ -769,8 +888,9 @@ int dispatch_ps(const so_render_args &a, hipStream_t st) {
     if (fast) {
         if (a.sdf_brick) {
             const int cells = a.map.h.tot_len * a.map.w.tot_len * a.map.d.tot_len;
+            const int with_codes = (NF == 0 && !per_sample && !(a.flags & SO_FLAG_NO_SKIP)) ? 1 : 0;
             hipLaunchKernelGGL(sdf_brickify_kernel, dim3((cells + 255) / 256), dim3(256), 0, st, a.sdf_vol, a.sdf_brick,
-                               a.map.h.tot_len, a.map.w.tot_len, a.map.d.tot_len);
+                               a.map.h.tot_len, a.map.w.tot_len, a.map.d.tot_len, a, with_codes);
         }
         return per_sample ? launch_fwd<NF, BF16, true, true>(a, st) : launch_fwd<NF, BF16, false, true>(a, st);
     }

@@ -8,10 +8,15 @@ with NO data-path collective:
   * eval:              every rank scores its shard, the integer / float metric sums are
                        all-reduced once per epoch (MeanIoU._after_epoch), or the rendered maps
                        are ``gather_rays``-ed;
-  * train:             each rank back-propagates its shard's loss; the gradient of the
-                       replicated field w.r.t. the tri-planes / MLP is summed by the usual DDP
-                       bucketed all-reduce, ``all_reduce_mean`` reports the global loss.
-The reference itself only has frame-per-GPU DDP (train.py:86-91).
+  * train:             ``replicate_grad_sum`` marks the replicated field volume: identity in
+                       forward, ONE all-reduce(sum) of dL/d(volume) in backward (the exchange step
+                       of SURVEY §8e cfg3); every rank renders its row block and
+                       ``gather_rays_autograd`` rebuilds the full-frame per-ray / per-sample tensors
+                       the (lattice-shaped) losses consume — its backward hands each rank the slice
+                       of the gradient that belongs to its rays.  ``all_reduce_mean`` reports the
+                       global rendered-depth loss.
+``NeuSHead(ray_shard=True)`` (or SELFOCC_RAY_SHARD=1) switches the head to this mode; bench.py
+``--shard rays`` times it.  The reference itself only has frame-per-GPU DDP (train.py:86-91).
 """
 import torch
 import torch.distributed as dist
@@ -49,6 +54,18 @@ def shard_rays(rays: RaySet, rank=None, world_size=None) -> RaySet:
                   dir_norm=None if rays.dir_norm is None else rays.dir_norm[s0:s1].contiguous())
 
 
+def _all_gather(bufs, t):
+    """dist.all_gather; gloo has no CUDA all_gather, so CUDA tensors are staged through the host there (only the
+    single-GPU test rigs run gloo on CUDA tensors — production is RCCL)."""
+    if t.is_cuda and dist.get_backend() == 'gloo':
+        host = [torch.empty(b.shape, dtype=b.dtype) for b in bufs]
+        dist.all_gather(host, t.cpu())
+        for b, h in zip(bufs, host):
+            b.copy_(h)
+        return
+    dist.all_gather(bufs, t)
+
+
 def gather_rays(t, rays: RaySet, dim_per_ray=()):
     """All-gather a per-ray tensor of the local shard back into full-frame order
     (n_cams, ny, nx, ...) for lattices / (n_rays, ...) for explicit rays.  ``rays`` is the
@@ -64,14 +81,14 @@ def gather_rays(t, rays: RaySet, dim_per_ray=()):
         pad = loc.new_zeros(n_cams, max_rows, rays.nx, *t.shape[1:])
         pad[:, :loc.shape[1]] = loc
         bufs = [torch.empty_like(pad) for _ in range(ws)]
-        dist.all_gather(bufs, pad.contiguous())
+        _all_gather(bufs, pad.contiguous())
         return torch.cat([b[:, :(r1 - r0)] for b, (r0, r1) in zip(bufs, rows)], dim=1)
     sizes = [row_block(rays.n_rays, r, ws) for r in range(ws)]
     mx = max(b - a for a, b in sizes)
     pad = t.new_zeros(mx, *t.shape[1:])
     pad[:t.shape[0]] = t
     bufs = [torch.empty_like(pad) for _ in range(ws)]
-    dist.all_gather(bufs, pad.contiguous())
+    _all_gather(bufs, pad.contiguous())
     return torch.cat([b[:(s1 - s0)] for b, (s0, s1) in zip(bufs, sizes)], dim=0)
 
 
@@ -84,3 +101,66 @@ def all_reduce_mean(value: torch.Tensor, count):
     buf = torch.stack([value.detach().reshape(()) * count, value.new_tensor(float(count))])
     dist.all_reduce(buf)
     return buf[0] / buf[1]
+
+
+def local_slice(full, rays: RaySet, rank=None, world_size=None):
+    """Inverse of ``gather_rays`` for one rank: the rows of a full-frame per-ray tensor ((n_cams * ny * nx, ...)
+    or (n_rays, ...)) that belong to ``rank``'s shard, flattened back to (n_local, ...)."""
+    if rank is None:
+        rank, world_size = world()
+    if world_size == 1:
+        return full
+    if rays.pixel_grid:
+        n_cams = rays.img2lidar.shape[0]
+        r0, r1 = row_block(rays.ny, rank, world_size)
+        f = full.reshape(n_cams, rays.ny, rays.nx, *full.shape[1:])
+        return f[:, r0:r1].reshape(-1, *full.shape[1:])
+    s0, s1 = row_block(rays.n_rays, rank, world_size)
+    return full[s0:s1]
+
+
+class _GatherRays(torch.autograd.Function):
+    """all-gather in forward; in backward every rank keeps the slice of the (rank-identical) full-frame gradient
+    that belongs to its own rays."""
+
+    @staticmethod
+    def forward(ctx, t, rays):
+        ctx.rays = rays
+        out = gather_rays(t, rays)
+        return out.reshape(-1, *t.shape[1:])
+
+    @staticmethod
+    def backward(ctx, g):
+        return local_slice(g, ctx.rays).contiguous(), None
+
+
+def gather_rays_autograd(t, rays: RaySet):
+    """``gather_rays`` under autograd, returned flat: (n_rays_full, ...)."""
+    if world()[1] == 1:
+        return t
+    return _GatherRays.apply(t, rays)
+
+
+class _GradSum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t):
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        if g.is_cuda and dist.get_backend() == 'gloo':   # single-GPU test rigs only
+            h = g.cpu()
+            dist.all_reduce(h)
+            return h.to(g.device)
+        dist.all_reduce(g)           # RCCL: one sum of dL/d(volume) over xGMI per iteration
+        return g
+
+
+def replicate_grad_sum(t):
+    """Mark a tensor that is REPLICATED on every rank and consumed by rank-local shards of the work: identity in
+    forward, all-reduce(sum) of its gradient in backward, so that each rank ends up with the gradient of the whole
+    (unsharded) loss.  For the ray-sharded head this is dL/d(sdf volume) and dL/d(feature volume)."""
+    if t is None or world()[1] == 1:
+        return t
+    return _GradSum.apply(t)

@@ -47,6 +47,67 @@ def field_query(vol, xyz, want_sdf=True, want_logits=False, want_argmax=False):
     return out
 
 
+class FieldQueryFunction(torch.autograd.Function):
+    """Differentiable trilinear query of the field volume at fixed metre positions: ``sdf (n)`` (and the
+    semantic ``logits (n, n_sem)``) attached to the autograd graph of ``sdf_vol`` / ``feat_vol``.  The reference
+    gets this gradient from autograd through ``F.grid_sample`` inside ``get_uniform_sdf``
+    (model/head/neus_head/neus_head.py:265-293, 532-538) — it is what makes ``uniform_sdf`` trainable for
+    SoftSparsityLoss / SparsityLoss (loss/sparsity_loss.py:28-81; config/kitti/kitti_occ.py:135-138,
+    config/nuscenes/nuscenes_occ_bev.py:157-160).  Positions carry no gradient (a fixed lattice)."""
+
+    @staticmethod
+    def forward(ctx, sdf_vol, feat_vol, xyz, mapping, n_rgb, n_sem, want_logits):
+        vol_feat = feat_vol if (feat_vol is not None and feat_vol.numel() > 0) else None
+        from .render import SDFVolume
+        vol = SDFVolume(mapping, sdf_vol.detach(), None if vol_feat is None else vol_feat.detach(), n_rgb, n_sem)
+        q = field_query(vol, xyz, want_sdf=True, want_logits=want_logits)
+        ctx.save_for_backward(sdf_vol, feat_vol if vol_feat is not None else sdf_vol.new_zeros(0), xyz)
+        ctx.meta = (mapping, n_rgb, n_sem, want_logits, vol_feat is not None)
+        if want_logits:
+            return q['sdf'], q['logits']
+        return q['sdf'], sdf_vol.new_zeros(0)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_sdf, g_logits):
+        sdf_vol, feat_vol, xyz = ctx.saved_tensors
+        mapping, n_rgb, n_sem, want_logits, has_feat = ctx.meta
+        a = abi.SoQueryArgs()
+        a.map = mapping.to_abi()
+        a.sdf_vol = ptr(sdf_vol)
+        a.n_rgb, a.n_sem = n_rgb, n_sem
+        xyz = xyz.contiguous().float()
+        a.xyz, a.n = ptr(xyz), xyz.shape[0]
+        g_sdf_vol = g_feat_vol = None
+        gs = gl = None
+        if ctx.needs_input_grad[0] and g_sdf is not None:
+            gs = g_sdf.contiguous().float()
+            g_sdf_vol = torch.zeros_like(sdf_vol, dtype=torch.float32)
+        if want_logits and has_feat and ctx.needs_input_grad[1] and g_logits is not None and g_logits.numel() > 0:
+            if feat_vol.dtype != torch.float32:
+                raise NotImplementedError("gradient of the semantic query needs a float32 feature volume")
+            a.feat_vol, a.feat_dtype, a.feat_stride = ptr(feat_vol), abi.DTYPE_F32, feat_vol.shape[3]
+            gl = g_logits.contiguous().float()
+            g_feat_vol = torch.zeros_like(feat_vol)
+        if gs is not None or gl is not None:
+            check(lib().selfocc_field_query_bwd(a, ptr(gs), ptr(gl), ptr(g_sdf_vol), ptr(g_feat_vol),
+                                                current_stream(xyz.device)), "selfocc_field_query_bwd")
+        return g_sdf_vol, g_feat_vol, None, None, None, None, None
+
+
+def field_query_autograd(vol, xyz, want_logits=False):
+    """``field_query`` under autograd: dict(sdf (n)[, logits (n, n_sem)]) differentiable w.r.t. ``vol.sdf`` /
+    ``vol.feat``."""
+    _need_cuda(vol.sdf, "field_query_autograd")
+    feat = vol.feat if (vol.feat is not None and want_logits) else vol.sdf.new_zeros(0)
+    sdf, logits = FieldQueryFunction.apply(vol.sdf, feat, xyz.reshape(-1, 3).detach(), vol.mapping, vol.n_rgb, vol.n_sem,
+                                           bool(want_logits and vol.n_sem > 0))
+    out = {'sdf': sdf}
+    if want_logits and vol.n_sem > 0:
+        out['logits'] = logits
+    return out
+
+
 def uniform_lattice(aabb, resolution, device, shift=False):
     """xyz lattice of NeuSHead.get_uniform_sdf (neus_head.py:266-281): (H, W, D, 3)."""
     xs = torch.linspace(aabb[0], aabb[3], int((aabb[3] - aabb[0]) / resolution), device=device)

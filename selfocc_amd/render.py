@@ -115,6 +115,8 @@ class RenderConfig:
     clamp_rgb: bool = False
     exact: bool = False               # canonical IEEE op order (bit-exact with the oracle), slower
     brick: bool = True                # fast path: re-pack the SDF volume into 8-corner records per launch
+    skip: bool = True                 # fast path + brick: composite saturated free-space samples without interpolating
+    face_safe: bool = True            # fast path: canonical cell selection within a few ulp of a voxel face
 
 
 def _c(t, dtype=torch.float32):
@@ -170,7 +172,8 @@ def marshal_render_args(vol: SDFVolume, rays: RaySet, cfg: RenderConfig, *, per_
         assert bkgd_rays is not None and tuple(bkgd_rays.shape) == (N, 3)
         a.bkgd_rays = ptr(_c(bkgd_rays))
     a.flags = (abi.FLAG_DEPTH_DIV_NORM if cfg.depth_div_norm else 0) | (abi.FLAG_CLAMP_RGB if cfg.clamp_rgb else 0) | \
-        (abi.FLAG_EXACT if cfg.exact else 0)
+        (abi.FLAG_EXACT if cfg.exact else 0) | (0 if cfg.skip else abi.FLAG_NO_SKIP) | \
+        (0 if cfg.face_safe else abi.FLAG_NO_FACE_SAFE)
 
     f32 = dict(dtype=torch.float32, device=dev)
     out = outputs if outputs is not None else {}
@@ -212,12 +215,14 @@ _BRICK_WS = {}
 
 
 def _brick_workspace(sdf):
-    """Per (device, shape) scratch for the 8-corner records of the SDF volume ([H][W][D][8] f32);
-    rewritten by every launch on the launch stream, so it is never stale."""
-    key = (sdf.device, tuple(sdf.shape))
+    """Per (device, stream, shape) scratch for the 8-corner records of the SDF volume ([H][W][D][8] f32) followed
+    by one skip-code byte per cell; rewritten by every launch on the launch stream, so it is never stale and two
+    streams never share one."""
+    key = (sdf.device, torch.cuda.current_stream(sdf.device).cuda_stream, tuple(sdf.shape))
     ws = _BRICK_WS.get(key)
     if ws is None:
-        ws = _BRICK_WS[key] = torch.empty(*sdf.shape, 8, dtype=torch.float32, device=sdf.device)
+        n = sdf.numel()
+        ws = _BRICK_WS[key] = torch.empty((n * 33 + 15) // 16 * 16, dtype=torch.uint8, device=sdf.device)
     return ws
 
 

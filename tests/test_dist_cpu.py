@@ -69,3 +69,52 @@ def test_ray_sharding_world2_gloo(explicit):
         p.join(120)
         assert p.exitcode == 0
     assert all(ret.get(r) for r in range(ws)), dict(ret)
+
+
+def _worker_autograd(rank, ws, port, ret):
+    """Sharded autograd == unsharded autograd: a replicated 'volume', rays split by rows, a lattice-shaped loss
+    on the gathered per-ray outputs.  A toy differentiable 'render' stands in for the kernel."""
+    from selfocc_amd.dist import gather_rays_autograd, replicate_grad_sum, local_slice
+    from selfocc_amd.render import RaySet
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        g = torch.Generator().manual_seed(0)
+        vol = torch.randn(16, generator=g, dtype=torch.float64)
+        n_cams, ny, nx = 2, 7, 5                                     # 7 rows: uneven split
+        full = RaySet(img2lidar=torch.eye(4)[None].repeat(n_cams, 1, 1), nx=nx, ny=ny, sx=1.0, sy=1.0)
+        feats = torch.randn(n_cams * ny * nx, 16, generator=g, dtype=torch.float64)   # per-ray "geometry"
+        target = torch.randn(n_cams, ny, nx, generator=g, dtype=torch.float64)
+
+        def render(v, f):                                            # per ray: a nonlinear function of the volume
+            return torch.tanh(f @ v), torch.sigmoid(f * v[None])     # (n,), (n, 16) "per-sample"
+
+        def loss_fn(depth, samples):                                 # needs the whole lattice (neighbour differences)
+            d = depth.reshape(n_cams, ny, nx)
+            return ((d - target) ** 2).mean() + (d[:, 1:] - d[:, :-1]).abs().mean() + samples.pow(3).mean()
+
+        v0 = vol.clone().requires_grad_(True)
+        loss_fn(*render(v0, feats)).backward()
+        v1 = vol.clone().requires_grad_(True)
+        mine = local_slice(feats, full)
+        assert mine.shape[0] < feats.shape[0]
+        d, s = render(replicate_grad_sum(v1), mine)
+        loss = loss_fn(gather_rays_autograd(d, full), gather_rays_autograd(s, full))
+        loss.backward()
+        ret[rank] = bool(torch.allclose(v1.grad, v0.grad, rtol=1e-12, atol=1e-14))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_autograd_equals_unsharded_world2_gloo():
+    ws = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_autograd, args=(r, ws, port, ret)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(ret.get(r) for r in range(ws)), dict(ret)

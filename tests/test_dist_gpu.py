@@ -1,0 +1,99 @@
+"""GPU (one MI355X, two processes sharing cuda:0 over gloo — RCCL refuses two ranks on one device, so the
+collectives are staged through the host here; production runs one rank per GPU over RCCL): the ray-sharded
+NeuSHead == the unsharded NeuSHead, eval render and training gradients, with the real HIP kernels."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, ws, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        import test_head_gpu as th
+        from selfocc_amd.registry import OPENOCC_LOSS
+        d = th.D0
+        msgs = []
+
+        def build(shard):
+            h = th.make_head(color_dims=8, return_sem=True, ray_sample_mode='fixed', ray_number=[7, 10],
+                             render_bkgd='white', ray_shard=shard, single_jitter=True)
+            return h
+
+        # ---- eval: prepare + render, sharded vs not ----------------------------------------------------
+        os.environ['eval'] = 'true'
+        rep, metas, imgs = th.make_inputs()
+        outs = []
+        for shard in (False, True):
+            h = build(shard).eval()
+            with torch.no_grad():
+                h.prepare(rep, metas)
+                outs.append(h.render(metas))
+        for k in ('ms_depths', 'ms_accs', 'ms_colors', 'ms_max_depths', 'sem'):
+            a, b = outs[0][k][0], outs[1][k][0]
+            # the shard's lattice offset oy + r0 * sy rounds differently from (iy + r0) * sy + oy: 1e-4, not bit-equal
+            if not torch.allclose(a, b, rtol=1e-4, atol=1e-5):
+                msgs.append(f"eval {k}: max diff {(a - b).abs().max().item():.3e}")
+        # ---- train: forward + loss + backward; gradient of the planes and of the field parameters ----
+        os.environ['eval'] = 'false'
+        grads = []
+        for shard in (False, True):
+            h = build(shard).eval()      # eval(): no jitter / random background, so both runs see the same rays
+            rep, metas, imgs = th.make_inputs()
+            out = h(rep, metas, global_iter=0)
+            loss_fn = OPENOCC_LOSS.build(dict(type='MultiLoss', sync_items=False, loss_cfgs=[
+                dict(type='ReprojLossMonoMultiNewCombine', weight=1.0, no_ssim=False, img_size=[64, 64], ray_resize=[7, 10],
+                     input_dict={'curr_imgs': 'curr_imgs', 'prev_imgs': 'prev_imgs', 'next_imgs': 'next_imgs',
+                                 'ray_indices': 'ray_indices', 'weights': 'weights', 'ts': 'ts', 'metas': 'metas',
+                                 'ms_rays': 'ms_rays'}),
+                dict(type='RGBLossMS', weight=0.1, img_size=[64, 64], no_ssim=False, ray_resize=[7, 10],
+                     input_dict={'ms_colors': 'ms_colors', 'ms_rays': 'ms_rays', 'gt_imgs': 'curr_imgs'}),
+                dict(type='EikonalLoss', weight=0.1)]))
+            total, _ = loss_fn(dict(out, metas=metas, **imgs))
+            total.backward()
+            grads.append(([r.grad.clone() for r in rep],
+                          {n: p.grad.clone() for n, p in h.named_parameters() if p.grad is not None}, total.detach()))
+        if not torch.allclose(grads[0][2], grads[1][2], rtol=1e-4, atol=1e-6):
+            msgs.append(f"loss {grads[0][2].item()} vs {grads[1][2].item()}")
+        for i, (a, b) in enumerate(zip(grads[0][0], grads[1][0])):
+            scale = a.abs().max().item()
+            if (a - b).abs().max().item() > 1e-4 * scale + 1e-9:
+                msgs.append(f"plane {i} grad: max diff {(a - b).abs().max().item():.3e} of {scale:.3e}")
+        for n in grads[0][1]:
+            a, b = grads[0][1][n], grads[1][1][n]
+            scale = a.abs().max().item()
+            if (a - b).abs().max().item() > 1e-4 * scale + 1e-9:
+                msgs.append(f"param {n} grad: max diff {(a - b).abs().max().item():.3e} of {scale:.3e}")
+        ret[rank] = msgs
+    except Exception as e:   # surface the failure in the parent
+        import traceback
+        ret[rank] = [f"exception: {e!r}\n{traceback.format_exc()}"]
+    finally:
+        dist.destroy_process_group()
+
+
+def test_ray_sharded_head_equals_unsharded_world2(hip):
+    ws = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, ws, port, ret)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    for r in range(ws):
+        assert ret.get(r) == [], f"rank {r}: {ret.get(r)}"

@@ -124,3 +124,69 @@ def test_head_forward_occ_matches_grid_sample(hip):
     assert torch.equal(res['sdf'].flatten().cpu(), h[:, 0])
     assert torch.equal(res['logits'].reshape(-1, 5).cpu(), h[:, 4:])
     assert torch.equal(res['sem'].flatten().cpu(), torch.argmax(h[:, 4:], -1))
+
+
+def test_field_query_backward_vs_torch_f64(hip):
+    """FieldQueryFunction: d/d(sdf volume) and d/d(feature volume) of the trilinear query against float64
+    torch autograd through the op the reference uses (F.grid_sample, align_corners=True)."""
+    from selfocc_amd.occ import field_query_autograd, uniform_lattice
+    from selfocc_amd.render import SDFVolume
+    vol = sy.make_volume("cfg1", n_rgb=3, n_sem=5, seed=5)
+    xyz = uniform_lattice(AABB, 0.4, torch.device('cpu'), shift=True).reshape(-1, 3)
+    xyz = torch.cat([xyz, xyz[:50] + torch.tensor([20.0, 0.0, 0.0])])          # some points outside: zero padding
+    g = torch.Generator().manual_seed(1)
+    gs, gl = torch.randn(xyz.shape[0], generator=g), torch.randn(xyz.shape[0], 5, generator=g)
+    # float64 reference through grid_sample
+    dc = vol.to_reference_layout().double().requires_grad_(True)
+    h = tp.field_lookup(vol.mapping, dc, xyz.double())
+    ((h[:, 0] * gs.double()).sum() + (h[:, 4:] * gl.double()).sum()).backward()
+    ref_gs = dc.grad[0, 0]
+    ref_gf = dc.grad[0, 4:].permute(1, 2, 3, 0)
+    v = SDFVolume(vol.mapping, vol.sdf.to(D0).requires_grad_(True), vol.feat.to(D0).requires_grad_(True), 3, 5)
+    q = field_query_autograd(v, xyz.to(D0), want_logits=True)
+    assert torch.allclose(q['sdf'].detach().cpu().double(), h[:, 0].detach(), rtol=1e-5, atol=1e-6)
+    ((q['sdf'] * gs.to(D0)).sum() + (q['logits'] * gl.to(D0)).sum()).backward()
+    assert torch.allclose(v.sdf.grad.cpu().double(), ref_gs, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(v.feat.grad[..., 3:8].cpu().double(), ref_gf, rtol=1e-4, atol=1e-5)
+    assert v.feat.grad[..., :3].abs().max() == 0
+
+
+@pytest.mark.parametrize("tpv,loss_type", [(True, 'SoftSparsityLoss'), (False, 'SoftSparsityLoss'), (True, 'SparsityLoss')])
+def test_uniform_sdf_gradient_reaches_the_planes(hip, tpv, loss_type, monkeypatch):
+    """return_uniform_sdf=True (config/kitti/kitti_occ.py:135-138,294; nuscenes_occ_bev.py:157-160,323): the
+    sparsity loss on `uniform_sdf` must train the field.  d loss / d (sdf volume) is checked against float64 torch
+    autograd of the reference's own op chain (grid_sample lookup -> loss; neus_head.py:265-293,
+    loss/sparsity_loss.py:7-81) on the very lattice the head drew."""
+    import selfocc_amd.model.head.neus_head as nh
+    os.environ['eval'] = 'false'
+    drawn = {}
+    real_lattice = nh.uniform_lattice
+
+    def recording_lattice(*a, **k):
+        drawn['xyz'] = real_lattice(*a, **k)
+        return drawn['xyz']
+    monkeypatch.setattr(nh, 'uniform_lattice', recording_lattice)
+    head = make_head(color_dims=3, return_sem=False, return_uniform_sdf=True, return_second_grad=False, tpv=tpv,
+                     embed_dims=32).train()
+    rep, metas, _ = make_inputs()
+    if not tpv:
+        rep = rep[0].detach().clone().requires_grad_(True)          # BEV: one (1, H*W, C) plane
+    np.random.seed(0)
+    out = head(rep, metas, global_iter=0)
+    usdf = out['uniform_sdf']
+    assert usdf is not None and usdf.requires_grad and usdf.shape == (32, 32, 7)
+    vol = head.model.field.volume
+    vol.sdf.retain_grad()
+    kw = dict(type=loss_type, weight=0.5, input_dict={'density': 'uniform_sdf'})
+    loss = OPENOCC_LOSS.build(kw)(out)
+    loss.backward()
+    for r in (rep if tpv else [rep]):
+        assert r.grad is not None and torch.isfinite(r.grad).all() and r.grad.abs().sum() > 0
+    # float64 reference on the recorded lattice
+    dc = vol.sdf.detach().cpu().double()[None, None].requires_grad_(True)
+    h = tp.field_lookup(vol.mapping, dc, drawn['xyz'].reshape(-1, 3).cpu().double())[:, 0].reshape(32, 32, 7)
+    assert torch.allclose(h.float(), usdf.detach().cpu(), rtol=1e-4, atol=1e-5)
+    ref_loss = OPENOCC_LOSS.build(kw)({'uniform_sdf': h})
+    ref_loss.backward()
+    assert torch.allclose(ref_loss.float(), loss.detach().cpu(), rtol=1e-4, atol=1e-7)
+    assert torch.allclose(vol.sdf.grad.cpu().double(), dc.grad[0, 0], rtol=1e-4, atol=1e-9)
