@@ -8,9 +8,12 @@ nuScenes-sized frame of BASELINE.json configs[1] — 6 cameras x 450x800 rays, 1
 samples / ray, 200x200x16 volume — rendered by selfocc_render_fwd (ray generation,
 AABB clip, sampling, trilinear SDF/colour/semantic lookup, NeuS alpha, compositing).
 Inputs (volume, camera matrices) are resident in HBM before the timed region.
-N > 1: one process per GPU (torchrun env), every rank renders its own frame (rays are
-independent units: no data-path collective) and the ranks all-reduce the scalar
-rendered-depth loss over RCCL each step, as north_star describes => weak scaling.
+N > 1: one process per GPU (torchrun env).  Default (`--shard frames`): the global ray batch is N
+frames, every rank marches one frame's worth of rays (rays are independent units: no data-path
+collective) and the ranks all-reduce the scalar rendered-depth loss over RCCL each step, as
+north_star describes => weak scaling.  `--shard rays`: ONE frame is split into
+row blocks over the ranks (selfocc_amd.dist.shard_rays, the mode NeuSHead(ray_shard=True) runs) =>
+strong scaling; at N > 1 the default run also reports it under "strong_scaling".
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the render
 kernel is the only kernel in a step); `cpu_baseline` times the torch-op port of the
@@ -39,6 +42,16 @@ def algorithmic_bytes(vol, n_rays, n_sem):
     return v + n_rays * per_ray_out, v, per_ray_out
 
 
+def kernel_source_hash():
+    """sha1 (12 hex) of the render kernel's sources: ties a PMC record in profiles/pmc_traffic.json to the
+    kernel it was measured on (scripts/pmc.sh writes the same hash next to the counters)."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in ("selfocc_amd/csrc/render_fwd.hip", "selfocc_amd/csrc/so_device.h", "include/selfocc_hip.h"):
+        h.update(open(os.path.join(ROOT, f), "rb").read())
+    return h.hexdigest()[:12]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -51,6 +64,12 @@ def main():
     ap.add_argument("--exact", action="store_true", help="canonical IEEE path (bit-exact with the oracle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
+    ap.add_argument("--shard", default="frames", choices=["frames", "rays"],
+                    help="N > 1: frames = one frame per rank (weak scaling, default) | rays = one frame split into row "
+                         "blocks over the ranks (strong scaling, SURVEY cfg3)")
+    ap.add_argument("--inv-s", type=float, default=20.0)
+    ap.add_argument("--no-skip", action="store_true", help="fast path without free-space skipping (A/B)")
+    ap.add_argument("--no-face-safe", action="store_true", help="fast path without canonical cell selection near faces (A/B)")
     ap.add_argument("--no-hotpath", action="store_true",
                     help="skip the whole-path stage timings (scripts/bench_hotpath_*.py) reported under \"hot_path\"")
     args = ap.parse_args()
@@ -76,17 +95,23 @@ def main():
 
     from selfocc_amd import synthetic as sy
     from selfocc_amd.render import render_rays, RaySet
+    from selfocc_amd.dist import shard_rays
 
     name = "cfg2"
     n_rgb, n_sem = {1: (0, 0), 4: (3, 0), 25: (3, 21)}[args.channels]
     fdt = torch.float32 if args.feat_dtype == "f32" else torch.bfloat16
-    vol_cpu = sy.make_volume(name, n_rgb=n_rgb, n_sem=n_sem, feat_dtype=fdt, seed=rank)
-    rays_cpu = sy.make_rays(name, seed=rank)
-    cfg = sy.make_render_config(name, inv_s=20.0, exact=args.exact)
+    split = args.shard == "rays" and world > 1
+    seed = 0 if split else rank                 # ray-sharded ranks work on the SAME frame
+    vol_cpu = sy.make_volume(name, n_rgb=n_rgb, n_sem=n_sem, feat_dtype=fdt, seed=seed)
+    rays_cpu = sy.make_rays(name, seed=seed)
+    cfg = sy.make_render_config(name, inv_s=args.inv_s, exact=args.exact, skip=not args.no_skip,
+                                face_safe=not args.no_face_safe)
     vol = vol_cpu.to(dev)
-    rays = RaySet(img2lidar=rays_cpu.img2lidar.to(dev), nx=rays_cpu.nx, ny=rays_cpu.ny,
-                  sx=rays_cpu.sx, sy=rays_cpu.sy)
+    full_rays = RaySet(img2lidar=rays_cpu.img2lidar.to(dev), nx=rays_cpu.nx, ny=rays_cpu.ny,
+                       sx=rays_cpu.sx, sy=rays_cpu.sy)
+    rays = shard_rays(full_rays, rank, world) if split else full_rays
     n_rays = rays.n_rays
+    rays_per_step_all_ranks = full_rays.n_rays if split else n_rays * world
     out = render_rays(vol, rays, cfg)  # allocates outputs once
     # ray-sharded ranks all-reduce the rendered-depth loss (north_star): one 4-byte RCCL all-reduce per
     # step, issued asynchronously into its own slot so that step i+1's render never waits for it
@@ -97,7 +122,12 @@ def main():
         render_rays(vol, rays, cfg, outputs=out)
         if world > 1:
             slot = losses[i:i + 1]
-            torch.mean(out['depth'], dim=0, keepdim=True, out=slot)
+            if split:   # shards differ by a row: weight the local mean by the local ray count
+                torch.sum(out['depth'], dim=0, keepdim=True, out=slot)
+                slot.div_(full_rays.n_rays)
+            else:
+                torch.mean(out['depth'], dim=0, keepdim=True, out=slot)
+                slot.div_(world)
             pending.append(dist.all_reduce(slot, async_op=True))
 
     def fence():
@@ -120,7 +150,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = t.item()
     ms_per_step = elapsed / args.steps * 1e3
-    value = n_rays * world * args.steps / elapsed
+    value = rays_per_step_all_ranks * args.steps / elapsed
 
     # ---- roofline of the dominant kernel: HIP events on the launch stream, kernel only ----
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -149,6 +179,11 @@ def main():
     if os.path.exists(pmc_file):
         key = f"c{args.channels}_{args.feat_dtype}_{'exact' if args.exact else 'fast'}"
         rec = json.load(open(pmc_file)).get(key)
+        if rec and rec.get("kernel_source_sha1") != kernel_source_hash():
+            # counters taken on an older build of the kernel say nothing about this one
+            roofline["traffic_note"] = (f"profiles/pmc_traffic.json[{key}] was measured on kernel source "
+                                        f"{rec.get('kernel_source_sha1')} != current {kernel_source_hash()}: not reported")
+            rec = None
         if rec:
             roofline["traffic"] = rec["traffic_bytes"]
             roofline["traffic_note"] = rec["note"]
@@ -161,10 +196,10 @@ def main():
 
     extras = {}
     if rank == 0 and world == 1 and not args.no_extras:
-        def time_variant(c, dt, exact, k=10):
+        def time_variant(c, dt, exact, k=10, **kw):
             nr, ns = {1: (0, 0), 4: (3, 0), 25: (3, 21)}[c]
             v = sy.make_volume(name, n_rgb=nr, n_sem=ns, feat_dtype=dt, seed=0).to(dev)
-            cf = sy.make_render_config(name, inv_s=20.0, exact=exact)
+            cf = sy.make_render_config(name, **{**dict(inv_s=args.inv_s, exact=exact), **kw})
             o = render_rays(v, rays, cf)
             torch.cuda.synchronize()
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -176,12 +211,62 @@ def main():
             return round(n_rays / (a.elapsed_time(b) / k * 1e-3), 1)
         extras = {
             "rays_per_s_c1_f32": time_variant(1, torch.float32, False),
+            "rays_per_s_c1_f32_no_skip": time_variant(1, torch.float32, False, skip=False),
+            "rays_per_s_c1_f32_no_skip_no_face_safe": time_variant(1, torch.float32, False, skip=False, face_safe=False),
+            "rays_per_s_c1_f32_inv_s_200": time_variant(1, torch.float32, False, inv_s=200.0),
             "rays_per_s_c1_f32_exact": time_variant(1, torch.float32, True, k=3),
             "rays_per_s_c4_f32": time_variant(4, torch.float32, False),
             "rays_per_s_c25_f32": time_variant(25, torch.float32, False),
             "rays_per_s_c25_bf16": time_variant(25, torch.bfloat16, False),
             "rays_per_s_c25_f32_exact": time_variant(25, torch.float32, True, k=3),
         }
+
+    # ---- parity of the timed configuration: the C oracle (float32 canonical order) on every 7th ray of the
+    # frame, against the outputs of the very launch that was timed (oracle/ is used as the checker only) ----
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle
+        ex = sy.explicit_rays(rays_cpu)
+        st = 7
+        sub = RaySet(origins=ex.origins[::st].contiguous(), dirs=ex.dirs[::st].contiguous(),
+                     dir_norm=ex.dir_norm[::st].contiguous())
+        ref = oracle.render_fwd(vol_cpu, sub, cfg)
+        got = {k: out[k][::st].cpu() for k in ('depth', 'acc')}
+        ok = ref['acc'] > 0.05
+        rel = (got['depth'] - ref['depth']).abs() / ref['depth'].abs().clamp_min(1e-6)
+        parity = {"checker": "oracle/oracle_render.c (float32 canonical order), every 7th ray of the timed frame",
+                  "n_rays": int(sub.n_rays), "frac_rays_acc_gt_0.05": round(ok.float().mean().item(), 4),
+                  "parity_frac_1e-4": round((rel[ok] < 1e-4).float().mean().item(), 6),
+                  "depth_max_rel_acc_gt_0.05": float(f"{rel[ok].max().item():.3e}"),
+                  "depth_max_abs_all_rays_m": float(f"{(got['depth'] - ref['depth']).abs().max().item():.3e}"),
+                  "acc_max_abs_all_rays": float(f"{(got['acc'] - ref['acc']).abs().max().item():.3e}"),
+                  "excluded_rays": 0}
+        if 'rgb' in ref:
+            parity["rgb_max_abs_all_rays"] = float(f"{(out['rgb'][::st].cpu() - ref['rgb']).abs().max().item():.3e}")
+
+    # ---- "the reference's batched-ray render path" on this GPU: the torch-op port of the reference's render
+    # (F.grid_sample + autograd gradient + NeuS compositing, oracle/torch_port.py) executed with stock
+    # PyTorch-ROCm ops on the MI355X in README-sized 90 000-ray chunks (neus_head.py:329-385).  Baseline only. ----
+    gpu_torch_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import torch_port as tp
+        ex = sy.explicit_rays(rays_cpu)
+        n_base = min(n_rays, 8 * 90_000)
+        eo, ed, en = ex.origins[:n_base].to(dev), ex.dirs[:n_base].to(dev), ex.dir_norm[:n_base].to(dev)
+        dc = vol.to_reference_layout()
+        tp.render_port(vol.mapping, dc, n_rgb, n_sem, eo[:90_000], ed[:90_000], en[:90_000], cfg)   # warm-up
+        torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        tp.render_port(vol.mapping, dc, n_rgb, n_sem, eo, ed, en, cfg, chunk=90_000)
+        torch.cuda.synchronize()
+        spent = time.perf_counter() - c0
+        gpu_torch_baseline = {"value": round(n_base / spent, 1), "unit": "rays/s",
+                              "kind": "torch-op port of the reference render on the same MI355X (stock PyTorch-ROCm "
+                                      "ops, 90 000-ray chunks)",
+                              "sample": f"first {n_base} rays of the same frame, C={args.channels}, {spent:.2f} s",
+                              "speedup_of_value": round(value / (n_base / spent), 1)}
+        del eo, ed, en, dc
+        torch.cuda.empty_cache()
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -203,6 +288,13 @@ def main():
         cpu_baseline = {"value": round(done / spent, 1), "unit": "rays/s", "cores": cores, "kind": "port",
                         "sample": f"first {done} rays of the same cfg2 frame (chunks of 90000), C={args.channels}, "
                                   f"torch CPU F.grid_sample + NeuS compositing, {spent:.1f} s"}
+        # the plain-C restatement (OpenMP, all cores) on every 7th ray of the frame, for scale
+        import oracle
+        ex7 = RaySet(origins=ex.origins[::7].contiguous(), dirs=ex.dirs[::7].contiguous(), dir_norm=ex.dir_norm[::7].contiguous())
+        c0 = time.perf_counter()
+        oracle.render_fwd(vol_cpu, ex7, cfg)
+        cpu_baseline["c_oracle_rays_per_s"] = round(ex7.n_rays / (time.perf_counter() - c0), 1)
+        cpu_baseline["c_oracle_cores"] = os.cpu_count()
 
     hot_path = None
     if rank == 0 and world == 1 and not args.no_hotpath and not args.no_extras:
@@ -223,18 +315,65 @@ def main():
             except Exception as e:   # never let the side measurement break the bench line
                 hot_path[key] = {"error": repr(e)[:300]}
 
+    roofline_msda = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        # the lifter's kernels, where an HBM roofline is meaningful: algorithmic bytes / HIP-event time
+        import subprocess
+        torch.cuda.empty_cache()
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_msda.py"), "--json"],
+                               capture_output=True, text=True, timeout=240)
+            last = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+            roofline_msda = json.loads(last[-1]) if last else {"error": (r.stderr or "no output")[-300:]}
+        except Exception as e:
+            roofline_msda = {"error": repr(e)[:300]}
+
+    strong = None
+    if world > 1 and not split:
+        # the same ranks, ONE frame split into row blocks (SURVEY cfg3), after the timed region
+        f0 = sy.make_rays(name, seed=0)
+        v0 = sy.make_volume(name, n_rgb=n_rgb, n_sem=n_sem, feat_dtype=fdt, seed=0).to(dev)
+        fr = RaySet(img2lidar=f0.img2lidar.to(dev), nx=f0.nx, ny=f0.ny, sx=f0.sx, sy=f0.sy)
+        mine = shard_rays(fr, rank, world)
+        o2 = render_rays(v0, mine, cfg)
+        dist.barrier(); torch.cuda.synchronize()
+        c0 = time.perf_counter()
+        acc2 = torch.zeros(args.steps, device=dev)
+        hs = []
+        for i in range(args.steps):
+            render_rays(v0, mine, cfg, outputs=o2)
+            torch.sum(o2['depth'], dim=0, keepdim=True, out=acc2[i:i + 1])
+            hs.append(dist.all_reduce(acc2[i:i + 1], async_op=True))
+        for h in hs:
+            h.wait()
+        dist.barrier(); torch.cuda.synchronize()
+        t2 = torch.tensor([time.perf_counter() - c0], device=dev, dtype=torch.float64)
+        dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+        strong = {"mode": "one frame split into row blocks over the ranks + all-reduce of the rendered-depth sum",
+                  "rays_per_s": round(fr.n_rays * args.steps / t2.item(), 1),
+                  "ms_per_frame": round(t2.item() / args.steps * 1e3, 4), "rays_per_rank": mine.n_rays}
+
     if rank == 0:
         line = {
             "metric": "rendered rays/sec (6-cam 450x800, 128 samples/ray)",
             "value": round(value, 1), "unit": "rays/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "strong" if split else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: 6 cams x 450x800 rays, 128 samples/ray, volume 200x200x16",
                        "volume_channels": args.channels, "feat_storage": args.feat_dtype,
-                       "rays_per_step_per_gpu": n_rays, "inv_s": 20.0,
-                       "path": "exact" if args.exact else "fast", "sharding": f"frame-per-rank x{world}"},
+                       "rays_per_step_per_gpu": n_rays, "inv_s": args.inv_s,
+                       "path": "exact" if args.exact else ("fast" + ("" if cfg.skip else ", no skip") + ("" if cfg.face_safe else ", no face_safe")),
+                       "sharding": (f"one frame split by rows x{world}" if split else f"frame-per-rank x{world}")},
             "roofline": roofline, "cpu_baseline": cpu_baseline,
         }
+        if parity:
+            line["parity"] = parity
+        if gpu_torch_baseline:
+            line["gpu_torch_baseline"] = gpu_torch_baseline
+        if roofline_msda:
+            line["roofline_msda"] = roofline_msda
+        if strong:
+            line["strong_scaling"] = strong
         if extras:
             line["extras"] = extras
         if hot_path:

@@ -33,7 +33,7 @@ def sh0_color(raw):
 # upstream sdfstudio pieces (absent fork; restated from the published algorithm)
 # ---------------------------------------------------------------------------------------
 def aabb_collider(origins, dirs, aabb, near_plane=0.0):
-    aabb = torch.as_tensor(aabb, dtype=origins.dtype).reshape(2, 3)
+    aabb = torch.as_tensor(aabb, dtype=origins.dtype, device=origins.device).reshape(2, 3)
     frac = 1.0 / (dirs + 1e-6)
     t1 = (aabb[0, 0] - origins[:, 0:1]) * frac[:, 0:1]
     t2 = (aabb[1, 0] - origins[:, 0:1]) * frac[:, 0:1]
@@ -49,7 +49,7 @@ def aabb_collider(origins, dirs, aabb, near_plane=0.0):
 
 
 def uniform_bins(n_rays, n_samples, nears, fars, t_rand=None):
-    bins = torch.linspace(0.0, 1.0, n_samples + 1)[None, :]
+    bins = torch.linspace(0.0, 1.0, n_samples + 1, device=nears.device)[None, :]
     if t_rand is not None:
         if t_rand.dim() == 1:
             t_rand = t_rand[:, None]
@@ -119,7 +119,7 @@ def _render_chunk(mapping, vol, n_rgb, n_sem, o, d, dn, cfg, t_rand, bkgd_rays, 
         col = sh0_color(h[:, 1:1 + n_rgb]).reshape(-1, S, 3)
         rgb = (weights[..., None] * col).sum(-2)
         if cfg.bkgd_mode == 1:
-            rgb = rgb + torch.tensor(cfg.bkgd) * (1.0 - acc[:, None])
+            rgb = rgb + torch.tensor(cfg.bkgd, device=rgb.device) * (1.0 - acc[:, None])
         elif cfg.bkgd_mode == 2:
             rgb = rgb + bkgd_rays * (1.0 - acc[:, None])
         if cfg.clamp_rgb:

@@ -1,23 +1,62 @@
-"""MSDA micro-benchmark at the reference's nuscenes_occ shapes:
-cross-attention of the three TPV planes (6 cameras as batch, 25500 keys, 6 heads x 16, 4 levels,
-P = 8 / 48 / 48) and the cross-view self-attention (78899 queries, 3 levels, P = 12).
-Prints per-kernel time and ALGORITHMIC GB/s (value + loc + attw + out, each once)."""
+"""MSDA micro-benchmark at the reference's nuscenes_occ shapes: cross-attention of the TPV
+planes (6 cameras, FPN 96x200 .. 12x25 = 25500 keys, 6 heads x 16, 4 levels, P = 8 / 48) and the cross-view
+self-attention (78899 queries, 3 levels, P = 12).
+
+Per kernel: HIP-event time and ALGORITHMIC GB/s — SURVEY §8(d): every distinct input byte once + every
+API-visible output byte once — against the 8 TB/s HBM peak.
+    plain     value + loc + attw + out                       (selfocc_msda_fwd / _bwd_banded)
+    fused     value + ref + off_raw + logits + out           (selfocc_msda_fused_fwd / _fused_bwd)
+    cross     value + ref + vis + off_raw + logits + out     (selfocc_msda_cross_fwd / _cross_bwd, camera loop)
+`--json`: one JSON object on the last line (bench.py's "roofline_msda")."""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from selfocc_amd.msda import MultiScaleDeformableAttnFunction as F
+from selfocc_amd.msda import (MultiScaleDeformableAttnFunction as F, MSDAFusedFunction, MSDACrossFunction,
+                              msda_fused_inference, msda_cross_inference)
 
+PEAK = 8000.0
 d = torch.device("cuda:0")
 torch.manual_seed(0)
+FPN = [[96, 200], [48, 100], [24, 50], [12, 25]]
 CASES = {
-    # name: (bs, nq, shapes, P, visible fraction of queries per camera)
-    "cross_hw": (6, 66049 // 3, [[96, 200], [48, 100], [24, 50], [12, 25]], 8),
-    "cross_zh": (6, 6425 // 3 * 2, [[96, 200], [48, 100], [24, 50], [12, 25]], 48),
+    # name: (bs, nq, shapes, P)
+    "cross_hw": (6, 66049 // 3, FPN, 8),
+    "cross_zh": (6, 6425 // 3 * 2, FPN, 48),
     "self_xview": (1, 78899, [[257, 257], [25, 257], [257, 25]], 12),
 }
-res = {}
+
+
+def timeit(fn, n=10):
+    fn(); torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record(); torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+
+def time_bwd(make_out, g, n=10):
+    """backward only (forward outside the events); includes the zero-fill of grad_value."""
+    tb = 0.0
+    for _ in range(n):
+        out = make_out()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); out.backward(g); b.record(); torch.cuda.synchronize()
+        tb += a.elapsed_time(b)
+    return tb / n
+
+
+def rec(kernel, shape, alg_bytes, ms, points):
+    gbps = alg_bytes / ms / 1e6
+    return dict(kernel=kernel, shape=shape, alg_MB=round(alg_bytes / 1e6, 1), ms=round(ms, 4), GBps=round(gbps, 1),
+                frac_of_8TBps=round(gbps / PEAK, 4), Gpoints_per_s=round(points / ms / 1e6, 2))
+
+
+rows = []
 for name, (bs, nq, shapes, P) in CASES.items():
     sh = torch.tensor(shapes, device=d)
+    sh._so_host = [int(v) for v in sh.reshape(-1).tolist()]
     st = torch.cat([sh.new_zeros(1), (sh[:, 0] * sh[:, 1]).cumsum(0)[:-1]])
     nv = int((sh[:, 0] * sh[:, 1]).sum()); L = len(shapes); H = 6; D = 16
     value = torch.randn(bs, nv, H, D, device=d)
@@ -25,34 +64,61 @@ for name, (bs, nq, shapes, P) in CASES.items():
     side = int(nq ** 0.5) + 1
     qi = torch.arange(nq, device=d)
     base = torch.stack([(qi % side) / side, (qi // side) / side], -1)            # nq, 2
-    loc = base[None, :, None, None, None, :] + torch.randn(bs, nq, H, L, P, 2, device=d) * (2.0 / 100)
-    attw = torch.softmax(torch.randn(bs, nq, H, L * P, device=d), -1).view(bs, nq, H, L, P)
+    off_raw = torch.randn(bs, nq, H, L, P, 2, device=d) * 2.0                     # pixels
+    wh = torch.stack([sh[:, 1], sh[:, 0]], -1).float()                            # (L, 2) = (W, H)
+    loc = base[None, :, None, None, None, :] + off_raw / wh[None, None, None, :, None, :]
+    logits = torch.randn(bs, nq, H, L * P, device=d)
+    attw = torch.softmax(logits, -1).view(bs, nq, H, L, P)
+    pts = bs * nq * H * L * P
+    tag = f"{name}: bs={bs} nq={nq} L={L} P={P} heads=6x16 keys={nv}"
+    # ---- plain op (the mmcv boundary) ----
     value.requires_grad_(True); loc.requires_grad_(True); attw.requires_grad_(True)
     out = F.apply(value, sh, st, loc, attw, 64)
     g = torch.randn_like(out)
-    out.backward(g)
-    torch.cuda.synchronize()
-    e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-    n = 10
-    e[0].record()
-    for _ in range(n):
-        with torch.no_grad():
-            F.apply(value, sh, st, loc, attw, 64)
-    e[1].record()
-    torch.cuda.synchronize()
-    fwd_ms = e[0].elapsed_time(e[1]) / n
-    tb = 0.0
-    for _ in range(n):
-        value.grad = loc.grad = attw.grad = None
-        out = F.apply(value, sh, st, loc, attw, 64)
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        a.record(); out.backward(g); b.record(); torch.cuda.synchronize()
-        tb += a.elapsed_time(b)
-    bwd_ms = tb / n
-    pts = bs * nq * H * L * P
+    with torch.no_grad():
+        fwd_ms = timeit(lambda: F.apply(value, sh, st, loc, attw, 64))
+    bwd_ms = time_bwd(lambda: F.apply(value, sh, st, loc, attw, 64), g)
     alg_f = 4 * (value.numel() + loc.numel() + attw.numel() + out.numel())
     alg_b = 4 * (value.numel() * 2 + loc.numel() * 2 + attw.numel() * 2 + out.numel())
-    res[name] = dict(points=pts, fwd_ms=round(fwd_ms, 4), bwd_ms_incl_memset=round(bwd_ms, 4),
-                     fwd_alg_GBps=round(alg_f / fwd_ms / 1e6, 1), bwd_alg_GBps=round(alg_b / bwd_ms / 1e6, 1),
-                     fwd_Gpts_per_s=round(pts / fwd_ms / 1e6, 2), alg_fwd_MB=round(alg_f / 1e6, 1))
-    print(name, json.dumps(res[name]), flush=True)
+    rows.append(rec("msda_fwd (plain)", tag, alg_f, fwd_ms, pts))
+    rows.append(rec("msda_bwd point+band (plain, incl. grad_value memset)", tag, alg_b, bwd_ms, pts))
+    # ---- fused prologue (softmax + loc inside the kernel) ----
+    ref = base[None, :, None, :].expand(bs, nq, L, 2).contiguous()               # ref_kind 0: (bs, nq, L, 2)
+    off_d = off_raw.detach().clone().requires_grad_(True)
+    lg_d = logits.detach().clone().requires_grad_(True)
+    val_d = value.detach().clone().requires_grad_(True)
+    try:
+        with torch.no_grad():
+            f_ms = timeit(lambda: msda_fused_inference(val_d, sh, st, ref, 0, off_d, lg_d))
+        alg_ff = 4 * (value.numel() + ref.numel() + off_raw.numel() + logits.numel() + out.numel())
+        rows.append(rec("msda_fused_fwd", tag, alg_ff, f_ms, pts))
+        fb_ms = time_bwd(lambda: MSDAFusedFunction.apply(val_d, sh, st, ref, 0, off_d, lg_d, sh._so_host), g)
+        alg_fb = 4 * (value.numel() * 2 + ref.numel() + off_raw.numel() * 2 + logits.numel() * 2 + out.numel())
+        rows.append(rec("msda_fused_bwd point+band (incl. grad_value memset)", tag, alg_fb, fb_ms, pts))
+    except Exception as e:   # a shape the fused / banded path does not take: keep the other rows
+        rows.append(dict(kernel="msda_fused", shape=tag, error=repr(e)[:200]))
+    if name == "cross_hw":
+        # ---- camera loop: BEVCrossAttention without the re-batch; every query visible in ~2 of 6 cameras ----
+        nq_full = 66049
+        vis = (torch.rand(bs, nq_full, device=d) < 1.0 / 3.0)
+        refc = torch.rand(bs, nq_full, P, 2, device=d)
+        offc = (torch.randn(nq_full, H, L, P, 2, device=d) * 2.0).requires_grad_(True)
+        lgc = torch.randn(nq_full, H, L * P, device=d).requires_grad_(True)
+        with torch.no_grad():
+            c_ms = timeit(lambda: msda_cross_inference(val_d, sh, st, refc, vis, offc, lgc))
+        outc = nq_full * H * D
+        alg_c = 4 * (value.numel() + refc.numel() + offc.numel() + lgc.numel() + outc) + vis.numel()
+        ptsc = int(vis.sum().item()) * H * L * P
+        tagc = f"cross_hw camera loop: cams=6 nq={nq_full} (visible pairs {int(vis.sum().item())}) L=4 P=8"
+        rows.append(rec("msda_cross_fwd", tagc, alg_c, c_ms, ptsc))
+        gc = torch.randn(nq_full, H * D, device=d)
+        cb_ms = time_bwd(lambda: MSDACrossFunction.apply(val_d, sh, st, refc, vis, offc, lgc, sh._so_host), gc)
+        alg_cb = 4 * (value.numel() * 2 + refc.numel() + offc.numel() * 2 + lgc.numel() * 2 + outc) + vis.numel()
+        rows.append(rec("msda_cross_bwd point+band (incl. grad_value memset)", tagc, alg_cb, cb_ms, ptsc))
+    for r in rows[-6:]:
+        if name in r["shape"] or "camera loop" in r["shape"]:
+            print(json.dumps(r), flush=True)
+
+print(json.dumps({"peak_GBps": PEAK, "bound": "hbm",
+                  "definition": "algorithmic bytes (SURVEY 8d: inputs once + outputs once) / HIP-event time per call",
+                  "kernels": rows}), flush=True)

@@ -10,6 +10,7 @@ for pass in "SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLE
   timeout 200 rocprofv3 --pmc $pass --output-format csv -d $R/gpurun_out/pmc_$TAG/p$i -o p -- python $R/scripts/prof_render.py $C 3 > /dev/null 2>&1
 done
 python - <<PY
+import sys; sys.path.insert(0, "$R"); import bench; print("kernel_source_sha1", bench.kernel_source_hash())
 import csv, glob, collections
 for f in sorted(glob.glob("$R/gpurun_out/pmc_$TAG/p*/p_counter_collection.csv")):
     agg = collections.defaultdict(list)

@@ -543,6 +543,11 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, GeomFn geom, bool 
                     // cannot see through (both kernels take so_render_args as their FIRST parameter): otherwise
                     // every mapping / camera constant of this rare branch is hoisted out of the march loop and
                     // held in ~40 SGPRs for its whole duration.
+#ifdef SO_FALLBACK_FLAT   // A/B build: read the arguments through a generic pointer (vector loads, fewer SGPRs)
+                    const so_render_args *ka = (const so_render_args *)__builtin_amdgcn_kernarg_segment_ptr();
+                    asm volatile("" : "+s"(ka));
+                    const so_render_args &ac = *ka;
+#else
                     typedef const __attribute__((address_space(4))) uint32_t *so_kernarg_ptr;
                     so_kernarg_ptr ka = (so_kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
                     asm volatile("" : "+s"(ka));
@@ -550,6 +555,7 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, GeomFn geom, bool 
                     static_assert(sizeof(ac) % 4 == 0, "so_render_args is dword-sized");
 #pragma unroll
                     for (unsigned k = 0; k < sizeof(ac) / 4; ++k) ((uint32_t *)&ac)[k] = ka[k];
+#endif
                     const RayGeom gc = geom(ac);
                     float tn, tf;
                     so_collide(ac, gc, tn, tf);
