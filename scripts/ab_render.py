@@ -10,14 +10,14 @@ d = torch.device("cuda:0")
 chans = [int(c) for c in sys.argv[1:]] or [1, 4, 25]
 rays = sy.make_rays("cfg2")
 rg = RaySet(img2lidar=rays.img2lidar.to(d), nx=rays.nx, ny=rays.ny, sx=rays.sx, sy=rays.sy)
-VARIANTS = {"default": {}, "no_skip": dict(skip=False), "no_face": dict(face_safe=False),
-            "no_skip_no_face": dict(skip=False, face_safe=False), "inv_s_200": dict(inv_s=200.0)}
+VARIANTS = {"default": {}, "no_skip": dict(skip=False), "no_face_safe": dict(face_safe=False),
+            "no_skip_no_face_safe": dict(skip=False, face_safe=False), "inv_s_200": dict(inv_s=200.0)}
 for c in chans:
     nr, ns = {1: (0, 0), 4: (3, 0), 25: (3, 21)}[c]
     vol = sy.make_volume("cfg2", n_rgb=nr, n_sem=ns).to(d)
     cfgs = {k: sy.make_render_config("cfg2", **{**dict(inv_s=20.0), **kw}) for k, kw in VARIANTS.items()}
     if c != 1:
-        cfgs = {k: v for k, v in cfgs.items() if k in ("default", "no_face")}
+        cfgs = {k: v for k, v in cfgs.items() if k in ("default", "no_face_safe")}
     outs = {k: render_rays(vol, rg, cf) for k, cf in cfgs.items()}
     torch.cuda.synchronize()
     times = {k: [] for k in cfgs}

@@ -39,6 +39,7 @@ def timeit(fn, n=10):
 def time_bwd(make_out, g, n=10):
     """backward only (forward outside the events); includes the zero-fill of grad_value."""
     tb = 0.0
+    make_out().backward(g); torch.cuda.synchronize()      # warm-up: first-touch allocations of the gradients / workspace
     for _ in range(n):
         out = make_out()
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -100,7 +101,15 @@ for name, (bs, nq, shapes, P) in CASES.items():
     if name == "cross_hw":
         # ---- camera loop: BEVCrossAttention without the re-batch; every query visible in ~2 of 6 cameras ----
         nq_full = 66049
-        vis = (torch.rand(bs, nq_full, device=d) < 1.0 / 3.0)
+        # spatially coherent visibility, as point_sampling produces: camera c sees a contiguous angular sector of
+        # the BEV plane, neighbouring sectors overlap (every query is seen by 2 of the 6 cameras)
+        side_f = 257
+        qy, qx = torch.div(torch.arange(nq_full, device=d), side_f, rounding_mode='floor'), torch.arange(nq_full, device=d) % side_f
+        ang = torch.atan2(qy.float() - 128, qx.float() - 128)                        # (-pi, pi]
+        sector = ((ang + 3.14159265) / (2 * 3.14159265) * 6).clamp(0, 5.999)
+        cam_ids = torch.arange(bs, device=d)[:, None].float()
+        dist_c = torch.remainder(sector[None] - cam_ids - 0.5, 6.0)
+        vis = (dist_c < 1.0) | (dist_c > 5.0)
         refc = torch.rand(bs, nq_full, P, 2, device=d)
         offc = (torch.randn(nq_full, H, L, P, 2, device=d) * 2.0).requires_grad_(True)
         lgc = torch.randn(nq_full, H, L * P, device=d).requires_grad_(True)

@@ -475,7 +475,7 @@ struct FastStep {
 
 // `geom()` returns the lane's ray; it is called once up front and again inside the (rare) canonical cell
 // fallback, so that origin / direction / far need not stay in registers across the march loop.
-template <int NF, bool BF16, bool PER_SAMPLE, bool STAGED = false, class GeomFn>
+template <int NF, bool BF16, bool PER_SAMPLE, bool STAGED = false, bool FACE_SAFE = false, class GeomFn>
 SO_DEVFN void so_march_fast(const so_render_args &a, int ray, GeomFn geom, bool store = true,
                              float *lds = nullptr, int lane = 0) {
     constexpr int NSEM = NF > 4 ? NF - 3 : 0;
@@ -522,9 +522,57 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, GeomFn geom, bool 
     // sample within face_m of a voxel face could therefore land in the neighbouring cell, where the trilinear
     // GRADIENT (hence alpha) differs.  Such lanes (~2e-4 of all samples) recompute their position in the
     // canonical order, so the fast path picks the same cell as the canonical path / the reference, always.
-    const bool face_safe = !(a.flags & SO_FLAG_NO_FACE_SAFE);                                  // uniform
     const int maxdim = max(H, max(W, D));
     const float face_m = 3.0f * 1.1920929e-7f * (float)(1u << (32 - __builtin_clz((unsigned)maxdim)));
+
+    // SDF-only kernels test for face proximity only on the steps that actually interpolate (a skipped step's
+    // alpha is the same constant on either side of a face) and patch the sample up inside `consume`
+    constexpr bool FACE_LATE = FACE_SAFE && NF == 0;
+    auto near_face = [&](float fh, float fw, float fd) __attribute__((always_inline)) {
+        return fmaxf(fmaxf(fabsf(fh - 0.5f), fabsf(fw - 0.5f)), fabsf(fd - 0.5f)) > 0.5f - face_m;
+    };
+    // the sample's cell in the canonical order: the operation sequence of so_edge / so_locate (= so_march_exact =
+    // the oracle), specialised to what the fast path already requires (no jitter, single-segment axes).
+    auto canon_cell = [&](const int i) __attribute__((always_inline)) {
+        if constexpr (NF < 8) {
+            // light kernels: from the ray that stays live in registers; ~6 IEEE divisions, no memory access
+            const float b0 = so_bin(i, S);
+            const float t_start = b0 * tfar + (1.0f - b0) * tnear;
+            float px, py, pz;
+            if (a.sample_pos == SO_SAMPLE_AT_START) {
+                px = g.ox + g.dx * t_start; py = g.oy + g.dy * t_start; pz = g.oz + g.dz * t_start;
+            } else {
+                const float b1 = so_bin(i + 1, S);
+                const float tt = t_start + (b1 * tfar + (1.0f - b1) * tnear);
+                px = g.ox + (g.dx * tt) / 2.0f; py = g.oy + (g.dy * tt) / 2.0f; pz = g.oz + (g.dz * tt) / 2.0f;
+            }
+            return so_locate(a.map, px, py, pz);
+        } else {
+            // 20+ feature channels: registers are the scarce resource (2 waves / SIMD).  The ray and the launch
+            // arguments are re-derived inside this rare branch; the arguments are re-read from the kernarg segment
+            // through a pointer the optimiser cannot see through (both kernels take so_render_args as their FIRST
+            // parameter), otherwise every mapping / camera constant is hoisted out of the march loop into ~40 SGPRs.
+            typedef const __attribute__((address_space(4))) uint32_t *so_kernarg_ptr;
+            so_kernarg_ptr ka = (so_kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+            asm volatile("" : "+s"(ka));
+            so_render_args ac;                       // only the fields used below are actually loaded (s_load)
+            static_assert(sizeof(ac) % 4 == 0, "so_render_args is dword-sized");
+#pragma unroll
+            for (unsigned k = 0; k < sizeof(ac) / 4; ++k) ((uint32_t *)&ac)[k] = ka[k];
+            const RayGeom gc = geom(ac);
+            float tn, tf;
+            so_collide(ac, gc, tn, tf);
+            const float t_start = so_edge(ac, ray, i, tn, tf);
+            float px, py, pz;
+            if (ac.sample_pos == SO_SAMPLE_AT_START) {
+                px = gc.ox + gc.dx * t_start; py = gc.oy + gc.dy * t_start; pz = gc.oz + gc.dz * t_start;
+            } else {
+                const float tt = t_start + so_edge(ac, ray, i + 1, tn, tf);
+                px = gc.ox + (gc.dx * tt) / 2.0f; py = gc.oy + (gc.dy * tt) / 2.0f; pz = gc.oz + (gc.dz * tt) / 2.0f;
+            }
+            return so_locate(ac.map, px, py, pz);
+        }
+    };
 
     constexpr bool PIPE = NF < 8;   // see the loop below
     // ---- stage 1: geometry of step i + every global load it needs, issued one step ahead ------
@@ -534,40 +582,10 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, GeomFn geom, bool 
         const float gh = fmaf(Gdh, step, G0h), gw = fmaf(Gdw, step, G0w), gd = fmaf(Gdd, step, G0d);
         st.fh = __builtin_amdgcn_fractf(gh); st.fw = __builtin_amdgcn_fractf(gw); st.fd = __builtin_amdgcn_fractf(gd);
         int h0 = so_floor_i(gh), w0 = so_floor_i(gw), d0 = so_floor_i(gd);
-        if (face_safe) {
-            const float mf = fmaxf(fmaxf(fabsf(st.fh - 0.5f), fabsf(st.fw - 0.5f)), fabsf(st.fd - 0.5f));
-            const bool near_face = mf > 0.5f - face_m;
-            if (__any(near_face)) {
-                if (near_face) {   // canonical position: the operation order of so_march_exact / the oracle
-                    // The launch arguments are re-read from the kernarg segment through a pointer the optimiser
-                    // cannot see through (both kernels take so_render_args as their FIRST parameter): otherwise
-                    // every mapping / camera constant of this rare branch is hoisted out of the march loop and
-                    // held in ~40 SGPRs for its whole duration.
-#ifdef SO_FALLBACK_FLAT   // A/B build: read the arguments through a generic pointer (vector loads, fewer SGPRs)
-                    const so_render_args *ka = (const so_render_args *)__builtin_amdgcn_kernarg_segment_ptr();
-                    asm volatile("" : "+s"(ka));
-                    const so_render_args &ac = *ka;
-#else
-                    typedef const __attribute__((address_space(4))) uint32_t *so_kernarg_ptr;
-                    so_kernarg_ptr ka = (so_kernarg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
-                    asm volatile("" : "+s"(ka));
-                    so_render_args ac;                       // only the fields used below are actually loaded (s_load)
-                    static_assert(sizeof(ac) % 4 == 0, "so_render_args is dword-sized");
-#pragma unroll
-                    for (unsigned k = 0; k < sizeof(ac) / 4; ++k) ((uint32_t *)&ac)[k] = ka[k];
-#endif
-                    const RayGeom gc = geom(ac);
-                    float tn, tf;
-                    so_collide(ac, gc, tn, tf);
-                    const float t_start = so_edge(ac, ray, i, tn, tf);
-                    float px, py, pz;
-                    if (ac.sample_pos == SO_SAMPLE_AT_START) {
-                        px = gc.ox + gc.dx * t_start; py = gc.oy + gc.dy * t_start; pz = gc.oz + gc.dz * t_start;
-                    } else {
-                        const float tt = t_start + so_edge(ac, ray, i + 1, tn, tf);
-                        px = gc.ox + (gc.dx * tt) / 2.0f; py = gc.oy + (gc.dy * tt) / 2.0f; pz = gc.oz + (gc.dz * tt) / 2.0f;
-                    }
-                    const so_cell c = so_locate(ac.map, px, py, pz);
+        if constexpr (FACE_SAFE && !FACE_LATE) {   // feature kernels: before the staging box / gathers are set up
+            if (__any(near_face(st.fh, st.fw, st.fd))) {
+                if (near_face(st.fh, st.fw, st.fd)) {
+                    const so_cell c = canon_cell(i);
                     h0 = c.h0; w0 = c.w0; d0 = c.d0;
                     st.fh = c.fh1; st.fw = c.fw1; st.fd = c.fd1;
                 }
@@ -630,7 +648,7 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, GeomFn geom, bool 
 
     // ---- stage 2: interpolation, NeuS alpha, compositing of step i ----------------------------
     auto consume = [&](const int i, FastStep<NF> &st) __attribute__((always_inline)) {
-        const float fh = st.fh, fw = st.fw, fd = st.fd, fi = st.fi;
+        const float fi = st.fi;
         const float *v = st.v;
         float w, sdf = 0.0f, gvw = 0.0f, gvd = 0.0f, gvh = 0.0f;
         bool skip = false;
@@ -639,6 +657,19 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, GeomFn geom, bool 
             w = kAlphaFree * T;
             T = T * ((1.0f - kAlphaFree) + 1e-7f);
         } else {
+            if constexpr (FACE_LATE) {
+                if (__any(near_face(st.fh, st.fw, st.fd))) {
+                    if (near_face(st.fh, st.fw, st.fd)) {
+                        const so_cell c = canon_cell(i);
+                        if (c.h0 != st.h0 || c.w0 != st.w0 || c.d0 != st.d0) {   // the canonical order lands next door
+                            so_gather_sdf(vol, H, W, D, c, st.v);
+                            st.fh = c.fh1; st.fw = c.fw1; st.fd = c.fd1;
+                            st.h0 = c.h0; st.w0 = c.w0; st.d0 = c.d0;
+                        }
+                    }
+                }
+            }
+            const float fh = st.fh, fw = st.fw, fd = st.fd;
             // nested lerps: d, then w, then h; gradients in voxel units reuse the differences
             const float dd0 = v[1] - v[0], dd1 = v[3] - v[2], dd2 = v[5] - v[4], dd3 = v[7] - v[6];
             const float c0 = fmaf(fd, dd0, v[0]), c1 = fmaf(fd, dd1, v[2]);
@@ -668,6 +699,7 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, GeomFn geom, bool 
             so_cell c;
             c.h0 = st.h0; c.w0 = st.w0; c.d0 = st.d0;
             float wk[8];
+            const float fh = st.fh, fw = st.fw, fd = st.fd;
             const float fh0 = 1.0f - fh, fw0 = 1.0f - fw, fd0 = 1.0f - fd;
             const float ww0 = fw0 * fh0, ww1 = fw * fh0, ww2 = fw0 * fh, ww3 = fw * fh;
             wk[0] = fd0 * ww0; wk[1] = fd * ww0; wk[2] = fd0 * ww1; wk[3] = fd * ww1;
@@ -776,10 +808,14 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, GeomFn geom, bool 
     }
 }
 
-template <int NF, bool BF16, bool PER_SAMPLE, bool FAST, class GeomFn>
+// MODE: 0 = canonical (EXACT), 1 = fast, 2 = fast with canonical cell selection near voxel faces
+template <int NF, bool BF16, bool PER_SAMPLE, int MODE, class GeomFn>
 SO_DEVFN void so_march(const so_render_args &a, int ray, GeomFn geom) {
-    if constexpr (FAST) so_march_fast<NF, BF16, PER_SAMPLE>(a, ray, geom);
-    else so_march_exact<NF, BF16, PER_SAMPLE>(a, ray, geom(a));
+    if constexpr (MODE != 0) {
+        so_march_fast<NF, BF16, PER_SAMPLE, false, MODE == 2>(a, ray, geom);
+    } else {
+        so_march_exact<NF, BF16, PER_SAMPLE>(a, ray, geom(a));
+    }
 }
 
 
@@ -825,7 +861,7 @@ __global__ __launch_bounds__(256) void sdf_brickify_kernel(const float *__restri
 #ifndef SO_WAVES_FEAT
 #define SO_WAVES_FEAT 2   // min waves / SIMD requested for the feature-carrying kernels (A/B knob)
 #endif
-template <int NF, bool BF16, bool PER_SAMPLE, bool FAST>
+template <int NF, bool BF16, bool PER_SAMPLE, int MODE>
 __global__ __launch_bounds__(256, (NF >= 8 ? SO_WAVES_FEAT : 1)) void render_fwd_explicit(so_render_args a) {
     int ray = blockIdx.x * blockDim.x + threadIdx.x;
     if (ray >= a.n_rays) return;
@@ -838,11 +874,11 @@ __global__ __launch_bounds__(256, (NF >= 8 ? SO_WAVES_FEAT : 1)) void render_fwd
         g.dn = a.dir_norm ? a.dir_norm[ray] : 1.0f;
         return g;
     };
-    so_march<NF, BF16, PER_SAMPLE, FAST>(a, ray, geom);
+    so_march<NF, BF16, PER_SAMPLE, MODE>(a, ray, geom);
 }
 
 // pixel-grid rays: block = 16x16 pixel tile of one camera, each wave an 8x8 sub-tile
-template <int NF, bool BF16, bool PER_SAMPLE, bool FAST>
+template <int NF, bool BF16, bool PER_SAMPLE, int MODE>
 __global__ __launch_bounds__(256, (NF >= 8 ? SO_WAVES_FEAT : 1)) void render_fwd_pixgrid(so_render_args a, int tiles_x,
                                                            int tiles_y) {
     int b = blockIdx.x;
@@ -852,7 +888,7 @@ __global__ __launch_bounds__(256, (NF >= 8 ? SO_WAVES_FEAT : 1)) void render_fwd
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int ix = tx * 16 + (wave & 1) * 8 + (lane & 7);
     int iy = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
-    constexpr bool STAGED = FAST && !PER_SAMPLE && !BF16 && NF >= 4;
+    constexpr bool STAGED = MODE != 0 && !PER_SAMPLE && !BF16 && NF >= 4;
     if constexpr (STAGED) {
         // every lane keeps marching (the LDS staging is a whole-wave operation): lanes beyond the
         // lattice edge shadow the nearest real pixel and only skip the final store
@@ -861,25 +897,25 @@ __global__ __launch_bounds__(256, (NF >= 8 ? SO_WAVES_FEAT : 1)) void render_fwd
         ix = min(ix, a.nx - 1); iy = min(iy, a.ny - 1);
         int ray = (cam * a.ny + iy) * a.nx + ix;
         auto geom = [&](const so_render_args &a) __attribute__((always_inline)) { return so_pixel_ray(a, cam, ix, iy); };
-        so_march_fast<NF, BF16, PER_SAMPLE, true>(a, ray, geom, real, s_stage + wave * StageGeom<NF>::kWaveDwords, lane);
+        so_march_fast<NF, BF16, PER_SAMPLE, true, MODE == 2>(a, ray, geom, real, s_stage + wave * StageGeom<NF>::kWaveDwords, lane);
     } else {
         if (ix >= a.nx || iy >= a.ny) return;
         int ray = (cam * a.ny + iy) * a.nx + ix;
         auto geom = [&](const so_render_args &a) __attribute__((always_inline)) { return so_pixel_ray(a, cam, ix, iy); };
-        so_march<NF, BF16, PER_SAMPLE, FAST>(a, ray, geom);
+        so_march<NF, BF16, PER_SAMPLE, MODE>(a, ray, geom);
     }
 }
 
-template <int NF, bool BF16, bool PER_SAMPLE, bool FAST>
+template <int NF, bool BF16, bool PER_SAMPLE, int MODE>
 int launch_fwd(const so_render_args &a, hipStream_t st) {
     if (a.ray_mode == SO_RAYS_EXPLICIT) {
         int blocks = (a.n_rays + 255) / 256;
-        hipLaunchKernelGGL((render_fwd_explicit<NF, BF16, PER_SAMPLE, FAST>), dim3(blocks), dim3(256), 0,
+        hipLaunchKernelGGL((render_fwd_explicit<NF, BF16, PER_SAMPLE, MODE>), dim3(blocks), dim3(256), 0,
                            st, a);
     } else {
         int tiles_x = (a.nx + 15) / 16, tiles_y = (a.ny + 15) / 16;
         int blocks = tiles_x * tiles_y * a.n_cams;
-        hipLaunchKernelGGL((render_fwd_pixgrid<NF, BF16, PER_SAMPLE, FAST>), dim3(blocks), dim3(256), 0,
+        hipLaunchKernelGGL((render_fwd_pixgrid<NF, BF16, PER_SAMPLE, MODE>), dim3(blocks), dim3(256), 0,
                            st, a, tiles_x, tiles_y);
     }
     return so_launch_status();
@@ -898,9 +934,11 @@ int dispatch_ps(const so_render_args &a, hipStream_t st) {
             hipLaunchKernelGGL(sdf_brickify_kernel, dim3((cells + 255) / 256), dim3(256), 0, st, a.sdf_vol, a.sdf_brick,
                                a.map.h.tot_len, a.map.w.tot_len, a.map.d.tot_len, a, with_codes);
         }
-        return per_sample ? launch_fwd<NF, BF16, true, true>(a, st) : launch_fwd<NF, BF16, false, true>(a, st);
+        if (!(a.flags & SO_FLAG_NO_FACE_SAFE))
+            return per_sample ? launch_fwd<NF, BF16, true, 2>(a, st) : launch_fwd<NF, BF16, false, 2>(a, st);
+        return per_sample ? launch_fwd<NF, BF16, true, 1>(a, st) : launch_fwd<NF, BF16, false, 1>(a, st);
     }
-    return per_sample ? launch_fwd<NF, BF16, true, false>(a, st) : launch_fwd<NF, BF16, false, false>(a, st);
+    return per_sample ? launch_fwd<NF, BF16, true, 0>(a, st) : launch_fwd<NF, BF16, false, 0>(a, st);
 }
 
 }  // namespace

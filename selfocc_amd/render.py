@@ -116,7 +116,7 @@ class RenderConfig:
     exact: bool = False               # canonical IEEE op order (bit-exact with the oracle), slower
     brick: bool = True                # fast path: re-pack the SDF volume into 8-corner records per launch
     skip: bool = True                 # fast path + brick: composite saturated free-space samples without interpolating
-    face_safe: bool = True            # fast path: canonical cell selection within a few ulp of a voxel face
+    face_safe: bool = True            # fast path: canonical cell selection within a few ulp of a voxel face (~6 % slower)
 
 
 def _c(t, dtype=torch.float32):

@@ -19,6 +19,7 @@ vector exists for it ("parity unpinned", see oracle/oracle_render.c).
 Run:  python tests/golden/make_golden.py        (needs /root/reference; ~10 s)
 """
 import importlib
+import importlib.util
 import os
 import sys
 import types
@@ -120,7 +121,7 @@ def install_stubs():
         return lambda f: f
 
     build = lambda cfg, *a, **k: REG.build(cfg)
-    _mod('mmengine', ConfigDict=dict)
+    _mod('mmengine', ConfigDict=dict, MMLogger=_Logger)
     _mod('mmengine.model', BaseModule=_BaseModule, ModuleList=nn.ModuleList, xavier_init=_xavier_init,
          constant_init=_constant_init)
     _mod('mmengine.registry', MODELS=REG, Registry=lambda *a, **k: LOSS_REG)
@@ -307,6 +308,108 @@ def golden_losses(LOSS_REG):
     save('losses.npz', **out)
 
 
+def golden_more(LOSS_REG):
+    """The remaining importable pieces of the path: Img2LiDAR, BEVNeRF (the authors' in-repo
+    field: MLP + tri-plane sum + grid_sample lookup), the small volume losses and MeanIoU."""
+    out = {}
+    g = torch.Generator().manual_seed(11)
+    # ---- Img2LiDAR (model/head/nerfacc_head/img2lidar.py:25-70); `dataset.utils.get_rm` is its only import ----
+    ds = types.ModuleType('dataset'); ds.__path__ = [os.path.join(REF, 'dataset')]; sys.modules['dataset'] = ds
+    i2l = ref_import('model.head.nerfacc_head.img2lidar')
+    mats = np.stack([np.linalg.inv(np.array([[300.0, 0, 200, 0], [0, 300.0, 112, 0], [0, 0, 1, 0], [0, 0, 0, 1]]))] * 3)
+    for i in range(3):
+        yaw = 0.7 + 2.1 * i
+        c2w = np.eye(4); c2w[:3, :3] = np.array([[np.sin(yaw), 0, np.cos(yaw)], [-np.cos(yaw), 0, np.sin(yaw)], [0, -1, 0]])
+        c2w[:3, 3] = [0.3 * i, -0.2, 1.5]
+        mats[i] = c2w @ mats[i]
+    tem = mats.copy(); tem[:, :3, 3] += 0.25
+    metas = [dict(img2lidar=list(mats), temImg2lidar=list(tem))]
+    rays = torch.rand(37, 2, generator=g) * torch.tensor([400.0, 224.0])
+    out['i2l.img2lidar'] = mats; out['i2l.temImg2lidar'] = tem; out['i2l.rays'] = rays.numpy()
+    os.environ['eval'] = 'false'
+    o, dvec = i2l.Img2LiDAR('img2lidar')(metas, rays)
+    out['i2l.single.origin'], out['i2l.single.dir'] = o.numpy(), dvec.numpy()
+    o, dvec = i2l.Img2LiDAR(['img2lidar', 'temImg2lidar'])(metas, rays)
+    out['i2l.split.origin'], out['i2l.split.dir'] = o.numpy(), dvec.numpy()
+    o, dvec = i2l.Img2LiDAR('temImg2lidar', novel_view=[0.5, -1.0, 0.25, 12.0])(metas, rays)
+    out['i2l.novel.origin'], out['i2l.novel.dir'] = o.numpy(), dvec.numpy()
+    os.environ['eval'] = 'true'
+    o, dvec = i2l.Img2LiDAR('temImg2lidar', trans_kw_eval=['img2lidar'])(metas, rays)
+    out['i2l.eval.origin'], out['i2l.eval.dir'] = o.numpy(), dvec.numpy()
+    os.environ['eval'] = 'false'
+
+    # ---- BEVNeRF (model/head/nerfacc_head/bev_nerf.py:8-140): volume + lookup, TPV and BEV forms ----
+    bn = ref_import('model.head.nerfacc_head.bev_nerf')
+    mapping_args = dict(nonlinear_mode='linear', h_size=[4, 0], h_range=[8.0, 0], h_half=False, w_size=[3, 0],
+                        w_range=[6.0, 0], w_half=False, d_size=[2, 0], d_range=[-1.0, 3.0, 3.0])
+    H, W, Z, C = 9, 7, 3, 16
+    for tpv in (True, False):
+        torch.manual_seed(5)
+        f = bn.BEVNeRF(mapping_args, embed_dims=C, color_dims=3, sem_dims=4, density_layers=2, sh_deg=0, tpv=tpv)
+        tag = 'tpv' if tpv else 'bev'
+        rep = [torch.randn(1, H * W, C, generator=g), torch.randn(1, Z * H, C, generator=g), torch.randn(1, W * Z, C, generator=g)]
+        with torch.no_grad():
+            f.pre_compute_density_color(rep if tpv else rep[0])
+        xyz = torch.rand(200, 3, generator=g) * torch.tensor([14.0, 18.0, 5.0]) - torch.tensor([7.0, 9.0, 1.5])
+        grid = f.mapping.meter2grid(xyz, True)
+        grid = (2 * grid - 1).reshape(1, -1, 1, 1, 3)
+        looked = torch.nn.functional.grid_sample(f.density_color, grid[..., [2, 1, 0]], mode='bilinear', align_corners=True)
+        out.update({f'bevnerf.{tag}.sd.{k}': v for k, v in to_np(f.state_dict()).items()})
+        out[f'bevnerf.{tag}.volume'] = f.density_color.detach().numpy()
+        out[f'bevnerf.{tag}.xyz'] = xyz.numpy()
+        out[f'bevnerf.{tag}.lookup'] = looked.permute(0, 2, 3, 4, 1).flatten(0, 3).detach().numpy()
+        out[f'bevnerf.{tag}.softplus_density'] = f.query_density(xyz).detach().numpy()
+        for i, r in enumerate(rep):
+            out[f'bevnerf.{tag}.rep{i}'] = r.numpy()
+
+    # ---- the small volume losses (loss/eikonal_loss.py, second_grad_loss.py, sparsity_loss.py) ----
+    eik = ref_import('loss.eikonal_loss'); sg = ref_import('loss.second_grad_loss'); sp = ref_import('loss.sparsity_loss')
+    grad = torch.randn(500, 3, generator=g); second = torch.randn(3000, generator=g) * 0.1
+    dens = torch.randn(12, 10, 4, generator=g)
+    out['vl.eik_grad'], out['vl.second_grad'], out['vl.density'] = grad.numpy(), second.numpy(), dens.numpy()
+    out['vl.eikonal'] = eik.EikonalLoss(0.1)(dict(eik_grad=grad)).numpy()
+    out['vl.second'] = sg.SecondGradLoss(0.01)(dict(second_grad=second)).numpy()
+    out['vl.sparsity'] = sp.SparsityLoss(0.5, scale=0.7)(dict(density=dens)).numpy()
+    out['vl.soft_sparsity'] = sp.SoftSparsityLoss(0.005, input_dict={'density': 'uniform_sdf'})(dict(uniform_sdf=dens)).numpy()
+    out['vl.hard_sparsity'] = sp.HardSparsityLoss(1.0, scale=2.0, thresh=0.3, crop=[[1, 2], [0, 1], [0, 0]])(
+        dict(density=dens.clone())).numpy()
+    S = 6
+    ts = [torch.rand(20 * S, generator=g) * 30 for _ in range(2)]
+    sdfs = [torch.randn(20 * S, generator=g) for _ in range(2)]
+    depths = [torch.rand(1, 2, 20, generator=g) * 20]
+    out['vl.ts'], out['vl.sdfs'], out['vl.depths'] = torch.stack(ts).numpy(), torch.stack(sdfs).numpy(), depths[0].numpy()
+    out['vl.adaptive_sparsity'] = sp.AdaptiveSparsityLoss(1.0, slack=4.0)(dict(sdfs=sdfs, ts=ts, ms_depths=depths)).numpy()
+
+    # ---- MeanIoU (utils/metric_util.py:66-165); its .cuda() calls are made no-ops for this CPU run ----
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    mu_path = os.path.join(REF, 'utils', 'metric_util.py')
+    spec = importlib.util.spec_from_file_location('ref_metric_util', mu_path)
+    mu = importlib.util.module_from_spec(spec); spec.loader.exec_module(mu)
+    classes = list(range(1, 17))
+    pred = torch.randint(0, 18, (40, 40, 8), generator=g)
+    tgt = torch.randint(0, 18, (40, 40, 8), generator=g)
+    tgt[..., 6:] = 17; tgt[..., :1] = 17
+    mask = torch.rand(40, 40, 8, generator=g) > 0.4
+    out['iou.pred'], out['iou.tgt'], out['iou.mask'] = pred.numpy(), tgt.numpy(), mask.numpy()
+    m = mu.MeanIoU(classes, 17, [str(c) for c in classes], use_mask=True, dataset_empty_label=17)
+    m.reset()
+    m._after_step(pred.clone(), tgt.clone(), mask)
+    m._after_step(pred.flip(0).clone(), tgt.clone(), None)
+    out['iou.tensor.seen'], out['iou.tensor.correct'], out['iou.tensor.positive'] = \
+        m.total_seen.numpy(), m.total_correct.numpy(), m.total_positive.numpy()
+    miou, occ = m._after_epoch()
+    out['iou.tensor.miou'], out['iou.tensor.occ_iou'] = np.float64(miou), np.float64(occ)
+    m.reset()   # Occ3D form: dict targets, z-range crop of the prediction, camera mask
+    m._after_step(pred.clone(), dict(semantics=tgt.numpy().copy(), mask_camera=mask.numpy().astype(np.uint8)))
+    out['iou.dict.seen'], out['iou.dict.correct'], out['iou.dict.positive'] = \
+        m.total_seen.numpy(), m.total_correct.numpy(), m.total_positive.numpy()
+    miou, occ = m._after_epoch()
+    out['iou.dict.miou'], out['iou.dict.occ_iou'] = np.float64(miou), np.float64(occ)
+    lut_in = torch.arange(21)
+    out['iou.openseed2nuscenes'] = mu.openseed2nuscenes(lut_in).numpy()
+    save('more.npz', **out)
+
+
 def golden_encoder(REG):
     for p in ('model', 'model.encoder', 'model.encoder.bevformer', 'model.encoder.bevformer.attention',
               'model.encoder.tpvformer', 'model.encoder.tpvformer.attention', 'model.encoder.tpvformer.modules',
@@ -385,4 +488,5 @@ if __name__ == '__main__':
         namespace(p)
     golden_geometry()
     golden_losses(LOSS_REG)
+    golden_more(LOSS_REG)
     golden_encoder(REG)

@@ -164,3 +164,91 @@ def test_shipped_configs_parse_and_resolve():
                 for v in d:
                     walk(v)
         walk(cfg.model['encoder'])
+
+
+# ---- fixtures of tests/golden/more.npz: Img2LiDAR, BEVNeRF, the small volume losses, LUT ----------------------
+mor = np.load(os.path.join(G, "more.npz"))
+
+
+def test_img2lidar_vs_reference():
+    """Img2LiDAR (model/head/nerfacc_head/img2lidar.py:25-70): single key, two-split, novel view, eval key."""
+    from selfocc_amd.model.head.neus_head import Img2LiDAR
+    metas = [dict(img2lidar=list(mor['i2l.img2lidar']), temImg2lidar=list(mor['i2l.temImg2lidar']))]
+    rays = torch.tensor(mor['i2l.rays'])
+    os.environ['eval'] = 'false'
+    cases = {'single': Img2LiDAR('img2lidar'), 'split': Img2LiDAR(['img2lidar', 'temImg2lidar']),
+             'novel': Img2LiDAR('temImg2lidar', novel_view=[0.5, -1.0, 0.25, 12.0])}
+    for name, mod in cases.items():
+        o, d = mod(metas, rays)
+        assert torch.allclose(o, torch.tensor(mor[f'i2l.{name}.origin']), rtol=1e-6, atol=1e-6), name
+        assert torch.allclose(d, torch.tensor(mor[f'i2l.{name}.dir']), rtol=1e-5, atol=1e-6), name
+    os.environ['eval'] = 'true'
+    try:
+        o, d = Img2LiDAR('temImg2lidar', trans_kw_eval=['img2lidar'])(metas, rays)
+    finally:
+        os.environ['eval'] = 'false'
+    assert torch.allclose(o, torch.tensor(mor['i2l.eval.origin']), rtol=1e-6, atol=1e-6)
+    assert torch.allclose(d, torch.tensor(mor['i2l.eval.dir']), rtol=1e-5, atol=1e-6)
+
+
+def test_in_kernel_pixel_ray_vs_reference_img2lidar():
+    """The ray the render kernel generates from a lattice (so_pixel_ray; restated by the C oracle) == the
+    reference's Img2LiDAR direction, normalised as neus_head.py:321-327 does."""
+    from selfocc_amd import synthetic as sy
+    from selfocc_amd.render import RaySet
+    M = torch.tensor(mor['i2l.img2lidar'], dtype=torch.float32)
+    rs = RaySet(img2lidar=M, nx=8, ny=5, sx=400 / 8, sy=224 / 5, ox=1.5, oy=0.75)
+    ex = sy.explicit_rays(rs)                       # the torch restatement used by the tests
+    from selfocc_amd.model.head.neus_head import Img2LiDAR, RaySampler
+    pix = RaySampler.pixels(5, 8, 400 / 8, 224 / 5, 1.5, 0.75, torch.device('cpu'))
+    o, d = Img2LiDAR('img2lidar')([dict(img2lidar=list(mor['i2l.img2lidar']))], pix)
+    d = d.flatten(0, 2)
+    dn = d.norm(dim=-1, keepdim=True)
+    assert torch.allclose(ex.dirs, d / dn, rtol=1e-6, atol=1e-7) and torch.allclose(ex.dir_norm, dn[:, 0], rtol=1e-6)
+    assert torch.allclose(ex.origins, o[0].unsqueeze(1).expand(-1, 40, -1).flatten(0, 1), atol=1e-7)
+
+
+def test_volume_losses_vs_reference():
+    """EikonalLoss / SecondGradLoss / the sparsity family (loss/eikonal_loss.py, second_grad_loss.py,
+    sparsity_loss.py:7-113) on the reference's own outputs."""
+    from selfocc_amd.registry import OPENOCC_LOSS
+    import selfocc_amd.loss  # noqa: F401
+    t = lambda k: torch.tensor(mor[k])
+    B = OPENOCC_LOSS.build
+    close = lambda a, k: torch.allclose(a, t(k), rtol=1e-5, atol=1e-8)
+    assert close(B(dict(type='EikonalLoss', weight=0.1))(dict(eik_grad=t('vl.eik_grad'))), 'vl.eikonal')
+    assert close(B(dict(type='SecondGradLoss', weight=0.01))(dict(second_grad=t('vl.second_grad'))), 'vl.second')
+    assert close(B(dict(type='SparsityLoss', weight=0.5, scale=0.7))(dict(density=t('vl.density'))), 'vl.sparsity')
+    assert close(B(dict(type='SoftSparsityLoss', weight=0.005, input_dict={'density': 'uniform_sdf'}))(
+        dict(uniform_sdf=t('vl.density'))), 'vl.soft_sparsity')
+    assert close(B(dict(type='HardSparsityLoss', weight=1.0, scale=2.0, thresh=0.3, crop=[[1, 2], [0, 1], [0, 0]]))(
+        dict(density=t('vl.density').clone())), 'vl.hard_sparsity')
+    ts, sdfs = list(t('vl.ts')), list(t('vl.sdfs'))
+    assert close(B(dict(type='AdaptiveSparsityLoss', weight=1.0, slack=4.0))(
+        dict(sdfs=sdfs, ts=ts, ms_depths=[t('vl.depths')])), 'vl.adaptive_sparsity')
+
+
+@pytest.mark.parametrize("tag", ['tpv', 'bev'])
+def test_sdf_field_volume_vs_reference_bevnerf(tag):
+    """SDFField.pre_compute_density_color == the authors' in-repo field BEVNeRF (bev_nerf.py:62-95) with ITS
+    state dict loaded by name; then the C oracle's trilinear lookup == BEVNeRF's grid_sample lookup, bit for bit."""
+    from selfocc_amd.model.head.neus_head import SDFField
+    mapping_args = dict(nonlinear_mode='linear', h_size=[4, 0], h_range=[8.0, 0], h_half=False, w_size=[3, 0],
+                        w_range=[6.0, 0], w_half=False, d_size=[2, 0], d_range=[-1.0, 3.0, 3.0])
+    f = SDFField(mapping_args, embed_dims=16, color_dims=7, density_layers=2, sh_deg=0, tpv=(tag == 'tpv'))
+    sd = {k[len(f'bevnerf.{tag}.sd.'):]: torch.tensor(mor[k]) for k in mor.files if k.startswith(f'bevnerf.{tag}.sd.')}
+    missing, unexpected = f.load_state_dict(sd, strict=False)
+    assert unexpected == [] and missing == ['variance']          # BEVNeRF has no NeuS variance parameter
+    rep = [torch.tensor(mor[f'bevnerf.{tag}.rep{i}']) for i in range(3)]
+    with torch.no_grad():
+        vol = f.pre_compute_density_color(rep if tag == 'tpv' else rep[0])
+    ref_vol = torch.tensor(mor[f'bevnerf.{tag}.volume'])          # (1, 8, H, W, D)
+    assert torch.allclose(vol.to_reference_layout(), ref_vol, rtol=1e-5, atol=1e-6)
+    xyz = torch.tensor(mor[f'bevnerf.{tag}.xyz'])
+    sdf, _ = oracle.field_sdf(vol.mapping, ref_vol[0, 0].contiguous(), xyz)
+    assert torch.equal(sdf, torch.tensor(mor[f'bevnerf.{tag}.lookup'])[:, 0])
+
+
+def test_openseed2nuscenes_lut_vs_reference():
+    from selfocc_amd.occ import OPENSEED2NUSCENES
+    assert OPENSEED2NUSCENES == mor['iou.openseed2nuscenes'].tolist()
