@@ -410,6 +410,66 @@ def golden_more(LOSS_REG):
     save('more.npz', **out)
 
 
+def golden_segmentor(REG):
+    """The calling protocol of the reference's own TPVSegmentor (model/segmentor/tpv_segmentor.py:87-123) over
+    lifter / encoder / head: which method of which stage is called with which keyword arguments, in the three modes
+    train.py / eval_depth.py / eval_iou.py use.  Recording stand-ins take the place of the five sub-modules, so the
+    fixture pins the reference's control flow itself; tests/test_golden_gpu.py replays it over OUR lifter / encoder
+    / head (the reference tree is not available on the GPU box)."""
+    import json
+    calls = []
+
+    class Rec(nn.Module):
+        def __init__(self, stage):
+            super().__init__()
+            self.stage = stage
+
+        def _rec(self, method, kw):
+            calls.append(dict(stage=self.stage, method=method, kwargs=sorted(kw)))
+
+        def forward(self, *args, **kw):
+            assert not args
+            self._rec('forward', kw)
+            return {'representation': 'rep'} if self.stage in ('lifter', 'encoder') else {'head_out': 1}
+
+        def prepare(self, *args, **kw):
+            self._rec('prepare', kw); return {}
+
+        def forward_occ(self, *args, **kw):
+            self._rec('forward_occ', kw); return {'sdf': 0}
+
+    class Backbone(nn.Module):
+        def forward(self, x):
+            return [torch.zeros(x.shape[0], 8, 8 >> i, 8 >> i) for i in range(4)]
+
+    class Neck(nn.Module):
+        def forward(self, feats):
+            return [f[:, :4] for f in feats]
+
+    SEG = _Registry('segmentors')
+    builder = types.SimpleNamespace(build_backbone=lambda cfg: Backbone(), build_neck=lambda cfg: Neck(),
+                                    build_head=lambda cfg: Rec(cfg['stage']))
+    sys.modules['mmseg.models'].SEGMENTORS = SEG
+    sys.modules['mmseg.models'].builder = builder
+    sys.modules['mmseg.models'].build_backbone = builder.build_backbone
+    _mod('mmdet3d'); _mod('mmdet3d.registry', MODELS=REG)
+    namespace('model.segmentor')
+    ref_import('model.segmentor.base_segmentor')
+    seg_mod = ref_import('model.segmentor.tpv_segmentor')
+    seg = seg_mod.TPVSegmentor(img_backbone=dict(type='B'), img_neck=dict(type='N'), lifter=dict(stage='lifter'),
+                               encoder=dict(stage='encoder'), head=dict(stage='head'), img_backbone_out_indices=[1, 2, 3])
+    imgs = torch.zeros(1, 2, 3, 16, 16)
+    metas = [dict(flip=False)]
+    protocol = {}
+    for mode, kw in (('train', dict(global_iter=7)), ('prepare', dict(prepare=True)), ('occ_only', dict(occ_only=True, aabb=[0] * 6, resolution=0.4))):
+        calls.clear()
+        res = seg(imgs=imgs, metas=metas, points=None, **kw)
+        protocol[mode] = dict(calls=list(calls), result_keys=sorted(res))
+    with open(os.path.join(HERE, 'segmentor_protocol.json'), 'w') as f:
+        json.dump(protocol, f, indent=1)
+    print("wrote segmentor_protocol.json:", {m: [(c['stage'], c['method']) for c in v['calls']] for m, v in protocol.items()})
+
+
 def golden_encoder(REG):
     for p in ('model', 'model.encoder', 'model.encoder.bevformer', 'model.encoder.bevformer.attention',
               'model.encoder.tpvformer', 'model.encoder.tpvformer.attention', 'model.encoder.tpvformer.modules',
@@ -490,3 +550,4 @@ if __name__ == '__main__':
     golden_losses(LOSS_REG)
     golden_more(LOSS_REG)
     golden_encoder(REG)
+    golden_segmentor(REG)

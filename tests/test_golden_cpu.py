@@ -252,3 +252,23 @@ def test_sdf_field_volume_vs_reference_bevnerf(tag):
 def test_openseed2nuscenes_lut_vs_reference():
     from selfocc_amd.occ import OPENSEED2NUSCENES
     assert OPENSEED2NUSCENES == mor['iou.openseed2nuscenes'].tolist()
+
+
+def test_our_stages_bind_the_reference_segmentor_keywords():
+    """Every keyword set the reference's TPVSegmentor passes to lifter / encoder / head (recorded from the real class
+    into segmentor_protocol.json) binds to the corresponding method signature of OUR classes — the CPU half of the
+    drop-in check (the GPU half replays the calls with tensors)."""
+    import inspect
+    import selfocc_amd.model  # noqa: F401
+    from selfocc_amd.registry import MODELS, HEADS
+    proto = json.load(open(os.path.join(G, "segmentor_protocol.json")))
+    cls = dict(lifter=[MODELS.get('TPVQueryLifter'), MODELS.get('BEVQueryLifter')],
+               encoder=[MODELS.get('TPVFormerEncoder'), MODELS.get('BEVFormerEncoder')], head=[HEADS.get('NeuSHead')])
+    assert set(proto) == {'train', 'prepare', 'occ_only'}
+    for mode, rec in proto.items():
+        assert [c['stage'] for c in rec['calls']] == ['lifter', 'encoder', 'head']
+        for call in rec['calls']:
+            for c in cls[call['stage']]:
+                assert c is not None
+                sig = inspect.signature(getattr(c, call['method']))
+                sig.bind(None, **{k: None for k in call['kwargs']})     # raises TypeError if a keyword does not bind
