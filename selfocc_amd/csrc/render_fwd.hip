@@ -301,6 +301,14 @@ SO_DEVFN AxisK so_axis_affine(const so_axis &A) {
 
 SO_DEVFN float so_fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 SO_DEVFN float so_fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+// wave-wide AND of a per-lane predicate: one v_cmp + one scalar compare (HIP's __all() goes through a select)
+SO_DEVFN bool so_all(bool p) { return __builtin_amdgcn_ballot_w64(p) == __builtin_amdgcn_ballot_w64(true); }
+// (h * W + w) * D + d for in-range cells with full-rate 24-bit multiplies (v_mad_u32_u24); the 32-bit / 64-bit
+// integer multiplies the compiler picks for plain ints are quarter rate.  Needs H * W < 2^24, D < 2^24.
+SO_DEVFN unsigned so_cell_index(int h0, int w0, int d0, int W, int D) {
+    const unsigned hw = __umul24((unsigned)h0, (unsigned)W) + (unsigned)w0;
+    return __umul24(hw, (unsigned)D) + (unsigned)d0;
+}
 SO_DEVFN int so_floor_i(float x) {   // (int)floorf(x) in one instruction
     int r;
     asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
@@ -597,8 +605,8 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, GeomFn geom, bool 
         // 4 uniform (SGPR) offsets of a buffer resource; otherwise zero padding: clamp + select
         const bool interior = ((unsigned)h0 < (unsigned)(H - 1)) & ((unsigned)w0 < (unsigned)(W - 1)) &
                               ((unsigned)d0 < (unsigned)(D - 1));
-        st.all_interior = __all(interior);
-        st.cell = (unsigned)((h0 * W + w0) * D + d0);
+        st.all_interior = so_all(interior);
+        st.cell = so_cell_index(h0, w0, d0, W, D);     // only used when every lane is interior
         st.code = 0u;
         if (st.all_interior) {
             if (use_brick) {   // 8 corners = one 32-B record: 2 wide loads instead of 4 gathers
@@ -652,7 +660,7 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, GeomFn geom, bool 
         const float *v = st.v;
         float w, sdf = 0.0f, gvw = 0.0f, gvd = 0.0f, gvh = 0.0f;
         bool skip = false;
-        if constexpr (CAN_SKIP) skip = __all((int)st.code >= rcode);   // every lane in saturated free space
+        if constexpr (CAN_SKIP) skip = so_all((int)st.code >= rcode);   // every lane in saturated free space
         if (skip) {
             w = kAlphaFree * T;
             T = T * ((1.0f - kAlphaFree) + 1e-7f);
@@ -761,18 +769,18 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, GeomFn geom, bool 
             if (i + 1 < S) fetch(i + 1, B);
             consume(i, A);
             if (++i >= S) break;
-            if constexpr (!PER_SAMPLE) { if (__all(T < 1e-10f)) break; }
+            if constexpr (!PER_SAMPLE) { if (so_all(T < 1e-10f)) break; }
             if (i + 1 < S) fetch(i + 1, A);
             consume(i, B);
             if (++i >= S) break;
-            if constexpr (!PER_SAMPLE) { if (__all(T < 1e-10f)) break; }
+            if constexpr (!PER_SAMPLE) { if (so_all(T < 1e-10f)) break; }
         }
     } else {
         for (int i = 0; i < S; ++i) {
             FastStep<NF> A;
             fetch(i, A);
             consume(i, A);
-            if constexpr (!PER_SAMPLE) { if (__all(T < 1e-10f)) break; }
+            if constexpr (!PER_SAMPLE) { if (so_all(T < 1e-10f)) break; }
         }
     }
 
@@ -926,7 +934,8 @@ int dispatch_ps(const so_render_args &a, hipStream_t st) {
     bool per_sample = a.weights || a.ts || a.deltas || a.sdf || a.grad;
     // the fast path needs g(t) affine in t: no jitter, single-segment axes
     bool fast = !(a.flags & SO_FLAG_EXACT) && a.jitter_mode == SO_JITTER_NONE &&
-                a.map.h.size1 == 0.0f && a.map.w.size1 == 0.0f && a.map.d.size1 == 0.0f;
+                a.map.h.size1 == 0.0f && a.map.w.size1 == 0.0f && a.map.d.size1 == 0.0f &&
+                (long long)a.map.h.tot_len * a.map.w.tot_len < (1 << 24) && a.map.d.tot_len < (1 << 24);   // so_cell_index
     if (fast) {
         if (a.sdf_brick) {
             const int cells = a.map.h.tot_len * a.map.w.tot_len * a.map.d.tot_len;
