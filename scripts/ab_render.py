@@ -11,7 +11,9 @@ chans = [int(c) for c in sys.argv[1:]] or [1, 4, 25]
 rays = sy.make_rays("cfg2")
 rg = RaySet(img2lidar=rays.img2lidar.to(d), nx=rays.nx, ny=rays.ny, sx=rays.sx, sy=rays.sy)
 VARIANTS = {"default": {}, "no_skip": dict(skip=False), "no_face_safe": dict(face_safe=False),
-            "no_skip_no_face_safe": dict(skip=False, face_safe=False), "inv_s_200": dict(inv_s=200.0)}
+            "no_skip_no_face_safe": dict(skip=False, face_safe=False), "inv_s_200": dict(inv_s=200.0),
+            "no_ahead": dict(ahead=False), "no_ahead_no_face_safe": dict(ahead=False, face_safe=False),
+            "no_ahead_inv_s_200": dict(ahead=False, inv_s=200.0)}
 for c in chans:
     nr, ns = {1: (0, 0), 4: (3, 0), 25: (3, 21)}[c]
     vol = sy.make_volume("cfg2", n_rgb=nr, n_sem=ns).to(d)

@@ -816,10 +816,165 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, GeomFn geom, bool 
     }
 }
 
-// MODE: 0 = canonical (EXACT), 1 = fast, 2 = fast with canonical cell selection near voxel faces
+// ---------------------------------------------------------------------------------------
+// SDF-only per-ray launches with free-space skipping (the depth-evaluation path, bench.py).
+// PMC of the general march on this workload: the vector-L1 path is the limiter (TA address FIFO full, waves
+// parked in s_waitcnt), not the vector ALU — and a skipped step still fetched its 32-byte corner record,
+// because the skip code arrived together with it.  Here the skip code runs ONE step ahead of the records:
+//     per step i:  decide skip(i) from code(i) (already here)
+//                  position of step i + 1, issue its 1-byte code load
+//                  only if not skipping: the two 16-byte record loads of step i, then interpolate + alpha
+//                  composite
+// A skipped step moves 1 byte per lane through the L1 instead of 33.  Nothing is software-pipelined beyond
+// that: measurements showed the march insensitive to load/compute overlap inside a wave (8 waves / SIMD hide it).
+// ---------------------------------------------------------------------------------------
+struct AheadStep {
+    float fh, fw, fd, fi;
+    int h0, w0, d0;
+    unsigned cell, code;
+    bool all_interior;            // wave-uniform
+};
+
+template <bool FACE_SAFE, class GeomFn>
+SO_DEVFN void so_march_fast_ahead(const so_render_args &a, int ray, GeomFn geom) {
+    const int H = a.map.h.tot_len, W = a.map.w.tot_len, D = a.map.d.tot_len;
+    const int S = a.n_samples;
+    const RayGeom g = geom(a);
+    float tnear, tfar;
+    so_collide(a, g, tnear, tfar);
+    const float dt = (tfar - tnear) / (float)S;
+    const float inv_dn = 1.0f / g.dn;
+    const AxisK kh = so_axis_affine(a.map.h), kw = so_axis_affine(a.map.w), kd = so_axis_affine(a.map.d);
+    const float t_off = (a.sample_pos == SO_SAMPLE_AT_START) ? tnear : tnear + 0.5f * dt;
+    const float Gdh = g.dy * kh.k1, Gdw = g.dx * kw.k1, Gdd = g.dz * kd.k1;
+    const float G0h = fmaf(g.oy, kh.k1, kh.k0) + Gdh * t_off;
+    const float G0w = fmaf(g.ox, kw.k1, kw.k0) + Gdw * t_off;
+    const float G0d = fmaf(g.oz, kd.k1, kd.k0) + Gdd * t_off;
+    const float s2 = a.inv_s * 1.44269504088896341f;
+    const float hdt = 0.5f * dt, hdt_s2 = hdt * s2;
+    const float *__restrict__ vol = a.sdf_vol;
+    const unsigned n_cells = (unsigned)(H * W * D);
+    const __amdgpu_buffer_rsrc_t rb = so_make_rsrc(a.sdf_brick, (size_t)n_cells * 33);
+    const int rcode = max((int)ceilf(dt / so_skip_unit(a.aabb, S)), 1);
+    const int maxdim = max(H, max(W, D));
+    const float face_m = 3.0f * 1.1920929e-7f * (float)(1u << (32 - __builtin_clz((unsigned)maxdim)));
+
+    float T = 1.0f, acc = 0.0f, dsum = 0.0f, best_w = -1.0f, best_t = 0.0f;
+
+    auto locate = [&](const int i, AheadStep &st) __attribute__((always_inline)) {
+        st.fi = (float)i;
+        const float step = st.fi * dt;
+        const float gh = fmaf(Gdh, step, G0h), gw = fmaf(Gdw, step, G0w), gd = fmaf(Gdd, step, G0d);
+        st.fh = __builtin_amdgcn_fractf(gh); st.fw = __builtin_amdgcn_fractf(gw); st.fd = __builtin_amdgcn_fractf(gd);
+        const int h0 = so_floor_i(gh), w0 = so_floor_i(gw), d0 = so_floor_i(gd);
+        st.h0 = h0; st.w0 = w0; st.d0 = d0;
+        const bool interior = ((unsigned)h0 < (unsigned)(H - 1)) & ((unsigned)w0 < (unsigned)(W - 1)) &
+                              ((unsigned)d0 < (unsigned)(D - 1));
+        st.all_interior = so_all(interior);
+        st.cell = so_cell_index(h0, w0, d0, W, D);
+        st.code = 0u;
+        if (st.all_interior) st.code = __builtin_amdgcn_raw_buffer_load_b8(rb, st.cell, n_cells * 32u, 0);
+    };
+    auto near_face = [&](float fh, float fw, float fd) __attribute__((always_inline)) {
+        return fmaxf(fmaxf(fabsf(fh - 0.5f), fabsf(fw - 0.5f)), fabsf(fd - 0.5f)) > 0.5f - face_m;
+    };
+    auto canon_cell = [&](const int i) __attribute__((always_inline)) {   // see so_march_fast
+        const float b0 = so_bin(i, S);
+        const float t_start = b0 * tfar + (1.0f - b0) * tnear;
+        float px, py, pz;
+        if (a.sample_pos == SO_SAMPLE_AT_START) {
+            px = g.ox + g.dx * t_start; py = g.oy + g.dy * t_start; pz = g.oz + g.dz * t_start;
+        } else {
+            const float b1 = so_bin(i + 1, S);
+            const float tt = t_start + (b1 * tfar + (1.0f - b1) * tnear);
+            px = g.ox + (g.dx * tt) / 2.0f; py = g.oy + (g.dy * tt) / 2.0f; pz = g.oz + (g.dz * tt) / 2.0f;
+        }
+        return so_locate(a.map, px, py, pz);
+    };
+
+    auto step = [&](const int i, AheadStep &cur, AheadStep &nxt) __attribute__((always_inline)) {
+        const bool skip = cur.all_interior && so_all((int)cur.code >= rcode);
+        if (i + 1 < S) locate(i + 1, nxt);
+        float w;
+        if (skip) {
+            w = kAlphaFree * T;
+            T = T * ((1.0f - kAlphaFree) + 1e-7f);
+        } else {
+            // (issuing these loads before locate() above, to run it under them, measured 9 % SLOWER)
+            float v[8];
+            float fh = cur.fh, fw = cur.fw, fd = cur.fd;
+            if (cur.all_interior) {
+                const so_f4v lo = so_bload4(rb, cur.cell * 32u, 0u), hi = so_bload4(rb, cur.cell * 32u + 16u, 0u);
+                v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+            } else {
+                so_cell c;
+                c.h0 = cur.h0; c.w0 = cur.w0; c.d0 = cur.d0;
+                so_gather_sdf(vol, H, W, D, c, v);
+            }
+            if constexpr (FACE_SAFE) {
+                if (__any(near_face(fh, fw, fd))) {
+                    if (near_face(fh, fw, fd)) {
+                        const so_cell c = canon_cell(i);
+                        if (c.h0 != cur.h0 || c.w0 != cur.w0 || c.d0 != cur.d0) {   // the canonical order lands next door
+                            so_gather_sdf(vol, H, W, D, c, v);
+                            fh = c.fh1; fw = c.fw1; fd = c.fd1;
+                        }
+                    }
+                }
+            }
+            const float dd0 = v[1] - v[0], dd1 = v[3] - v[2], dd2 = v[5] - v[4], dd3 = v[7] - v[6];
+            const float c0 = fmaf(fd, dd0, v[0]), c1 = fmaf(fd, dd1, v[2]);
+            const float c2 = fmaf(fd, dd2, v[4]), c3 = fmaf(fd, dd3, v[6]);
+            const float dw0 = c1 - c0, dw1 = c3 - c2;
+            const float b0 = fmaf(fw, dw0, c0), b1 = fmaf(fw, dw1, c2);
+            const float dh0 = b1 - b0;
+            const float sdf = fmaf(fh, dh0, b0);
+            const float gvw = fmaf(fh, dw1 - dw0, dw0);
+            const float e0 = fmaf(fw, dd1 - dd0, dd0), e1 = fmaf(fw, dd3 - dd2, dd2);
+            const float gvd = fmaf(fh, e1 - e0, e0);
+            const float cosv = fmaf(gvd, Gdd, fmaf(gvw, Gdw, dh0 * Gdh));
+            const float alpha = so_alpha_fast(sdf * s2, fminf(cosv, 0.0f) * hdt_s2);
+            w = alpha * T;
+            T = T * ((1.0f - alpha) + 1e-7f);
+        }
+        const float t_mid = fmaf(cur.fi, dt, tnear + hdt);
+        acc = acc + w;
+        dsum = fmaf(w, t_mid, dsum);
+        if (w > best_w) { best_w = w; best_t = t_mid; }
+    };
+
+    {
+        AheadStep A, B;
+        locate(0, A);
+        for (int i = 0;;) {
+            step(i, A, B);
+            if (++i >= S) break;
+            if (so_all(T < 1e-10f)) break;
+            step(i, B, A);
+            if (++i >= S) break;
+            if (so_all(T < 1e-10f)) break;
+        }
+    }
+
+    const float eps32 = 1.1920928955078125e-07f;
+    if (dt * inv_dn < eps32) best_t = tnear + hdt;
+    float depth = dsum * so_fast_rcp(acc + 1e-10f);
+    if (a.flags & SO_FLAG_DEPTH_DIV_NORM) depth = depth * inv_dn;
+    if (a.depth) a.depth[ray] = depth;
+    if (a.acc) a.acc[ray] = acc;
+    if (a.max_depth) a.max_depth[ray] = best_t * inv_dn;
+    if (a.nears) a.nears[ray] = tnear;
+    if (a.fars) a.fars[ray] = tfar;
+}
+
+// MODE: 0 = canonical (EXACT), 1 = fast, 2 = fast with canonical cell selection near voxel faces,
+//       3 / 4 = the code-ahead skip marcher (SDF-only per-ray launches with brick + skip) without / with it
 template <int NF, bool BF16, bool PER_SAMPLE, int MODE, class GeomFn>
 SO_DEVFN void so_march(const so_render_args &a, int ray, GeomFn geom) {
-    if constexpr (MODE != 0) {
+    if constexpr (MODE >= 3) {
+        static_assert(NF == 0 && !PER_SAMPLE, "skip marcher: SDF-only per-ray launches");
+        so_march_fast_ahead<MODE == 4>(a, ray, geom);
+    } else if constexpr (MODE != 0) {
         so_march_fast<NF, BF16, PER_SAMPLE, false, MODE == 2>(a, ray, geom);
     } else {
         so_march_exact<NF, BF16, PER_SAMPLE>(a, ray, geom(a));
@@ -896,7 +1051,7 @@ __global__ __launch_bounds__(256, (NF >= 8 ? SO_WAVES_FEAT : 1)) void render_fwd
     int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int ix = tx * 16 + (wave & 1) * 8 + (lane & 7);
     int iy = ty * 16 + (wave >> 1) * 8 + (lane >> 3);
-    constexpr bool STAGED = MODE != 0 && !PER_SAMPLE && !BF16 && NF >= 4;
+    constexpr bool STAGED = MODE != 0 && MODE < 3 && !PER_SAMPLE && !BF16 && NF >= 4;
     if constexpr (STAGED) {
         // every lane keeps marching (the LDS staging is a whole-wave operation): lanes beyond the
         // lattice edge shadow the nearest real pixel and only skip the final store
@@ -942,6 +1097,10 @@ int dispatch_ps(const so_render_args &a, hipStream_t st) {
             const int with_codes = (NF == 0 && !per_sample && !(a.flags & SO_FLAG_NO_SKIP)) ? 1 : 0;
             hipLaunchKernelGGL(sdf_brickify_kernel, dim3((cells + 255) / 256), dim3(256), 0, st, a.sdf_vol, a.sdf_brick,
                                a.map.h.tot_len, a.map.w.tot_len, a.map.d.tot_len, a, with_codes);
+        }
+        if constexpr (NF == 0) {
+            if (!per_sample && a.sdf_brick && !(a.flags & (SO_FLAG_NO_SKIP | SO_FLAG_NO_AHEAD)))
+                return (a.flags & SO_FLAG_NO_FACE_SAFE) ? launch_fwd<0, false, false, 3>(a, st) : launch_fwd<0, false, false, 4>(a, st);
         }
         if (!(a.flags & SO_FLAG_NO_FACE_SAFE))
             return per_sample ? launch_fwd<NF, BF16, true, 2>(a, st) : launch_fwd<NF, BF16, false, 2>(a, st);
