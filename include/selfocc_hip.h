@@ -83,6 +83,8 @@ enum {
                                    section 4 / tests/test_render_gpu.py (whole benchmarked frame:
                                    depth within 1e-4 relative on every ray that accumulates > 0.05). */
     SO_FLAG_NO_SKIP = 8,        /* fast path: do not skip saturated free-space samples (A/B switch) */
+    SO_FLAG_RAY_PER_LANE = 64,  /* per-sample launches through the ray-per-lane kernels instead of the sample-parallel
+                                   training kernel (A/B switch; same results to float rounding)     */
     SO_FLAG_NO_AHEAD = 32,      /* fast path: general march even where the code-ahead skip marcher applies (A/B) */
     SO_FLAG_NO_FACE_SAFE = 16   /* fast path: never re-derive cells near voxel faces: ~6 % faster on
                                    the SDF-only kernel, but ~1e-4 of the rays (those with a sample

@@ -13,7 +13,7 @@ RAYS_EXPLICIT, RAYS_PIXEL_GRID = 0, 1
 SAMPLE_AT_START, SAMPLE_AT_MID = 0, 1
 BKGD_NONE, BKGD_CONST, BKGD_PER_RAY = 0, 1, 2
 JITTER_NONE, JITTER_SINGLE, JITTER_PER_BIN = 0, 1, 2
-FLAG_DEPTH_DIV_NORM, FLAG_CLAMP_RGB, FLAG_EXACT, FLAG_NO_SKIP, FLAG_NO_FACE_SAFE, FLAG_NO_AHEAD = 1, 2, 4, 8, 16, 32
+FLAG_DEPTH_DIV_NORM, FLAG_CLAMP_RGB, FLAG_EXACT, FLAG_NO_SKIP, FLAG_NO_FACE_SAFE, FLAG_NO_AHEAD, FLAG_RAY_PER_LANE = 1, 2, 4, 8, 16, 32, 64
 DTYPE_F32, DTYPE_BF16 = 0, 1
 
 _f, _i, _p = C.c_float, C.c_int32, C.c_void_p

@@ -93,6 +93,22 @@ SO_DEVFN void so_split_group(long long gq, long long n_groups, int nq, int heads
     }
 }
 
+// XCD-aware block order.  Workgroup b is observed to run on XCD b % 8, each XCD with its own 4 MB L2.  With the
+// plain order consecutive queries — which sample neighbouring pixels — are dealt round-robin to the 8 XCDs, so every
+// L2 sees the whole 10-60 MB value map; here XCD x works on ONE contiguous eighth of the (query, head) groups and
+// its L2 only has to hold the pixels that eighth looks at.  A bijection of [0, gridDim.x) for any grid size; the
+// mapping affects speed only (placement is not guaranteed by HIP).
+SO_DEVFN unsigned so_xcd_block() {
+#ifdef SO_MSDA_NO_XCD_SWIZZLE
+    return blockIdx.x;
+#else
+    const unsigned nb = gridDim.x, b = blockIdx.x;
+    const unsigned x = b & 7u, k = b >> 3;
+    const unsigned q = nb >> 3, r = nb & 7u;
+    return x * q + (x < r ? x : r) + k;
+#endif
+}
+
 // ---------------------------------------------------------------------------------------
 // forward building blocks.
 //
@@ -240,7 +256,7 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const float *__restrict__
     const int LP = dm.L * dm.P;
     const int groups_per_block = 256 / G;
     const long long n_groups = (long long)dm.bs * dm.nq * dm.heads;
-    const long long gid = (long long)blockIdx.x * groups_per_block + (threadIdx.x / G);
+    const long long gid = (long long)so_xcd_block() * groups_per_block + (threadIdx.x / G);
     const int gl = threadIdx.x & (G - 1);
     const bool live = gid < n_groups;  // whole groups are live or dead; exchanges stay in-group
     const long long gq = live ? gid : 0;
@@ -292,7 +308,7 @@ __global__ __launch_bounds__(256) void msda_fused_fwd_kernel(const float *__rest
     const int LP = dm.L * dm.P;
     const int groups_per_block = 256 / G;
     const long long n_groups = (long long)dm.bs * dm.nq * dm.heads;
-    const long long gid = (long long)blockIdx.x * groups_per_block + (threadIdx.x / G);
+    const long long gid = (long long)so_xcd_block() * groups_per_block + (threadIdx.x / G);
     const int gl = threadIdx.x & (G - 1);
     const bool live = gid < n_groups;
     const long long gq = live ? gid : 0;
@@ -380,7 +396,7 @@ __global__ __launch_bounds__(256) void msda_cross_fwd_kernel(const float *__rest
     const int LP = dm.L * dm.P;
     const int groups_per_block = 256 / G;
     const int n_groups = dm.nq * dm.heads;                       // < 2^31 (validated)
-    const int gid = blockIdx.x * groups_per_block + (threadIdx.x / G);
+    const int gid = (int)so_xcd_block() * groups_per_block + (threadIdx.x / G);
     const int gl = threadIdx.x & (G - 1);
     const bool live = gid < n_groups;
     const int gq = live ? gid : 0;
@@ -467,7 +483,7 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(const float *__restrict__
                                                        float *__restrict__ g_attw, MsdaDims dm) {
     const int LP = dm.L * dm.P;
     const long long n_pts = (long long)dm.bs * dm.nq * dm.heads * LP;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long idx = (long long)so_xcd_block() * blockDim.x + threadIdx.x;
     const bool live = idx < n_pts;
     const long long idc = live ? idx : n_pts - 1;
     long long gq;
@@ -632,7 +648,7 @@ __global__ __launch_bounds__(256) void msda_bwd_point_kernel(const float *__rest
     constexpr int QL = D / 4;
     const int LP = dm.L * dm.P;
     const long long n_pts = (long long)dm.bs * dm.nq * dm.heads * LP;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long idx = (long long)so_xcd_block() * blockDim.x + threadIdx.x;
     const bool live = idx < n_pts;
     const long long idc = live ? idx : n_pts - 1;
     long long gq;
@@ -744,7 +760,7 @@ __global__ __launch_bounds__(256) void msda_fused_bwd_point_kernel(const float *
     const int LP = dm.L * dm.P;
     const int groups_per_block = 256 / G;
     const long long n_groups = (long long)dm.bs * dm.nq * dm.heads;
-    const long long gid = (long long)blockIdx.x * groups_per_block + (threadIdx.x / G);
+    const long long gid = (long long)so_xcd_block() * groups_per_block + (threadIdx.x / G);
     const int gl = threadIdx.x & (G - 1);
     const bool live = gid < n_groups;
     const long long gq = live ? gid : 0;
@@ -868,7 +884,7 @@ __global__ __launch_bounds__(256) void msda_cross_bwd_point_kernel(const float *
     const int LP = dm.L * dm.P;
     const int groups_per_block = 256 / G;
     const int n_groups = dm.nq * dm.heads;
-    const int gid = blockIdx.x * groups_per_block + (threadIdx.x / G);
+    const int gid = (int)so_xcd_block() * groups_per_block + (threadIdx.x / G);
     const int gl = threadIdx.x & (G - 1);
     const bool live = gid < n_groups;
     const int gq = live ? gid : 0;

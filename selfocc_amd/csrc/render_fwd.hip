@@ -22,6 +22,10 @@ extern "C" int selfocc_debug_stage_stats(unsigned long long *out) {
 }
 #endif
 
+// render_train.hip
+template <int NF, bool BF16>
+int so_render_fwd_samples(const so_render_args &a, hipStream_t st);
+
 namespace {
 
 struct RayGeom {
@@ -1087,6 +1091,8 @@ int launch_fwd(const so_render_args &a, hipStream_t st) {
 template <int NF, bool BF16>
 int dispatch_ps(const so_render_args &a, hipStream_t st) {
     bool per_sample = a.weights || a.ts || a.deltas || a.sdf || a.grad;
+    // training API: the sample-parallel kernel of render_train.hip (a lane per sample, canonical arithmetic)
+    if (per_sample && !(a.flags & SO_FLAG_RAY_PER_LANE)) return so_render_fwd_samples<NF, BF16>(a, st);
     // the fast path needs g(t) affine in t: no jitter, single-segment axes
     bool fast = !(a.flags & SO_FLAG_EXACT) && a.jitter_mode == SO_JITTER_NONE &&
                 a.map.h.size1 == 0.0f && a.map.w.size1 == 0.0f && a.map.d.size1 == 0.0f &&

@@ -118,6 +118,7 @@ class RenderConfig:
     skip: bool = True                 # fast path + brick: composite saturated free-space samples without interpolating
     face_safe: bool = True            # fast path: canonical cell selection within a few ulp of a voxel face (~6 % slower)
     ahead: bool = True                # SDF-only per-ray launches with brick + skip: code-ahead skip marcher (A/B)
+    ray_per_lane: bool = False        # per-sample launches through the ray-per-lane kernels (A/B; default: sample-parallel)
 
 
 def _c(t, dtype=torch.float32):
@@ -174,7 +175,8 @@ def marshal_render_args(vol: SDFVolume, rays: RaySet, cfg: RenderConfig, *, per_
         a.bkgd_rays = ptr(_c(bkgd_rays))
     a.flags = (abi.FLAG_DEPTH_DIV_NORM if cfg.depth_div_norm else 0) | (abi.FLAG_CLAMP_RGB if cfg.clamp_rgb else 0) | \
         (abi.FLAG_EXACT if cfg.exact else 0) | (0 if cfg.skip else abi.FLAG_NO_SKIP) | \
-        (0 if cfg.face_safe else abi.FLAG_NO_FACE_SAFE) | (0 if cfg.ahead else abi.FLAG_NO_AHEAD)
+        (0 if cfg.face_safe else abi.FLAG_NO_FACE_SAFE) | (0 if cfg.ahead else abi.FLAG_NO_AHEAD) | \
+        (abi.FLAG_RAY_PER_LANE if cfg.ray_per_lane else 0)
 
     f32 = dict(dtype=torch.float32, device=dev)
     out = outputs if outputs is not None else {}

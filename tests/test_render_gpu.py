@@ -116,13 +116,24 @@ def test_cfg1_pixel_grid_vs_oracle(hip, n_rgb, n_sem, feat_dtype, sample_pos, ex
     got = render_rays(vol.to(d), RaySet(img2lidar=rays.img2lidar.to(d), nx=rays.nx, ny=rays.ny, sx=rays.sx,
                                         sy=rays.sy), cfg, per_sample=True, want_grad_samples=True)
     torch.cuda.synchronize()
+    # per-sample launches run the sample-parallel training kernel (render_train.hip): canonical arithmetic per
+    # sample whatever the mode, so the interpolated SDF / sample positions are bit-exact
+    assert torch.equal(got['sdf'].cpu(), ref['sdf'])
+    assert torch.equal(got['ts'].cpu(), ref['ts'])
+    _cmp(got, ref)
+    # the same launch without per-sample outputs: the ray-per-lane kernels of the requested mode
+    rg = RaySet(img2lidar=rays.img2lidar.to(d), nx=rays.nx, ny=rays.ny, sx=rays.sx, sy=rays.sy)
+    per_ray = [k for k in ref if ref[k].dim() == 1 or k in ('rgb', 'sem')]
+    got_e = render_rays(vol.to(d), rg, cfg)
     if exact is True:
-        # the SDF lookup is pure IEEE mul/add in a fixed order: bit-exact
-        assert torch.equal(got['sdf'].cpu(), ref['sdf'])
-        assert torch.equal(got['ts'].cpu(), ref['ts'])
-        _cmp(got, ref)
+        _cmp(got_e, ref, keys=[k for k in per_ray if k in got_e])
     else:
-        _cmp_fast(got, ref, vol, rays, cfg, same_cells=(exact is False))
+        loose = {} if exact is False else dict(max_rel=1.0, acc_abs=1.0, depth_abs_over_far=1.0)
+        parity_report(got_e, ref, label=f"cfg1 eval launch {exact}", **loose)
+        # A/B switch: per-sample outputs through the ray-per-lane kernels of this mode
+        from dataclasses import replace
+        got_l = render_rays(vol.to(d), rg, replace(cfg, ray_per_lane=True), per_sample=True, want_grad_samples=True)
+        _cmp_fast(got_l, ref, vol, rays, cfg, same_cells=(exact is False))
 
 
 def test_explicit_rays_and_jitter(hip):
@@ -308,11 +319,14 @@ def test_rays_entering_from_outside_the_box(hip, exact, n_rgb, n_sem):
         rel = (g['depth'] - ref['depth']).abs() / ref['depth'].abs().clamp_min(1e-6)
         assert (rel[ok] < 1e-4).float().mean() > 0.995
         assert (g['acc'] - ref['acc']).abs().max() < 0.5 and torch.isfinite(g['depth']).all()
-    # eval-mode launch (no per-sample outputs: early termination + LDS staging active) must give
-    # the same per-ray results as the per-sample launch of the same mode
+    # eval-mode launch (no per-sample outputs: the ray-per-lane kernels with early termination, LDS staging, brick
+    # and skip where they apply; the per-sample launch above ran the sample-parallel training kernel)
     got2 = render_rays(vol.to(d), rg, cfg)
-    for k in got2:
-        assert torch.allclose(got2[k], got[k], rtol=1e-5, atol=1e-6), k
+    if exact is True:
+        for k in got2:      # both canonical: only the summation order differs
+            assert torch.allclose(got2[k], got[k], rtol=1e-5, atol=1e-6), k
+    elif exact is False:
+        parity_report(got2, ref, label="cfg1-entering eval launch")
 
 
 def test_two_segment_mapping_takes_canonical_path(hip):
