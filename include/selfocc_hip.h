@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SELFOCC_ABI_VERSION 14
+#define SELFOCC_ABI_VERSION 16
 
 int selfocc_abi_version(void);
 const char *selfocc_last_error(void);
@@ -208,11 +208,13 @@ int selfocc_msda_fused_fwd(const float *value, const int32_t *shapes, const int3
  *   out[q] = sum_{cam: vis[cam][q]} msda(value[cam], ref[cam][q] + off[q] / (W_l, H_l), softmax(logits[q]))
  *            / max(#visible cams, 1)
  *   value (cams,nv,heads,d)  ref (cams,nq,P,2)  vis (cams,nq) u8  off_raw (nq,heads,L,P,2)
- *   logits (nq,heads,L*P)  out (nq,heads*d)            batch size 1 (as the reference's masks), L*P <= 256 */
+ *   logits (nq,heads,L*P)  out (nq,heads*d)            batch size 1 (as the reference's masks), L*P <= 256
+ * value_stride: floats between consecutive pixels of `value` (0 = dense, heads*d): lets `value` be a column block
+ * of a wider matrix, e.g. the three TPV planes' value projections computed by ONE GEMM with N = 3 * heads * d. */
 int selfocc_msda_cross_fwd(const float *value, const int32_t *shapes, const int32_t *starts,
                            const float *ref, const uint8_t *vis, const float *off_raw, const float *logits,
                            float *out, int32_t cams, int32_t nv, int32_t nq, int32_t heads, int32_t d,
-                           int32_t L, int32_t P, void *stream);
+                           int32_t L, int32_t P, int32_t value_stride, void *stream);
 
 /* Training counterpart of selfocc_msda_cross_fwd: g_out (nq, heads*d) is the gradient of the camera MEAN;
  * returns g_value (cams,nv,heads,d; zero-initialised by the caller), g_off (nq,heads,L,P,2) and
@@ -362,6 +364,22 @@ int selfocc_ssim_fwd(const float *x, const float *y, const int64_t *x_strides, c
 int selfocc_ssim_bwd(const float *x, const float *y, const int64_t *x_strides, const int64_t *y_strides,
                      int32_t N, int32_t C, int32_t H, int32_t W, const float *g_out, float *g_x, float *g_y,
                      void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * LayerNorm over the last dimension of a contiguous (rows, C) float32 tensor — the `norm` steps of
+ * TPVFormerLayer / BEVFormerLayer (mmcv build_norm_layer(dict(type='LN')) in the reference:
+ * model/encoder/tpvformer/tpvformer_encoder_layer.py, bevformer_encoder_layer.py), biased variance,
+ * y = (x - mean) / sqrt(var + eps) * gamma + beta.  C a multiple of 4 in [4, 128].
+ * mean / rstd (rows) are optional outputs of the forward (both or neither) and inputs of the backward.
+ * The backward writes dx (rows, C), dgamma (C), dbeta (C) (overwritten, deterministic) and needs
+ * selfocc_layernorm_bwd_workspace(rows, C) bytes of device scratch.
+ * ---------------------------------------------------------------------------------- */
+int selfocc_layernorm_fwd(const float *x, const float *gamma, const float *beta, float *y, float *mean,
+                          float *rstd, int64_t rows, int32_t C, float eps, void *stream);
+size_t selfocc_layernorm_bwd_workspace(int64_t rows, int32_t C);
+int selfocc_layernorm_bwd(const float *x, const float *gamma, const float *mean, const float *rstd,
+                          const float *dy, float *dx, float *dgamma, float *dbeta, int64_t rows, int32_t C,
+                          void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Fused temporal reprojection photometric term.  Replaces the per-sample part of

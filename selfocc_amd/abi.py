@@ -6,7 +6,7 @@ its exported symbols being callable with these layouts.
 """
 import ctypes as C
 
-ABI_VERSION = 14
+ABI_VERSION = 16
 
 # enums ---------------------------------------------------------------------------
 RAYS_EXPLICIT, RAYS_PIXEL_GRID = 0, 1
@@ -104,7 +104,7 @@ SYMBOLS = {
     "selfocc_render_bwd": (C.c_int, [C.POINTER(SoRenderBwdArgs), _p]),
     "selfocc_msda_fwd": (C.c_int, [_p, _p, _p, _p, _p, _p] + [_i] * 7 + [_p]),
     "selfocc_msda_fused_fwd": (C.c_int, [_p, _p, _p, _p, _i, _p, _p, _p] + [_i] * 7 + [_p]),
-    "selfocc_msda_cross_fwd": (C.c_int, [_p] * 8 + [_i] * 7 + [_p]),
+    "selfocc_msda_cross_fwd": (C.c_int, [_p] * 8 + [_i] * 8 + [_p]),
     "selfocc_msda_cross_bwd": (C.c_int, [_p] * 12 + [_i] * 7 + [_p, C.c_size_t, _p]),
     "selfocc_msda_bwd": (C.c_int, [_p] * 9 + [_i] * 7 + [_p]),
     "selfocc_msda_banded_supported": (C.c_int, [_p] + [_i] * 6),
@@ -117,6 +117,9 @@ SYMBOLS = {
     "selfocc_field_volume_fwd": (C.c_int, [_p] * 3 + [_i] * 4 + [_p, _p, _i, _p, _p, _i, _p, _p, _i, _i, _p]),
     "selfocc_occ_resample": (C.c_int, [C.POINTER(SoOccArgs), _p]),
     "selfocc_iou_counts": (C.c_int, [_p, _p, _p, C.c_int64, _p, _i, _i, _p, _p]),
+    "selfocc_layernorm_fwd": (C.c_int, [_p] * 6 + [C.c_int64, _i, C.c_float, _p]),
+    "selfocc_layernorm_bwd_workspace": (C.c_size_t, [C.c_int64, _i]),
+    "selfocc_layernorm_bwd": (C.c_int, [_p] * 8 + [C.c_int64, _i, _p, C.c_size_t, _p]),
     "selfocc_ssim_fwd": (C.c_int, [_p] * 4 + [_i] * 4 + [_p, _p]),
     "selfocc_ssim_bwd": (C.c_int, [_p] * 4 + [_i] * 4 + [_p, _p, _p, _p]),
     "selfocc_reproj_fwd": (C.c_int, [C.POINTER(SoReprojArgs), _p]),

@@ -30,6 +30,7 @@ namespace {
 struct MsdaDims {
     int bs, nv, nq, heads, L, P;
     int go_shared;   // band kernel: g_out has one row per (query, head) shared by all batch items (camera loop)
+    int vs;          // camera-loop forward: floats between consecutive pixels of `value` (0 = dense: heads * D)
 };
 
 struct Bilin {
@@ -401,7 +402,7 @@ __global__ __launch_bounds__(256) void msda_cross_fwd_kernel(const float *__rest
     const bool live = gid < n_groups;
     const int gq = live ? gid : 0;
     const int q = gq / dm.heads, h = gq - q * dm.heads;
-    const int pix_stride = dm.heads * D;
+    const int pix_stride = dm.vs ? dm.vs : dm.heads * D;     // `value` may be a column block of a wider matrix
     const int s = gl & (QL - 1);
     const float *vb = value + h * D + 4 * s;
 
@@ -1339,8 +1340,13 @@ extern "C" int selfocc_msda_fused_fwd(const float *value, const int32_t *shapes,
 extern "C" int selfocc_msda_cross_fwd(const float *value, const int32_t *shapes, const int32_t *starts,
                                       const float *ref, const uint8_t *vis, const float *off_raw,
                                       const float *logits, float *out, int32_t cams, int32_t nv, int32_t nq,
-                                      int32_t heads, int32_t d, int32_t L, int32_t P, void *stream) {
+                                      int32_t heads, int32_t d, int32_t L, int32_t P, int32_t value_stride,
+                                      void *stream) {
     SO_REQUIRE(cams >= 1, "msda_cross_fwd: cams must be >= 1");
+    SO_REQUIRE(value_stride == 0 || (value_stride >= heads * d && value_stride % 4 == 0),
+               "msda_cross_fwd: value_stride must be 0 or a multiple of 4 >= heads * d");
+    SO_REQUIRE((long long)cams * nv * (value_stride ? value_stride : heads * d) < (1LL << 31),
+               "msda_cross_fwd: value must span < 2^31 floats");
     if (validate(value, shapes, starts, off_raw, logits, cams, nv, nq, heads, d, L, P)) return -1;
     const long long n_groups = (long long)nq * heads;
     if (n_groups == 0) return 0;
@@ -1354,7 +1360,7 @@ extern "C" int selfocc_msda_cross_fwd(const float *value, const int32_t *shapes,
     const int gpb = 256 / G;
     const long long blocks = (n_groups + gpb - 1) / gpb;
     SO_REQUIRE(blocks < (1LL << 31), "msda_cross_fwd: grid too large");
-    MsdaDims dm{1, nv, nq, heads, L, P, 0};
+    MsdaDims dm{1, nv, nq, heads, L, P, 0, value_stride};
     hipStream_t st = (hipStream_t)stream;
 #define SO_LAUNCH_G(DD, LG)                                                                             \
     hipLaunchKernelGGL((msda_cross_fwd_kernel<DD, LG>), dim3((unsigned)blocks), dim3(256), 0, st, value, \

@@ -127,7 +127,8 @@ class BEVCrossAttention(BaseModule):
                     host = False
             if host is not False:
                 return self._forward_camera_loop(query, value, residual, spatial_shapes, reference_points_cams,
-                                                 bev_masks, level_start_index, host)
+                                                 bev_masks, level_start_index, host, out=kwargs.get('out'),
+                                                 value_pre=kwargs.get('value_pre'))
         plan = kwargs.get('rebatch_plan')
         if plan is None:
             plan = self.rebatch_plan(bev_masks)
@@ -154,15 +155,18 @@ class BEVCrossAttention(BaseModule):
 
 
     def _forward_camera_loop(self, query, value, residual, spatial_shapes, reference_points_cams, bev_masks,
-                             level_start_index, host_shapes=None):
+                             level_start_index, host_shapes=None, out=None, value_pre=None):
         """No re-batch (inference: plain op; training: MSDACrossFunction under autograd).  The offset / weight linears depend on the query only, so they run once
         on the num_query rows; one HIP launch loops over the cameras that see each query and averages
         (selfocc_msda_cross_fwd) — same arithmetic as the re-batched path, camera order preserved."""
         da = self.deformable_attention
         num_cams, heads, L, P = self.num_cams, da.num_heads, da.num_levels, da.num_points
         _, l, _, _ = value.shape                                            # (cams, nv, bs, C)
-        v = da.value_proj(value.permute(2, 0, 1, 3).reshape(num_cams, l, self.embed_dims))
-        v = v.view(num_cams, l, heads, -1)
+        if value_pre is not None:      # this plane's column block of the merged value projection (TPVCrossAttention)
+            v = value_pre.view(num_cams, l, heads, -1)
+        else:
+            v = da.value_proj(value.permute(2, 0, 1, 3).reshape(num_cams, l, self.embed_dims))
+            v = v.view(num_cams, l, heads, -1)
         off = da.sampling_offsets(query[0]).view(-1, heads, L, P, 2)
         logits = da.attention_weights(query[0]).view(-1, heads, L * P)
         visible = bev_masks[:, 0].any(-1)                                   # (cams, Q), batch element 0 as the reference
@@ -173,6 +177,8 @@ class BEVCrossAttention(BaseModule):
             slots = MSDACrossFunction.apply(v, spatial_shapes, level_start_index, reference_points_cams[:, 0], visible,
                                             off, logits, host_shapes)[None]
         slots = self.output_proj(slots)
+        if out is not None and not self.training and not torch.is_grad_enabled():
+            return torch.add(slots, residual, out=out)      # eval: dropout is the identity; `out` = the caller's slice
         return self.dropout(slots) + residual
 
 
@@ -201,11 +207,35 @@ class TPVCrossAttention(BaseModule):
     def forward(self, query, key, value, residual=None, spatial_shapes=None, reference_points_cams=None,
                 tpv_masks=None, level_start_index=None, **kwargs):
         plans = kwargs.get('rebatch_plans') or [None] * 3
+        outs, vpre = [None] * 3, [None] * 3
+        if not torch.is_grad_enabled() and not self.training and query[0].shape[0] == 1:
+            # inference: the three planes' results land in consecutive slices of ONE buffer, so that the layer's next
+            # norm / ffn step sees the concatenated tensor without a copy (tpvformer.cat_planes)
+            sizes = [q.shape[1] for q in query]
+            buf = query[0].new_empty(1, sum(sizes), query[0].shape[-1])
+            outs = list(torch.split(buf, sizes, 1))
+            if value.is_cuda and all(a.camera_loop for a in self.attns):
+                # ... and the three planes' value projections of the SAME image features are one GEMM with N = 3 C
+                # (the 68 MB input is read once instead of three times); each plane's kernel reads its column block
+                # in place (selfocc_msda_cross_fwd value_stride)
+                C = self.embed_dims
+                w, b = self._merged_value_proj()
+                cams, l = value.shape[0], value.shape[1]
+                v_all = torch.addmm(b, value.permute(2, 0, 1, 3).reshape(cams * l, C), w.t()).view(cams, l, 3 * C)
+                vpre = [v_all[..., i * C:(i + 1) * C] for i in range(3)]
         return [self.attns[i](query[i], key, value, residual[i] if residual is not None else None,
                               spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                               reference_points_cams=reference_points_cams[i], bev_masks=tpv_masks[i],
-                              rebatch_plan=plans[i])
+                              rebatch_plan=plans[i], out=outs[i], value_pre=vpre[i])
                 for i in range(3)]
+
+    def _merged_value_proj(self):
+        """(3 C, C) weight and (3 C) bias of the three planes' value_proj stacked; cached until a parameter changes."""
+        ps = [a.deformable_attention.value_proj for a in self.attns]
+        key = tuple((p.weight._version, p.weight.data_ptr(), p.bias._version, p.bias.data_ptr()) for p in ps)
+        if getattr(self, '_vp_cache', (None,))[0] != key:
+            self._vp_cache = (key, torch.cat([p.weight for p in ps], 0).detach(), torch.cat([p.bias for p in ps], 0).detach())
+        return self._vp_cache[1], self._vp_cache[2]
 
 
 @MODELS.register_module()

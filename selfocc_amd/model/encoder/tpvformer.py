@@ -97,6 +97,28 @@ class BEVPositionalEncoding(BaseModule):
         return self.position_layer(self.freq_feat)
 
 
+def cat_planes(planes):
+    """torch.cat(planes, dim=1) — without the copy when the planes already ARE consecutive slices of one
+    contiguous (1, N, C) buffer (the views torch.split hands out, or the slices TPVCrossAttention writes into):
+    the encoder layer alternates between the concatenated and the per-plane form five times, 30 MB per copy at the
+    shipped sizes.  Under autograd the plain cat is kept (its backward is already a view)."""
+    if torch.is_grad_enabled() or len(planes) == 1:
+        return planes[0] if len(planes) == 1 else torch.cat(planes, dim=1)
+    first = planes[0]
+    C = first.shape[-1]
+    ok = first.dim() == 3 and first.shape[0] == 1
+    off = first.storage_offset()
+    for p in planes:
+        ok = ok and p.dim() == 3 and p.shape[0] == 1 and p.shape[-1] == C and p.stride(1) == C and p.stride(2) == 1 \
+            and p.untyped_storage().data_ptr() == first.untyped_storage().data_ptr() and p.storage_offset() == off \
+            and p.dtype == first.dtype
+        off += p.shape[1] * C
+    if not ok:
+        return torch.cat(planes, dim=1)
+    n = sum(p.shape[1] for p in planes)
+    return first.as_strided((1, n, C), (n * C, C, 1), first.storage_offset())
+
+
 class _FormerLayerBase(BaseModule):
     """attention / norm / ffn stack driven by ``operation_order`` (mmcv BaseTransformerLayer idiom)."""
 
@@ -155,17 +177,20 @@ class TPVFormerLayer(_FormerLayerBase):
                 level_start_index=None, reference_points_cams=None, tpv_masks=None, tpv_size=None, **kwargs):
         H, W, Z = tpv_size
         sizes = [H * W, Z * H, W * Z]
+        tpv_pos_cat = kwargs.pop('tpv_pos_cat', None)
+        if tpv_pos_cat is None:
+            tpv_pos_cat = torch.cat(tpv_pos, dim=1)
         norm_i = attn_i = ffn_i = 0
         identity = query
         device = query[0].device
-        cat = lambda planes: planes if self.multi_plane_ffn_norm else torch.cat(planes, dim=1)
+        cat = lambda planes: planes if self.multi_plane_ffn_norm else cat_planes(list(planes))
         split = lambda t: t if self.multi_plane_ffn_norm else torch.split(t, sizes, 1)
         for op in self.operation_order:
             if op == 'self_attn':   # cross-view hybrid attention: the 3 planes are the 3 "levels"
                 ss, lsi = _plane_shapes(H, W, Z, device)     # constants: uploaded once, not once per layer call
-                q = torch.cat(query, dim=1)
-                q = self.attentions[attn_i](q, q, q, torch.cat(identity, dim=1) if self.pre_norm else None,
-                                            query_pos=torch.cat(tpv_pos, dim=1), reference_points=ref_2d,
+                q = cat_planes(list(query))
+                q = self.attentions[attn_i](q, q, q, cat_planes(list(identity)) if self.pre_norm else None,
+                                            query_pos=tpv_pos_cat, reference_points=ref_2d,
                                             spatial_shapes=ss, level_start_index=lsi, **kwargs)
                 query = torch.split(q, sizes, 1)
                 attn_i += 1
@@ -307,8 +332,9 @@ class TPVFormerEncoder(_EncoderBase):
         # the camera-loop kernels need no re-batch plan (no host sync); a layer that cannot take that path
         # (batch > 1, shapes the banded scatter does not cover) builds its own
         plans = None
+        tpv_pos_cat = torch.cat(tpv_pos, dim=1)        # once per forward, not once per layer
         for layer in self.layers:
-            tpv_query = layer(tpv_query, key, value, tpv_pos=tpv_pos, ref_2d=ref_cross_view,
+            tpv_query = layer(tpv_query, key, value, tpv_pos=tpv_pos, tpv_pos_cat=tpv_pos_cat, ref_2d=ref_cross_view,
                               spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                               reference_points_cams=reference_points_cams, tpv_masks=tpv_masks,
                               tpv_size=self.tpv_size, rebatch_plans=plans, **kwargs)

@@ -127,7 +127,12 @@ def msda_cross_inference(value, spatial_shapes, level_start_index, reference_poi
         raise RuntimeError("msda_cross_inference needs CUDA(HIP) tensors: selfocc_amd has no CPU fallback")
     cams, nv, heads, d = value.shape
     nq, _, L, P, _ = sampling_offsets.shape
-    value = value.contiguous().float()
+    vstride = 0
+    if (value.dtype == torch.float32 and not value.is_contiguous() and value.stride(3) == 1 and value.stride(2) == d
+            and value.stride(1) % 4 == 0 and value.stride(0) == nv * value.stride(1)):
+        vstride = value.stride(1)        # a column block of a wider (cams * nv, N) matrix: no copy
+    else:
+        value = value.contiguous().float()
     off = sampling_offsets.contiguous().float()
     lg = attention_logits.contiguous().float()
     ref = reference_points_cam.contiguous().float()
@@ -137,7 +142,7 @@ def msda_cross_inference(value, spatial_shapes, level_start_index, reference_poi
     st = level_start_index.to(device=value.device, dtype=torch.int32).contiguous()
     out = torch.empty(nq, heads * d, device=value.device, dtype=torch.float32)
     check(lib().selfocc_msda_cross_fwd(ptr(value), ptr(sh), ptr(st), ptr(ref), ptr(vis), ptr(off), ptr(lg),
-                                       ptr(out), cams, nv, nq, heads, d, L, P, current_stream(value.device)),
+                                       ptr(out), cams, nv, nq, heads, d, L, P, vstride, current_stream(value.device)),
           "selfocc_msda_cross_fwd")
     return out
 
