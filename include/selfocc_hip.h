@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SELFOCC_ABI_VERSION 16
+#define SELFOCC_ABI_VERSION 17
 
 int selfocc_abi_version(void);
 const char *selfocc_last_error(void);
@@ -149,6 +149,10 @@ typedef struct so_render_args {
                          canonical float32 order too), so SDF-only per-ray launches composite
                          such samples without interpolating.  The re-pack kernel is launched by
                          selfocc_render_fwd on the same stream before the march.              */
+    const float *inv_s_dev; /* optional DEVICE pointer to inv_s (1 float).  When non-NULL the kernels read
+                         inv_s from it and ignore the host value above: a training loop whose inv_s is
+                         a learnable parameter (exp(10 * variance), neus_head.py:631-633) never has to
+                         read it back to the host (no stream sync, nothing to go stale).       */
 } so_render_args;
 
 int selfocc_render_fwd(const so_render_args *args, void *stream);

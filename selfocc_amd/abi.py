@@ -6,7 +6,7 @@ its exported symbols being callable with these layouts.
 """
 import ctypes as C
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 # enums ---------------------------------------------------------------------------
 RAYS_EXPLICIT, RAYS_PIXEL_GRID = 0, 1
@@ -48,6 +48,7 @@ class SoRenderArgs(C.Structure):
         ("nears", _p), ("fars", _p),
         ("weights", _p), ("ts", _p), ("deltas", _p), ("sdf", _p), ("grad", _p),
         ("sdf_brick", _p),
+        ("inv_s_dev", _p),
     ]
 
 

@@ -166,8 +166,8 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba) 
         const float cosv = (g.dx * gx + g.dy * gy) + g.dz * gz;
         cneg[j] = cosv < 0.0f;
         halfv[j] = (fminf(cosv, 0.0f) * delta[j]) * 0.5f;
-        Pc[j] = so_sigmoid((sdfv[j] - halfv[j]) * a.inv_s);
-        Nc[j] = so_sigmoid((sdfv[j] + halfv[j]) * a.inv_s);
+        Pc[j] = so_sigmoid((sdfv[j] - halfv[j]) * so_inv_s(a));
+        Nc[j] = so_sigmoid((sdfv[j] + halfv[j]) * so_inv_s(a));
         const float araw = ((Pc[j] - Nc[j]) + 1e-5f) / (Pc[j] + 1e-5f);
         unclipped[j] = (araw > 0.0f) && (araw < 1.0f);
         alpha[j] = live[j] ? fminf(fmaxf(araw, 0.0f), 1.0f) : 0.0f;
@@ -431,8 +431,8 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba) 
             const float da = dP * Pc[j] * (1.0f - Pc[j]);
             const float db = dN * Nc[j] * (1.0f - Nc[j]);
             const size_t so = (size_t)ray * S + ((j * WPR + wstep) * 64 + lane);
-            float ds = (da + db) * a.inv_s;
-            const float dh = (db - da) * a.inv_s;
+            float ds = (da + db) * so_inv_s(a);
+            const float dh = (db - da) * so_inv_s(a);
             dinv_s_l += da * (sdfv[j] - halfv[j]) + db * (sdfv[j] + halfv[j]);
             const float dc = cneg[j] ? dh * (delta[j] * 0.5f) : 0.0f;
             float dgx = dc * g.dx, dgy = dc * g.dy, dgz = dc * g.dz;

@@ -209,8 +209,8 @@ SO_DEVFN void so_march_exact(const so_render_args &a, int ray, const RayGeom &g)
         float cosv = (g.dx * gx + g.dy * gy) + g.dz * gz;
         float icos = fminf(cosv, 0.0f);
         float half = (icos * delta) * 0.5f;
-        float prev_cdf = so_sigmoid((sdf - half) * a.inv_s);
-        float next_cdf = so_sigmoid((sdf + half) * a.inv_s);
+        float prev_cdf = so_sigmoid((sdf - half) * so_inv_s(a));
+        float next_cdf = so_sigmoid((sdf + half) * so_inv_s(a));
         float alpha = ((prev_cdf - next_cdf) + 1e-5f) / (prev_cdf + 1e-5f);
         alpha = fminf(fmaxf(alpha, 0.0f), 1.0f);
         float w = alpha * T;
@@ -506,7 +506,7 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, GeomFn geom, bool 
     const float G0h = fmaf(g.oy, kh.k1, kh.k0) + Gdh * t_off;
     const float G0w = fmaf(g.ox, kw.k1, kw.k0) + Gdw * t_off;
     const float G0d = fmaf(g.oz, kd.k1, kd.k0) + Gdd * t_off;
-    const float s2 = a.inv_s * 1.44269504088896341f;  // exp(-x s) = exp2(-x s log2 e)
+    const float s2 = so_inv_s(a) * 1.44269504088896341f;  // exp(-x s) = exp2(-x s log2 e)
     const float hdt = 0.5f * dt;
     const float hdt_s2 = hdt * s2;
 
@@ -854,7 +854,7 @@ SO_DEVFN void so_march_fast_ahead(const so_render_args &a, int ray, GeomFn geom)
     const float G0h = fmaf(g.oy, kh.k1, kh.k0) + Gdh * t_off;
     const float G0w = fmaf(g.ox, kw.k1, kw.k0) + Gdw * t_off;
     const float G0d = fmaf(g.oz, kd.k1, kd.k0) + Gdd * t_off;
-    const float s2 = a.inv_s * 1.44269504088896341f;
+    const float s2 = so_inv_s(a) * 1.44269504088896341f;
     const float hdt = 0.5f * dt, hdt_s2 = hdt * s2;
     const float *__restrict__ vol = a.sdf_vol;
     const unsigned n_cells = (unsigned)(H * W * D);
@@ -1015,8 +1015,8 @@ __global__ __launch_bounds__(256) void sdf_brickify_kernel(const float *__restri
         const float gh = fmaxf(fmaxf(fabsf(v4 - v0), fabsf(v5 - v1)), fmaxf(fabsf(v6 - v2), fabsf(v7 - v3))) *
                          (a.map.h.size0 / a.map.h.range0);
         const float G = sqrtf((gd * gd + gw * gw) + gh * gh) * 1.001f + 1e-20f;
-        const float slack = m - kSkipArg / a.inv_s;                       // metres above the saturation level
-        if (slack > 0.0f && a.inv_s > 0.0f) {
+        const float slack = m - kSkipArg / so_inv_s(a);                       // metres above the saturation level
+        if (slack > 0.0f && so_inv_s(a) > 0.0f) {
             const float allow = 2.0f * slack / G / so_skip_unit(a.aabb, a.n_samples);   // in code units
             code = (unsigned)fminf(floorf(allow * 0.999f), 255.0f);
         }

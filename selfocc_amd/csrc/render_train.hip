@@ -179,8 +179,8 @@ __global__ __launch_bounds__(256) void render_fwd_samples_kernel(so_render_args 
             const float cosv = (g.dx * gx + g.dy * gy) + g.dz * gz;
             const float icos = fminf(cosv, 0.0f);
             const float half = (icos * delta) * 0.5f;
-            const float prev_cdf = so_sigmoid((sdf - half) * a.inv_s);
-            const float next_cdf = so_sigmoid((sdf + half) * a.inv_s);
+            const float prev_cdf = so_sigmoid((sdf - half) * so_inv_s(a));
+            const float next_cdf = so_sigmoid((sdf + half) * so_inv_s(a));
             alpha = ((prev_cdf - next_cdf) + 1e-5f) / (prev_cdf + 1e-5f);
             alpha = fminf(fmaxf(alpha, 0.0f), 1.0f);
             fstep = (1.0f - alpha) + 1e-7f;

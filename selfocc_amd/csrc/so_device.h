@@ -57,6 +57,9 @@ SO_DEVFN float so_expf(float x) {
 
 SO_DEVFN float so_sigmoid(float x) { return 1.0f / (1.0f + so_expf(-x)); }
 
+// inv_s of a render launch: the device copy wins when given (so_render_args::inv_s_dev)
+SO_DEVFN float so_inv_s(const so_render_args &a) { return a.inv_s_dev ? a.inv_s_dev[0] : a.inv_s; }
+
 // ---- grid <-> metre ---------------------------------------------------------------------
 // LinearMapping.meter2grid, one axis (reference model/encoder/bevformer/mappings.py:97-143)
 SO_DEVFN float so_axis_m2g(const so_axis &A, float m, float &slope) {

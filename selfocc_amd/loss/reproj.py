@@ -56,17 +56,10 @@ class SSIM(nn.Module):
     C1, C2 = 0.01 ** 2, 0.03 ** 2
 
     def forward(self, x, y):
-        if x.is_cuda:      # one HIP launch per direction instead of ~40 / ~80 tiny torch kernels
-            return _SSIMFunction.apply(x, y)
-        x, y = F.pad(x, (1, 1, 1, 1), mode='reflect'), F.pad(y, (1, 1, 1, 1), mode='reflect')
-        pool = lambda t: F.avg_pool2d(t, 3, 1)
-        mu_x, mu_y = pool(x), pool(y)
-        sigma_x = pool(x ** 2) - mu_x ** 2
-        sigma_y = pool(y ** 2) - mu_y ** 2
-        sigma_xy = pool(x * y) - mu_x * mu_y
-        n = (2 * mu_x * mu_y + self.C1) * (2 * sigma_xy + self.C2)
-        d = (mu_x ** 2 + mu_y ** 2 + self.C1) * (sigma_x + sigma_y + self.C2)
-        return torch.clamp((1 - n / d) / 2, 0, 1)
+        # one HIP launch per direction instead of ~40 / ~80 tiny torch kernels; no CPU fallback (selfocc_amd/_lib.py)
+        if not x.is_cuda:
+            raise RuntimeError("SSIM needs CUDA(HIP) tensors: selfocc_amd has no CPU fallback")
+        return _SSIMFunction.apply(x, y)
 
 
 # a transform that maps every point behind the camera: disables one temporal frame in the kernel

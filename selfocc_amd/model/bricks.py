@@ -114,16 +114,19 @@ class _TallLinear(torch.autograd.Function):
     nuscenes_occ sizes) runs on 2 workgroups — 23 ms per call, 4 calls per iteration in the
     round-1 profile; here the reduction over rows is split into 256 batched GEMMs + a sum."""
 
+    # under torch.autocast (the reference's env amp=true) the op runs in float32 like the HIP ops around it
     @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         return torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
 
     @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
-        dy = dy.contiguous()
+        dy = dy.contiguous().to(x.dtype)
         T = x.shape[0]
         G = max(1, min(256, T // 2048))  # ~2 k+ rows per batched GEMM: enough workgroups, small partial-sum tensor
         R = T // G                       # rows per batched GEMM

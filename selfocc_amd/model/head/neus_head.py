@@ -162,14 +162,11 @@ class SDFField(BaseModule):
     def inv_s(self):
         return torch.exp(self.variance * 10.0).clip(1e-6, 1e6)
 
-    def inv_s_host(self):
-        """inv_s as a python float for the render launch.  Reading it back is a stream sync, so the value is
-        cached until the parameter changes (evaluation: once; training: once per optimiser step)."""
-        v = self.variance
-        key = (v._version, v.data_ptr())
-        if getattr(self, '_inv_s_cache', (None, None))[0] != key:
-            self._inv_s_cache = (key, float(self.inv_s().detach()))
-        return self._inv_s_cache[1]
+    def inv_s_device(self):
+        """inv_s as a 1-element float32 device tensor for the render launch (RenderConfig.inv_s_dev): the kernels read
+        it from device memory, so the launch needs neither a host read-back (a stream sync) nor a cache that a write
+        through ``.data`` (EMA / checkpoint loaders) could leave stale."""
+        return self.inv_s().detach().reshape(1).float().contiguous()
 
     def _mlp(self, x):
         """density_net applied to (rows, C); Linear layers through _TallLinear (same parameters)."""
@@ -291,6 +288,11 @@ class NeuSHead(BaseModule):
                              beta_hand_tune=beta_hand_tune, return_surface_sdf=return_surface_sdf).items():
             if on:
                 raise NotImplementedError(f"NeuSHead({name}=...) is off in every shipped SelfOcc config and not built")
+        if return_second_grad and not use_compact_2nd_grad:
+            import warnings
+            warnings.warn("NeuSHead(return_second_grad=True, use_compact_2nd_grad=False): `second_grad` is always the compact "
+                          "second difference of the SDF volume here (declared restatement, DESIGN.md section 4); the "
+                          "SecondGradLoss weight of configs written for the non-compact form may need re-tuning")
         self.ray_sampler = RaySampler(ray_sample_mode, ray_number, ray_img_size, ray_upper_crop, ray_x_dsr_max, ray_y_dsr_max)
         self.ray_sampler_eval = RaySampler('fixed', ray_number, ray_img_size, ray_upper_crop)
         self.img2lidar = Img2LiDAR(trans_kw, trans_kw_eval, novel_view)
@@ -395,7 +397,7 @@ class NeuSHead(BaseModule):
         device = vol.sdf.device
         rays, pix, num_cams, num_rays = self._rays(metas, device)
         cfg = self._render_cfg(False)
-        cfg.inv_s = self.model.field.inv_s_host()
+        cfg.inv_s_dev = self.model.field.inv_s_device()
         vol = SDFVolume(vol.mapping, vol.sdf.detach(), None if vol.feat is None else vol.feat.detach(), vol.n_rgb, vol.n_sem)
         if self._sharding(rays):
             # every rank marches its row block of every camera; the per-ray maps are all-gathered back into the
@@ -444,9 +446,8 @@ class NeuSHead(BaseModule):
         inv_s = field.inv_s()
         if full_rays is not None:
             inv_s = sdist.replicate_grad_sum(inv_s)       # d/d(variance) is a sum over all rays as well
-        cfg.inv_s_host = field.inv_s_host()       # cached until the optimiser changes the parameter
         out = render_rays_autograd(vol, inv_s, rays, cfg, want_grad_samples=True, t_rand=t_rand, bkgd_rays=bk)
-        self.last_inv_s = cfg.inv_s_host
+        self.last_inv_s = inv_s.detach()          # device tensor (the reference logs output['inv_s'], neus_head.py:631-633)
         if full_rays is not None:
             out = {k: sdist.gather_rays_autograd(v, full_rays) for k, v in out.items()}
             rays = full_rays

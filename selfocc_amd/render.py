@@ -105,7 +105,7 @@ class RenderConfig:
     aabb: tuple                       # (xmin, ymin, zmin, xmax, ymax, zmax)
     n_samples: int = 128
     inv_s: float = 20.0
-    inv_s_host: object = None         # optional host copy of the differentiable inv_s tensor (render_rays_autograd)
+    inv_s_dev: object = None          # optional 1-element float32 DEVICE tensor: the kernels read inv_s from it (no host copy)
     near_plane: float = 0.0
     sample_pos: int = abi.SAMPLE_AT_START
     jitter_mode: int = abi.JITTER_NONE
@@ -167,6 +167,11 @@ def marshal_render_args(vol: SDFVolume, rays: RaySet, cfg: RenderConfig, *, per_
         assert t_rand is not None and tuple(t_rand.shape) == exp, f"t_rand must be {exp}"
         a.t_rand = ptr(_c(t_rand))
     a.inv_s = float(cfg.inv_s)
+    if cfg.inv_s_dev is not None:
+        t = cfg.inv_s_dev
+        assert t.dtype == torch.float32 and t.numel() == 1 and t.device == dev, "inv_s_dev: one float32 on the volume's device"
+        a.inv_s_dev = ptr(t)
+        keep.append(t)
     a.bkgd_mode = cfg.bkgd_mode
     for i in range(3):
         a.bkgd[i] = float(cfg.bkgd[i])
@@ -237,12 +242,16 @@ class _RenderFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, sdf_vol, feat_vol, inv_s, mapping, n_rgb, n_sem, rays, cfg, t_rand, bkgd_rays, want_grad_samples):
         vol = SDFVolume(mapping, sdf_vol, feat_vol, n_rgb, n_sem)
-        # cfg.inv_s_host: the caller already holds the value of inv_s on the host (saves a stream sync per step)
-        host = getattr(cfg, 'inv_s_host', None)
-        cfg_run = RenderConfig(**{**cfg.__dict__, 'inv_s': float(inv_s.detach().reshape(-1)[0]) if host is None else float(host)})
+        # the kernels read inv_s from the device tensor itself: no read-back, no stream sync, nothing to go stale
+        cfg_run = RenderConfig(**{**cfg.__dict__, 'inv_s_dev': inv_s.detach().reshape(1).float().contiguous()})
         out = render_rays(vol, rays, cfg_run, per_sample=True, want_grad_samples=want_grad_samples,
                           t_rand=t_rand, bkgd_rays=bkgd_rays)
-        ctx.vol, ctx.rays, ctx.cfg, ctx.t_rand, ctx.bkgd_rays = vol, rays, cfg_run, t_rand, bkgd_rays
+        # tensor inputs go through save_for_backward (version-counter checks, saved-tensor hooks); the ray set and
+        # the config are plain python state
+        ctx.has = (feat_vol is not None, t_rand is not None, bkgd_rays is not None)
+        ctx.save_for_backward(*[t for t in (sdf_vol, feat_vol, t_rand, bkgd_rays, cfg_run.inv_s_dev) if t is not None])
+        ctx.meta = (mapping, n_rgb, n_sem)
+        ctx.rays, ctx.cfg = rays, RenderConfig(**{**cfg_run.__dict__, 'inv_s_dev': None})
         ctx.inv_s_shape = inv_s.shape
         ctx.keys = ['depth', 'acc'] + (['rgb'] if n_rgb else []) + (['sem'] if n_sem else []) + ['weights'] + \
             (['sdf', 'grad'] if want_grad_samples else [])
@@ -253,10 +262,18 @@ class _RenderFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
-        vol, rays, cfg = ctx.vol, ctx.rays, ctx.cfg
+        saved = list(ctx.saved_tensors)
+        sdf_vol = saved.pop(0)
+        feat_vol = saved.pop(0) if ctx.has[0] else None
+        t_rand = saved.pop(0) if ctx.has[1] else None
+        bkgd_rays = saved.pop(0) if ctx.has[2] else None
+        inv_s_dev = saved.pop(0)
+        mapping, n_rgb, n_sem = ctx.meta
+        vol = SDFVolume(mapping, sdf_vol, feat_vol, n_rgb, n_sem)
+        rays, cfg = ctx.rays, RenderConfig(**{**ctx.cfg.__dict__, 'inv_s_dev': inv_s_dev})
         gmap = {k: g for k, g in zip(ctx.keys, grads)}
-        a, _out, _keep = marshal_render_args(vol, rays, cfg, per_sample=False, t_rand=ctx.t_rand,
-                                             bkgd_rays=ctx.bkgd_rays, outputs={})
+        a, _out, _keep = marshal_render_args(vol, rays, cfg, per_sample=False, t_rand=t_rand,
+                                             bkgd_rays=bkgd_rays, outputs={})
         ba = abi.SoRenderBwdArgs()
         ba.fwd = a
         hold = []

@@ -43,14 +43,20 @@ class ReprojSampleFunction(Function):
         anyv = torch.empty(R, device=dev)
         a.l1, a.rgb_combine, a.any_valid = ptr(l1), ptr(comb), ptr(anyv)
         check(lib().selfocc_reproj_fwd(a, current_stream(dev)), "selfocc_reproj_fwd")
-        ctx.tens, ctx.hw = tens, (img_h, img_w)
+        # saved through autograd (version-counter checks, saved-tensor hooks): an in-place change of `weights`
+        # between forward and backward is an error, not a silent mismatch
+        ctx.has_deltas = tens[2] is not None
+        ctx.save_for_backward(*[t for t in tens if t is not None])
+        ctx.hw = (img_h, img_w)
         ctx.mark_non_differentiable(anyv)
         return l1, comb, anyv
 
     @staticmethod
     @once_differentiable
     def backward(ctx, g_l1, g_comb, _g_any):
-        tens = ctx.tens
+        tens = list(ctx.saved_tensors)
+        if not ctx.has_deltas:
+            tens.insert(2, None)
         a = _args(*tens, *ctx.hw)
         g_l1 = g_l1.contiguous().float()
         g_comb = g_comb.contiguous().float()

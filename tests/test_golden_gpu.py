@@ -46,6 +46,18 @@ def test_reproj_losses_vs_reference_class(hip, name, cls, kw, use_d):
     assert ((gw - ref).norm() / ref.norm()) < 1e-3
 
 
+def test_rgb_ssim_loss_vs_reference_class(hip):
+    """RGBLossMS with its SSIM term (loss/rgb_loss_ms.py:41-100; SSIM class of
+    reproj_loss_mono_multi_new_combine.py:26-66) through csrc/ssim.hip == the reference class's value."""
+    from selfocc_amd.loss import RGBLossMS
+    los = np.load(os.path.join(G, "losses.npz"))
+    R, S, Hi, Wi, rh, rw = los['dims'].tolist()
+    t = lambda a: torch.tensor(a).to(D0)
+    v = RGBLossMS(1.0, [Hi, Wi], False, [rh, rw])(dict(ms_colors=[t(los['colors'])], ms_rays=t(los['rays']),
+                                                        gt_imgs=t(los['curr'])))
+    assert torch.allclose(v.cpu(), torch.tensor(los['rgb_ssim.loss']), rtol=1e-5)
+
+
 def test_tpvformer_encoder_vs_reference_class(hip):
     """Two TPVFormer layers (cross-view hybrid self-attention + per-plane image cross-attention
     over 2 cameras x 2 levels + FFN + LN) with the REFERENCE's state dict loaded by name."""

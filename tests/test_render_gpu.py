@@ -349,3 +349,24 @@ def test_two_segment_mapping_takes_canonical_path(hip):
                       per_sample=True, want_grad_samples=True)
     assert torch.equal(got['sdf'].cpu(), ref['sdf'])
     _cmp(got, ref)
+
+
+def test_device_inv_s_overrides_the_host_value(hip):
+    """RenderConfig.inv_s_dev (so_render_args::inv_s_dev): the kernels read inv_s from device memory, whatever the
+    (possibly stale) host value says — eval launch, training launch and the brick / skip-code pass alike."""
+    from dataclasses import replace
+    d = torch.device("cuda:0")
+    vol = sy.make_volume("cfg2", seed=3).to(d)
+    rays = sy.make_rays("cfg2", seed=3)
+    sub = _dev_rays(RaySet(img2lidar=rays.img2lidar, nx=rays.nx, ny=96, sx=rays.sx, sy=rays.sy, oy=rays.sy * 150), d)
+    want = sy.make_render_config("cfg2", inv_s=37.0)
+    stale = replace(sy.make_render_config("cfg2", inv_s=3.0), inv_s_dev=torch.tensor([37.0], device=d))
+    a = {k: v.clone() for k, v in render_rays(vol, sub, want).items()}
+    b = render_rays(vol, sub, stale)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    small = _dev_rays(RaySet(img2lidar=rays.img2lidar, nx=40, ny=10, sx=rays.sx * 20, sy=rays.sy * 40), d)
+    a = {k: v.clone() for k, v in render_rays(vol, small, want, per_sample=True, want_grad_samples=True).items()}
+    b = render_rays(vol, small, stale, per_sample=True, want_grad_samples=True)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
