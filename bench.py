@@ -55,8 +55,8 @@ def kernel_source_hash():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--channels", type=int, default=1, choices=[1, 4, 25],
                     help="volume channels: 1 = sdf only (config/nuscenes/nuscenes_depth.py, color_dims=0: the "
                          "eval_depth.py path the reference's README quotes) | 4 sdf+rgb | 25 sdf+rgb+21 sem (nuscenes_occ)")

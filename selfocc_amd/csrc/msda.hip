@@ -294,8 +294,11 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const float *__restrict__
 //            1: ref (bs, nq, P, 2)      (one anchor per point, all levels: BEVDeformableAttention)
 //            2: ref (bs, nq, L, P, 2)   (CrossViewHybridAttention)
 // ---------------------------------------------------------------------------------------
+// 4 waves / SIMD (<= 128 VGPRs) for the shipped head width: the camera-loop kernel otherwise takes 144 VGPRs (3 waves);
+// measured -1.5 % on the eval encoder, 5 / 6 waves spill (+20 % / +39 %)
+#define SO_MSDA_FWD_WAVES(D) ((D) <= 16 ? 4 : 1)
 template <int D, int LOGG>
-__global__ __launch_bounds__(256) void msda_fused_fwd_kernel(const float *__restrict__ value,
+__global__ __launch_bounds__(256, SO_MSDA_FWD_WAVES(D)) void msda_fused_fwd_kernel(const float *__restrict__ value,
                                                              const int32_t *__restrict__ shapes,
                                                              const int32_t *__restrict__ starts,
                                                              const float *__restrict__ ref, int ref_kind,
@@ -382,7 +385,7 @@ __global__ __launch_bounds__(256) void msda_fused_fwd_kernel(const float *__rest
 //   logits (nq, heads, L*P)      out (nq, heads*D) = sum_{cam visible} msda_cam(q) / max(#visible, 1)
 // ---------------------------------------------------------------------------------------
 template <int D, int LOGG>
-__global__ __launch_bounds__(256) void msda_cross_fwd_kernel(const float *__restrict__ value,
+__global__ __launch_bounds__(256, SO_MSDA_FWD_WAVES(D)) void msda_cross_fwd_kernel(const float *__restrict__ value,
                                                              const int32_t *__restrict__ shapes,
                                                              const int32_t *__restrict__ starts,
                                                              const float *__restrict__ ref,
