@@ -8,6 +8,8 @@ import numpy as np
 import torch
 from selfocc_amd.registry import MODELS
 import selfocc_amd.model  # noqa
+from selfocc_amd.model import bricks as _bricks
+_bricks.HEAD_MAJOR_VALUE = os.environ.get('SO_HEAD_MAJOR', '0') == '1'   # A/B switch of the MSDA value layout
 
 os.environ['eval'] = 'true'
 d = torch.device("cuda:0")

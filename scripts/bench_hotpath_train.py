@@ -9,6 +9,8 @@ import numpy as np
 import torch
 from selfocc_amd.registry import MODELS, OPENOCC_LOSS
 import selfocc_amd.model, selfocc_amd.loss  # noqa
+from selfocc_amd.model import bricks as _bricks
+_bricks.HEAD_MAJOR_VALUE = os.environ.get('SO_HEAD_MAJOR', '0') == '1'   # A/B switch of the MSDA value layout
 
 d = torch.device("cuda:0")
 torch.manual_seed(0); np.random.seed(0)

@@ -12,7 +12,7 @@ import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from selfocc_amd.msda import (MultiScaleDeformableAttnFunction as F, MSDAFusedFunction, MSDACrossFunction,
-                              msda_fused_inference, msda_cross_inference)
+                              msda_fused_inference, msda_cross_inference, to_head_major)
 
 PEAK = 8000.0
 d = torch.device("cuda:0")
@@ -96,6 +96,13 @@ for name, (bs, nq, shapes, P) in CASES.items():
         fb_ms = time_bwd(lambda: MSDAFusedFunction.apply(val_d, sh, st, ref, 0, off_d, lg_d, sh._so_host), g)
         alg_fb = 4 * (value.numel() * 2 + ref.numel() + off_raw.numel() * 2 + logits.numel() * 2 + out.numel())
         rows.append(rec("msda_fused_bwd point+band (incl. grad_value memset)", tag, alg_fb, fb_ms, pts))
+        # the layout the encoder modules use: head-major value (bs, heads, nv, d), same bytes
+        val_h = to_head_major(val_d.detach()).requires_grad_(True)
+        with torch.no_grad():
+            fh_ms = timeit(lambda: msda_fused_inference(val_h, sh, st, ref, 0, off_d, lg_d, True))
+        rows.append(rec("msda_fused_fwd head-major", tag, alg_ff, fh_ms, pts))
+        fhb_ms = time_bwd(lambda: MSDAFusedFunction.apply(val_h, sh, st, ref, 0, off_d, lg_d, sh._so_host, True), g)
+        rows.append(rec("msda_fused_bwd head-major point+band (incl. grad_value memset)", tag, alg_fb, fhb_ms, pts))
     except Exception as e:   # a shape the fused / banded path does not take: keep the other rows
         rows.append(dict(kernel="msda_fused", shape=tag, error=repr(e)[:200]))
     if name == "cross_hw":
@@ -124,7 +131,12 @@ for name, (bs, nq, shapes, P) in CASES.items():
         cb_ms = time_bwd(lambda: MSDACrossFunction.apply(val_d, sh, st, refc, vis, offc, lgc, sh._so_host), gc)
         alg_cb = 4 * (value.numel() * 2 + refc.numel() + offc.numel() * 2 + lgc.numel() * 2 + outc) + vis.numel()
         rows.append(rec("msda_cross_bwd point+band (incl. grad_value memset)", tagc, alg_cb, cb_ms, ptsc))
-    for r in rows[-6:]:
+        with torch.no_grad():
+            ch_ms = timeit(lambda: msda_cross_inference(val_h, sh, st, refc, vis, offc, lgc, True))
+        rows.append(rec("msda_cross_fwd head-major", tagc, alg_c, ch_ms, ptsc))
+        chb_ms = time_bwd(lambda: MSDACrossFunction.apply(val_h, sh, st, refc, vis, offc, lgc, sh._so_host, True), gc)
+        rows.append(rec("msda_cross_bwd head-major point+band (incl. grad_value memset)", tagc, alg_cb, chb_ms, ptsc))
+    for r in rows[-12:]:
         if name in r["shape"] or "camera loop" in r["shape"]:
             print(json.dumps(r), flush=True)
 

@@ -16,7 +16,8 @@ import torch.nn as nn
 from ...registry import MODELS, build_attention
 from ..bricks import (BaseModule, MultiScaleDeformableAttention, TallLinear, constant_init, xavier_init,
                       deformable_sampling)
-from ...msda import msda_cross_inference, MSDACrossFunction, msda_fused_supported
+from ...msda import msda_cross_inference, MSDACrossFunction, msda_fused_supported, to_head_major
+from .. import bricks
 
 
 @MODELS.register_module()
@@ -162,20 +163,25 @@ class BEVCrossAttention(BaseModule):
         da = self.deformable_attention
         num_cams, heads, L, P = self.num_cams, da.num_heads, da.num_levels, da.num_points
         _, l, _, _ = value.shape                                            # (cams, nv, bs, C)
-        if value_pre is not None:      # this plane's column block of the merged value projection (TPVCrossAttention)
-            v = value_pre.view(num_cams, l, heads, -1)
+        hm = bricks.HEAD_MAJOR_VALUE
+        if value_pre is not None and value_pre.dim() == 4:
+            v = value_pre              # TPVCrossAttention already laid this plane's values out head-major
+        elif value_pre is not None:    # this plane's column block of the merged value projection (TPVCrossAttention)
+            v, hm = value_pre.view(num_cams, l, heads, -1), False
         else:
             v = da.value_proj(value.permute(2, 0, 1, 3).reshape(num_cams, l, self.embed_dims))
             v = v.view(num_cams, l, heads, -1)
+            if hm:
+                v = to_head_major(v)
         off = da.sampling_offsets(query[0]).view(-1, heads, L, P, 2)
         logits = da.attention_weights(query[0]).view(-1, heads, L * P)
         visible = bev_masks[:, 0].any(-1)                                   # (cams, Q), batch element 0 as the reference
         if host_shapes is None:
             slots = msda_cross_inference(v, spatial_shapes, level_start_index, reference_points_cams[:, 0], visible,
-                                         off, logits)[None]
+                                         off, logits, hm)[None]
         else:
             slots = MSDACrossFunction.apply(v, spatial_shapes, level_start_index, reference_points_cams[:, 0], visible,
-                                            off, logits, host_shapes)[None]
+                                            off, logits, host_shapes, hm)[None]
         slots = self.output_proj(slots)
         if out is not None and not self.training and not torch.is_grad_enabled():
             return torch.add(slots, residual, out=out)      # eval: dropout is the identity; `out` = the caller's slice
@@ -222,7 +228,12 @@ class TPVCrossAttention(BaseModule):
                 w, b = self._merged_value_proj()
                 cams, l = value.shape[0], value.shape[1]
                 v_all = torch.addmm(b, value.permute(2, 0, 1, 3).reshape(cams * l, C), w.t()).view(cams, l, 3 * C)
-                vpre = [v_all[..., i * C:(i + 1) * C] for i in range(3)]
+                if bricks.HEAD_MAJOR_VALUE:
+                    # one transposing copy for the three planes: (plane, cams, heads, l, d), each plane dense
+                    heads = self.attns[0].deformable_attention.num_heads
+                    vpre = list(v_all.view(cams, l, 3, heads, C // heads).permute(2, 0, 3, 1, 4).contiguous())
+                else:
+                    vpre = [v_all[..., i * C:(i + 1) * C] for i in range(3)]
         return [self.attns[i](query[i], key, value, residual[i] if residual is not None else None,
                               spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                               reference_points_cams=reference_points_cams[i], bev_masks=tpv_masks[i],

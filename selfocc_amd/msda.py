@@ -94,14 +94,29 @@ def multi_scale_deformable_attn(value, spatial_shapes, level_start_index, sampli
                                                   sampling_locations, attention_weights, 64)
 
 
+def to_head_major(value):
+    """(bs, nv, h, d) -> a dense (bs, h, nv, d) copy: the layout the fused / camera-loop kernels gather fastest from
+    (a cache line holds x-neighbours of one head instead of one pixel of two heads; include/selfocc_hip.h)."""
+    return value.permute(0, 2, 1, 3).contiguous()
+
+
+def _value_dims(value, head_major):
+    if head_major:
+        bs, heads, nv, d = value.shape
+    else:
+        bs, nv, heads, d = value.shape
+    return bs, nv, heads, d
+
+
 def msda_fused_inference(value, spatial_shapes, level_start_index, reference_points, ref_kind, sampling_offsets,
-                         attention_logits):
-    """Inference-only fused op (no autograd): value (bs,nv,h,d); reference_points per ``ref_kind``
+                         attention_logits, head_major=False):
+    """Inference-only fused op (no autograd): value (bs,nv,h,d), or (bs,h,nv,d) with ``head_major``;
+    reference_points per ``ref_kind``
     (0: (bs,nq,L,2), 1: (bs,nq,P,2), 2: (bs,nq,L,P,2)); sampling_offsets (bs,nq,h,L,P,2) raw linear
     output; attention_logits (bs,nq,h,L*P) before softmax.  Returns (bs, nq, h*d)."""
     if not value.is_cuda:
         raise RuntimeError("msda_fused_inference needs CUDA(HIP) tensors: selfocc_amd has no CPU fallback")
-    bs, nv, heads, d = value.shape
+    bs, nv, heads, d = _value_dims(value, head_major)
     _, nq, _, L, P, _ = sampling_offsets.shape
     value = value.contiguous().float()
     off = sampling_offsets.contiguous().float()
@@ -111,24 +126,25 @@ def msda_fused_inference(value, spatial_shapes, level_start_index, reference_poi
     st = level_start_index.to(device=value.device, dtype=torch.int32).contiguous()
     out = torch.empty(bs, nq, heads * d, device=value.device, dtype=torch.float32)
     check(lib().selfocc_msda_fused_fwd(ptr(value), ptr(sh), ptr(st), ptr(ref), int(ref_kind), ptr(off), ptr(lg),
-                                       ptr(out), bs, nv, nq, heads, d, L, P, current_stream(value.device)),
+                                       ptr(out), bs, nv, nq, heads, d, L, P, int(bool(head_major)),
+                                       current_stream(value.device)),
           "selfocc_msda_fused_fwd")
     return out
 
 
 def msda_cross_inference(value, spatial_shapes, level_start_index, reference_points_cam, visible,
-                         sampling_offsets, attention_logits):
+                         sampling_offsets, attention_logits, head_major=False):
     """Inference-only camera-loop op (no autograd): the sampling stage of BEVCrossAttention
     (bevformer/attention/image_cross_attention.py:90-136) without re-batching.
-    value (cams,nv,h,d); reference_points_cam (cams,nq,P,2); visible (cams,nq) bool — the cameras that see
+    value (cams,nv,h,d), or (cams,h,nv,d) with ``head_major``; reference_points_cam (cams,nq,P,2); visible (cams,nq) bool — the cameras that see
     each query; sampling_offsets (nq,h,L,P,2) and attention_logits (nq,h,L*P): the raw linear outputs for
     the UN-rebatched queries.  Returns (nq, h*d): the mean over the visible cameras."""
     if not value.is_cuda:
         raise RuntimeError("msda_cross_inference needs CUDA(HIP) tensors: selfocc_amd has no CPU fallback")
-    cams, nv, heads, d = value.shape
+    cams, nv, heads, d = _value_dims(value, head_major)
     nq, _, L, P, _ = sampling_offsets.shape
     vstride = 0
-    if (value.dtype == torch.float32 and not value.is_contiguous() and value.stride(3) == 1 and value.stride(2) == d
+    if (not head_major and value.dtype == torch.float32 and not value.is_contiguous() and value.stride(3) == 1 and value.stride(2) == d
             and value.stride(1) % 4 == 0 and value.stride(0) == nv * value.stride(1)):
         vstride = value.stride(1)        # a column block of a wider (cams * nv, N) matrix: no copy
     else:
@@ -142,7 +158,8 @@ def msda_cross_inference(value, spatial_shapes, level_start_index, reference_poi
     st = level_start_index.to(device=value.device, dtype=torch.int32).contiguous()
     out = torch.empty(nq, heads * d, device=value.device, dtype=torch.float32)
     check(lib().selfocc_msda_cross_fwd(ptr(value), ptr(sh), ptr(st), ptr(ref), ptr(vis), ptr(off), ptr(lg),
-                                       ptr(out), cams, nv, nq, heads, d, L, P, vstride, current_stream(value.device)),
+                                       ptr(out), cams, nv, nq, heads, d, L, P, vstride, int(bool(head_major)),
+                                       current_stream(value.device)),
           "selfocc_msda_cross_fwd")
     return out
 
@@ -155,9 +172,10 @@ class MSDAFusedFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, value, spatial_shapes, level_start_index, reference_points, ref_kind, sampling_offsets,
-                attention_logits, host_shapes):
+                attention_logits, host_shapes, head_major=False):
         out = msda_fused_inference(value, spatial_shapes, level_start_index, reference_points, ref_kind,
-                                   sampling_offsets, attention_logits)
+                                   sampling_offsets, attention_logits, head_major)
+        ctx.head_major = bool(head_major)
         sh = spatial_shapes.to(device=value.device, dtype=torch.int32).contiguous()
         st = level_start_index.to(device=value.device, dtype=torch.int32).contiguous()
         ctx.save_for_backward(value, sh, st, reference_points, sampling_offsets, attention_logits)
@@ -170,7 +188,7 @@ class MSDAFusedFunction(torch.autograd.Function):
         import ctypes
         value, sh, st, ref, off, lg = ctx.saved_tensors
         value, ref, off, lg = (t.contiguous().float() for t in (value, ref, off, lg))
-        bs, nv, heads, d = value.shape
+        bs, nv, heads, d = _value_dims(value, ctx.head_major)
         _, nq, _, L, P, _ = off.shape
         g_out = grad_output.contiguous().float()
         g_value = torch.zeros_like(value)
@@ -181,10 +199,10 @@ class MSDAFusedFunction(torch.autograd.Function):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=value.device)
         check(lib().selfocc_msda_fused_bwd(ptr(value), ptr(sh), ptr(st), ctypes.cast(arr, ctypes.c_void_p), ptr(ref),
                                            ctx.ref_kind, ptr(off), ptr(lg), ptr(g_out), ptr(g_value), ptr(g_off),
-                                           ptr(g_lg), bs, nv, nq, heads, d, L, P, ptr(ws), nbytes,
+                                           ptr(g_lg), bs, nv, nq, heads, d, L, P, int(ctx.head_major), ptr(ws), nbytes,
                                            current_stream(value.device)),
               "selfocc_msda_fused_bwd")
-        return g_value, None, None, None, None, g_off, g_lg, None
+        return g_value, None, None, None, None, g_off, g_lg, None, None
 
 
 def msda_fused_supported(host_shapes, bs, nq, heads, d, L, P):
@@ -203,9 +221,10 @@ class MSDACrossFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, value, spatial_shapes, level_start_index, reference_points_cam, visible, sampling_offsets,
-                attention_logits, host_shapes):
+                attention_logits, host_shapes, head_major=False):
         out = msda_cross_inference(value, spatial_shapes, level_start_index, reference_points_cam, visible,
-                                   sampling_offsets, attention_logits)
+                                   sampling_offsets, attention_logits, head_major)
+        ctx.head_major = bool(head_major)
         sh = spatial_shapes.to(device=value.device, dtype=torch.int32).contiguous()
         st = level_start_index.to(device=value.device, dtype=torch.int32).contiguous()
         ctx.save_for_backward(value, sh, st, reference_points_cam, visible.to(torch.uint8), sampling_offsets,
@@ -220,7 +239,7 @@ class MSDACrossFunction(torch.autograd.Function):
         value, sh, st, ref, vis, off, lg = ctx.saved_tensors
         value, ref, off, lg = (t.contiguous().float() for t in (value, ref, off, lg))
         vis = vis.contiguous()
-        cams, nv, heads, d = value.shape
+        cams, nv, heads, d = _value_dims(value, ctx.head_major)
         nq, _, L, P, _ = off.shape
         g_out = grad_output.contiguous().float()
         g_value = torch.zeros_like(value)
@@ -231,7 +250,7 @@ class MSDACrossFunction(torch.autograd.Function):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=value.device)
         check(lib().selfocc_msda_cross_bwd(ptr(value), ptr(sh), ptr(st), ctypes.cast(arr, ctypes.c_void_p), ptr(ref),
                                            ptr(vis), ptr(off), ptr(lg), ptr(g_out), ptr(g_value), ptr(g_off),
-                                           ptr(g_lg), cams, nv, nq, heads, d, L, P, ptr(ws), nbytes,
-                                           current_stream(value.device)),
+                                           ptr(g_lg), cams, nv, nq, heads, d, L, P, int(ctx.head_major), ptr(ws),
+                                           nbytes, current_stream(value.device)),
               "selfocc_msda_cross_bwd")
-        return g_value, None, None, None, None, g_off, g_lg, None
+        return g_value, None, None, None, None, g_off, g_lg, None, None

@@ -275,3 +275,55 @@ def test_msda_backward_full_size_banded_vs_atomic(hip):
     scale = gv_a.abs().max().item()
     assert (gv_b - gv_a).abs().max().item() < 2e-4 * scale          # ~2300 float adds per element on the 12x25 level
     assert torch.isfinite(gv_b).all() and gv_b.abs().sum() > 0
+
+
+@pytest.mark.parametrize("P,L,D", [(8, 4, 16), (48, 4, 16), (5, 2, 8), (3, 1, 32)])
+def test_msda_head_major_value_layout(hip, P, L, D):
+    """value_layout = SO_VALUE_HEAD_MAJOR, (bs, heads, nv, d): the fused and camera-loop ops return the SAME output
+    bits as with mmcv's (bs, nv, heads, d) (the layout only moves where the corners are read from), and the same
+    gradients, g_value in the layout value came in."""
+    from selfocc_amd.msda import (MSDAFusedFunction, MSDACrossFunction, msda_fused_inference, msda_cross_inference,
+                                  to_head_major)
+    g = torch.Generator().manual_seed(P * 11 + L)
+    shapes = torch.tensor([[24, 50], [12, 25], [6, 13], [3, 7]][:L])
+    starts = torch.cat([torch.zeros(1, dtype=torch.int64), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    nv = int((shapes[:, 0] * shapes[:, 1]).sum())
+    cams, nq, H = 3, 260, 3
+    host = [int(v) for v in shapes.reshape(-1)]
+    d = torch.device("cuda:0")
+    sh, st = shapes.to(d), starts.to(d)
+    value = torch.randn(cams, nv, H, D, generator=g).to(d)
+    value_hm = to_head_major(value)
+    assert value_hm.shape == (cams, H, nv, D) and value_hm.is_contiguous()
+
+    # fused (self-attention form), reference kind 1
+    off = (torch.randn(cams, nq, H, L, P, 2, generator=g) * 3).to(d)
+    logits = (torch.randn(cams, nq, H, L * P, generator=g) * 2).to(d)
+    ref = (torch.rand(cams, nq, P, 2, generator=g) * 1.3 - 0.15).to(d)
+    a = msda_fused_inference(value, sh, st, ref, 1, off, logits)
+    b = msda_fused_inference(value_hm, sh, st, ref, 1, off, logits, head_major=True)
+    assert torch.equal(a, b)
+    gout = torch.randn(cams, nq, H * D, generator=g).to(d)
+
+    def run_fused(hm):
+        v, o, lg = (t.clone().requires_grad_(True) for t in (value_hm if hm else value, off, logits))
+        MSDAFusedFunction.apply(v, sh, st, ref, 1, o, lg, host, hm).backward(gout)
+        return (v.grad.permute(0, 2, 1, 3) if hm else v.grad), o.grad, lg.grad
+    for x, y in zip(run_fused(True), run_fused(False)):
+        assert torch.allclose(x, y, rtol=1e-5, atol=1e-5 * y.abs().max().item())
+
+    # camera loop
+    offc, lgc = off[0].contiguous(), logits[0].contiguous()
+    refc = (torch.rand(cams, nq, P, 2, generator=g) * 1.4 - 0.2).to(d)
+    vis = (torch.rand(cams, nq, generator=g) < 0.5).to(d)
+    a = msda_cross_inference(value, sh, st, refc, vis, offc, lgc)
+    b = msda_cross_inference(value_hm, sh, st, refc, vis, offc, lgc, head_major=True)
+    assert torch.equal(a, b)
+    goutc = torch.randn(nq, H * D, generator=g).to(d)
+
+    def run_cross(hm):
+        v, o, lg = (t.clone().requires_grad_(True) for t in (value_hm if hm else value, offc, lgc))
+        MSDACrossFunction.apply(v, sh, st, refc, vis, o, lg, host, hm).backward(goutc)
+        return (v.grad.permute(0, 2, 1, 3) if hm else v.grad), o.grad, lg.grad
+    for x, y in zip(run_cross(True), run_cross(False)):
+        assert torch.allclose(x, y, rtol=1e-5, atol=1e-5 * y.abs().max().item())
