@@ -247,15 +247,14 @@ int selfocc_msda_bwd(const float *value, const int32_t *shapes, const int32_t *s
                      int32_t L, int32_t P, void *stream);
 
 /* Banded (output-stationary) backward, same results as selfocc_msda_bwd up to summation order
- * (grad_value is accumulated in double precision and rounded once).  A block owns a band of rows
- * of one level's map of one (batch, head) in LDS and adds every sampling point that touches it
- * with ds_add_f64 — no global atomics in the scatter.  Needs a HOST copy of `shapes` (L, 2) for
- * the work decomposition (L <= 8) and a 16-byte aligned device workspace of
- * selfocc_msda_bwd_banded_workspace(...) bytes (18 bytes per sampling point: a 2-byte row key and
- * a 16-byte record in band order, plus 4 bytes per 64 queries of every (batch, head, level);
- * contents undefined before and after).  g_value must be zero-initialised by the caller.  Falls back to
- * selfocc_msda_bwd when a level is wider than the LDS tile or the maps are huge relative to the
- * number of points. */
+ * (grad_value is accumulated in double precision and rounded once per list segment).  The sampling points are
+ * counting-sorted by (batch, head, level, band of rows); a block owns one band of one level's map in LDS and
+ * adds the points of its list with ds_add_f64 — no global atomics in the scatter, no key scan per band.
+ * Needs a HOST copy of `shapes` (L, 2) for the work decomposition (L <= 8) and a 16-byte aligned device
+ * workspace of selfocc_msda_bwd_banded_workspace(...) bytes (26 bytes per sampling point: a 2-byte row key, a
+ * 16-byte record, two 4-byte list slots; plus 28 KB of counters per (batch, head, level); contents undefined
+ * before and after).  g_value must be zero-initialised by the caller.  Falls back to selfocc_msda_bwd when a
+ * level is wider than the LDS tile, needs more than 1024 bands, or the call has >= 2^30 sampling points. */
 size_t selfocc_msda_bwd_banded_workspace(int32_t bs, int32_t nq, int32_t heads, int32_t L, int32_t P);
 int selfocc_msda_bwd_banded(const float *value, const int32_t *shapes, const int32_t *starts,
                             const int32_t *host_shapes, const float *loc, const float *attw,

@@ -607,14 +607,16 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(const float *__restrict__
 //
 //   kernel 1 (points):  lane per sampling point; channel teams gather the 4 corners (as in the
 //       forward), dot them with g_out -> grad_attw / grad_loc; also writes a 2-byte key per point
-//       (the corner row floor(h_im), or "outside") into keys[b][h][l][q][p].
-//   kernel 2 (bands):   block = (b, h, level, row band, query chunk).  Streams the level's keys
-//       (2 bytes per point instead of 12), compacts the hits into a wave-private LDS ring, and for
-//       every 64 hits: lanes rebuild the bilinear weights of their own point, then 16-lane rows
-//       (one channel per lane) add w * attw * g_out into the band with ds_add_f64.  The band is
-//       flushed once (float atomics only so that query chunks of one band can share it).
+//       (the corner row floor(h_im), or "outside") into keys[b][h][l][q][p] and a 16-byte record
+//       (bilinear fractions, attention weight, corner row / column).
+//   kernels 2-4 (bins): counting sort of the point indices by (b, h, level, band of rows, class) — see
+//       "binned band scatter" below.
+//   kernel 5 (bands):   block = one segment of one band's index list.  For every 64 entries: lanes rebuild
+//       the bilinear weights of their own point, then 16-lane rows (one channel per lane) add
+//       w * attw * g_out into the band with ds_add_f64.  The band is flushed once (float atomics, so
+//       that the segments of one band can share it).
 // Besides the rate, f64 accumulation makes a band's sums order-independent to ~1e-16 relative (only the
-// float flush of several query chunks into one band is order-dependent).
+// float flush of several segments into one band is order-dependent).
 // ---------------------------------------------------------------------------------------
 constexpr int kKeyOutside = -32768;
 
@@ -976,6 +978,8 @@ __global__ __launch_bounds__(256) void msda_cross_bwd_point_kernel(const float *
                 so_bwd_team_step_g<D, 6>(value, go, s, goff, dot);
                 so_bwd_team_step_g<D, 7>(value, go, s, goff, dot);
             }
+            const size_t ki = ((((size_t)cam * dm.heads + h) * dm.L + l) * dm.nq + q) * dm.P + pp;
+            if (own && !bl.any) keys[ki] = (int16_t)kKeyOutside;   // every key of a visited (camera, query) is written
             if (own && bl.any) {
 #pragma unroll
                 for (int k = 0; k < 4; ++k) dot[k] = bl.valid[k] ? dot[k] : 0.0f;
@@ -984,7 +988,6 @@ __global__ __launch_bounds__(256) void msda_cross_bwd_point_kernel(const float *
                 const float gh = (bl.hw * (dot[2] - dot[0])) + (bl.lw * (dot[3] - dot[1]));
                 gxs[r] += ((float)Wl * gw * aw) / (float)Wl;
                 gys[r] += ((float)Hl * gh * aw) / (float)Hl;
-                const size_t ki = ((((size_t)cam * dm.heads + h) * dm.L + l) * dm.nq + q) * dm.P + pp;
                 keys[ki] = (int16_t)bl.h_low;
                 recs[ki] = make_float4(bl.lh, bl.lw, aw / cnt,
                                        __int_as_float((int)(((unsigned)bl.h_low << 16) | ((unsigned)bl.w_low & 0xffffu))));
@@ -1010,79 +1013,225 @@ __global__ __launch_bounds__(256) void msda_cross_bwd_point_kernel(const float *
     }
 }
 
-// Row range of the keys of 64 consecutive queries of one (b, h, level): lets a band skip the key blocks
-// that cannot touch it (consecutive queries of a plane project to neighbouring image rows).
-constexpr int kRangeQueries = 64;
-
-__global__ __launch_bounds__(256) void msda_key_range_kernel(const int16_t *__restrict__ keys, int32_t *__restrict__ ranges,
-                                                             int nq, int P, int nqb, long long n_ranges) {
-    const long long blk = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);   // one wave per range: (b, h, l) * nqb + qb
-    if (blk >= n_ranges) return;
-    const int lane = threadIdx.x & 63;
-    const long long bhl = blk / nqb;
-    const int qb = (int)(blk - bhl * nqb);
-    const int q0 = qb * kRangeQueries, q1 = min(nq, q0 + kRangeQueries);
-    const int16_t *k = keys + (bhl * nq + q0) * P;
-    const int n = (q1 - q0) * P;
-    int mn = 32767, mx = -32768;
-    for (int e = lane; e < n; e += 64) {
-        const int v = k[e];
-        if (v != kKeyOutside) { mn = min(mn, v); mx = max(mx, v); }
-    }
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
-        mn = min(mn, __shfl_xor(mn, m, 64));
-        mx = max(mx, __shfl_xor(mx, m, 64));
-    }
-    if (lane == 0) ranges[blk] = (int)(((unsigned)mn << 16) | ((unsigned)mx & 0xffffu));
-}
-
-struct MsdaBandPlan {
-    int rows[8];      // rows per band of level l
-    int bands[8];     // bands of level l
-    int chunks[8];    // query chunks per band of level l
-    int prefix[9];    // first work item of level l within a (batch, head)
-    int items;        // work items per (batch, head)
-};
-
-// two block shapes: 512 threads + 52 KB tile (two blocks per CU; fewer EDGE instances wasted per block switch) and
-// 1024 threads + 103 KB tile (one block per CU, 2x taller bands: fewer key scans when a level has many rows)
+// two block shapes: 512 threads + 52 KB tile (two blocks per CU: one block's zero / flush phases overlap the other's
+// adds) and 1024 threads + 103 KB tile (one block per CU, 2x taller bands: fewer points straddle two bands)
 constexpr int band_tile_bytes(int threads) { return threads == 512 ? 52 * 1024 : 103 * 1024; }
 
+// ---------------------------------------------------------------------------------------
+// binned band scatter.  Round 1 let every band block stream its level's keys and pick out its hits: O(bands x keys),
+// and measured on the training iteration 57 % of that kernel's time was the scan alone (no hit processed), 35 % the
+// per-hit work, 8 % the LDS atomics.  Now the keys are read three times in total, by a counting sort by
+// (batch, head, level, band, class):
+//   bin<false>: LDS histogram of a block of keys -> global counters        (class FULL: both corner rows in the band,
+//   scan:       exclusive scan of the counters, work items per band                EDGE: one corner row; a point whose
+//   bin<true>:  same histogram, reserve space, write the point indices             rows straddle two bands is listed in both)
+// and the band kernel walks its own index list: no scan, no rings, no ballots; bands nobody touches cost nothing
+// (not even the tile zero / flush), long lists are cut into segments of `seg` entries (one block each).
+// Training iteration (16 calls): 15.6 ms -> 8.1 ms; the band kernel now runs at the ds_add_f64 rate measured by
+// scripts/micro/atomics2.hip (~10.6 clk per 64-lane instruction).
+// ---------------------------------------------------------------------------------------
+constexpr int kMaxBands = 1024;            // bands per level (host falls back to the atomic kernel beyond)
+constexpr int kBinKeysPerBlock = 256 * 32;
+
+// n / d for any 32-bit n without a division (Granlund & Montgomery round-up method; host computes m, l from d)
+struct SoFastDiv {
+    unsigned m;
+    int l;
+};
+SO_DEVFN int so_fastdiv(int n, SoFastDiv f) {
+    if (f.l == 0) return n;                      // d == 1
+    const unsigned t = __umulhi(f.m, (unsigned)n);
+    return (int)((t + (((unsigned)n - t) >> 1)) >> (f.l - 1));
+}
+
+struct MsdaBinPlan {
+    int rows[8];      // rows per band of level l
+    int bands[8];     // bands of level l
+    int band0[9];     // first band of level l within a (batch, head)
+    int nbands;       // bands per (batch, head)
+    int seg;          // list entries per band-kernel block
+    SoFastDiv divP;   // key index -> query
+};
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void msda_bin_kernel(const int16_t *__restrict__ keys, const int32_t *__restrict__ shapes,
+                                                       int32_t *__restrict__ cnt, int32_t *__restrict__ cursor,
+                                                       const int32_t *__restrict__ off, int32_t *__restrict__ list,
+                                                       const unsigned char *__restrict__ vis, int bpb, MsdaDims dm,
+                                                       MsdaBinPlan plan) {
+    // vis != NULL (camera loop, P >= 4): keys of (camera, query) pairs with vis == 0 were never written — not read here
+    __shared__ int hist[2 * kMaxBands];
+    __shared__ int base_s[FILL ? 2 * kMaxBands : 1];
+    const long long bhl = blockIdx.x / bpb;
+    const int chunk = blockIdx.x - (int)(bhl * bpb);
+    const int l = (int)(bhl % dm.L);
+    const long long bh = bhl / dm.L;
+    int rows_l = plan.rows[0], bands_l = plan.bands[0], band0 = 0;
+    for (int k = 1; k < 8; ++k)
+        if (k == l) { rows_l = plan.rows[k]; bands_l = plan.bands[k]; band0 = plan.band0[k]; }
+    const int Hl = shapes[2 * l];
+    const long long n = (long long)dm.nq * dm.P;                      // keys of one (b, h, l)
+    const long long kbase = bhl * n;
+    // the block's keys: an 8-byte aligned window of kBinKeysPerBlock keys, clipped to this (b, h, l)
+    const long long win = (kbase & ~3LL) + (long long)chunk * kBinKeysPerBlock;
+    const long long lo = max(kbase, win), hi = min(kbase + n, win + kBinKeysPerBlock);
+    const long long bucket0 = (bh * plan.nbands + band0) * 2;         // bucket = (band id) * 2 + class
+    const float inv_rows = 1.0f / (float)rows_l;
+
+    for (int i = threadIdx.x; i < 2 * bands_l; i += 256) hist[i] = 0;
+
+    // every lane loads its keys ONCE (4 consecutive keys = 8 aligned bytes per step, all steps in flight together);
+    // keys outside [lo, hi) and keys of invisible (camera, query) pairs become "outside" in the registers
+    constexpr int IT = kBinKeysPerBlock / (256 * 4);
+    constexpr unsigned kNone = 0x80008000u;
+    uint2 kk[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const long long p = win + (long long)(it * 256 + (int)threadIdx.x) * 4;
+        kk[it] = make_uint2(kNone, kNone);
+        if (p + 3 < lo || p >= hi) continue;
+        bool v0 = true, v1 = true;     // visibility of the queries of the first / last key (P >= 4: at most two)
+        int qsplit = 0;
+        if (vis != nullptr) {
+            const unsigned char *vb = vis + (size_t)(bh / dm.heads) * dm.nq;
+            const int e0 = (int)(max(p, lo) - kbase), e1 = (int)(min(p + 3, hi - 1) - kbase);
+            const int q0 = so_fastdiv(e0, plan.divP), q1 = so_fastdiv(e1, plan.divP);
+            v0 = vb[q0] != 0;
+            v1 = vb[q1] != 0;
+            qsplit = q1 * dm.P;        // first key of the last query
+        }
+        if (!v0 && !v1) continue;
+        uint2 t = *(const uint2 *)(keys + p);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const long long gi = p + k;
+            const bool dead = gi < lo || gi >= hi || !((int)(gi - kbase) < qsplit ? v0 : v1);
+            if (dead) {
+                unsigned &w = (k & 2) ? t.y : t.x;
+                w = (k & 1) ? ((w & 0x0000ffffu) | 0x80000000u) : ((w & 0xffff0000u) | 0x00008000u);
+            }
+        }
+        kk[it] = t;
+    }
+    __syncthreads();
+
+    // pass(emit): emit(bucket-in-level, key index) per list entry.  (One LDS atomic per lane and entry: aggregating the
+    // lanes of a wave that want the same bucket measured 2.5x slower — the pillar points of a query span many rows.)
+    auto pass = [&](auto emit) {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            if (kk[it].x == kNone && kk[it].y == kNone) continue;
+            const int e4 = (int)(win - kbase) + (it * 256 + (int)threadIdx.x) * 4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int key = (int)(short)(((k & 2) ? kk[it].y : kk[it].x) >> (16 * (k & 1)));
+                if (key == kKeyOutside) continue;
+                const bool va = key >= 0 && key < Hl, vb = key + 1 >= 0 && key + 1 < Hl;
+                const int ba = (int)(((float)key + 0.5f) * inv_rows), bb = (int)(((float)key + 1.5f) * inv_rows);
+                const int e = e4 + k;
+                if (va && vb && ba == bb) {
+                    emit(2 * ba, e);
+                } else {
+                    if (va) emit(2 * ba + 1, e);
+                    if (vb) emit(2 * bb + 1, e);
+                }
+            }
+        }
+    };
+    pass([&](int i, int) { atomicAdd(&hist[i], 1); });
+    __syncthreads();
+    if constexpr (!FILL) {
+        for (int i = threadIdx.x; i < 2 * bands_l; i += 256) {
+            const int c = hist[i];
+            if (c) atomicAdd(&cnt[bucket0 + i], c);
+        }
+    } else {
+        for (int i = threadIdx.x; i < 2 * bands_l; i += 256) {
+            const int c = hist[i];
+            base_s[i] = c ? off[bucket0 + i] + atomicAdd(&cursor[bucket0 + i], c) : 0;
+            hist[i] = 0;
+        }
+        __syncthreads();
+        pass([&](int i, int e) { list[base_s[i] + atomicAdd(&hist[i], 1)] = e; });
+    }
+}
+
+// one block: off[bucket] = first list entry of the bucket (a band's EDGE list follows its FULL list),
+// item0[band] = first work item of the band (ceil(entries / seg) items), item0[n_bands] = number of items
+__global__ __launch_bounds__(1024) void msda_bin_scan_kernel(const int32_t *__restrict__ cnt, int32_t *__restrict__ off,
+                                                             int32_t *__restrict__ item0, int n_bands, int seg) {
+    __shared__ int se[1024], si[1024];
+    const int t = threadIdx.x;
+    const int per = (n_bands + 1023) / 1024;
+    const int b0 = min(n_bands, t * per), b1 = min(n_bands, b0 + per);
+    int ne = 0, ni = 0;
+    for (int b = b0; b < b1; ++b) {
+        const int c = cnt[2 * b] + cnt[2 * b + 1];
+        ne += c;
+        ni += (c + seg - 1) / seg;
+    }
+    se[t] = ne; si[t] = ni;
+    __syncthreads();
+    for (int m = 1; m < 1024; m <<= 1) {
+        const int ae = t >= m ? se[t - m] : 0, ai = t >= m ? si[t - m] : 0;
+        __syncthreads();
+        se[t] += ae; si[t] += ai;
+        __syncthreads();
+    }
+    int pe = se[t] - ne, pi = si[t] - ni;     // exclusive prefixes of this thread's run
+    for (int b = b0; b < b1; ++b) {
+        const int cf = cnt[2 * b], c = cf + cnt[2 * b + 1];
+        off[2 * b] = pe;
+        off[2 * b + 1] = pe + cf;
+        item0[b] = pi;
+        pe += c;
+        pi += (c + seg - 1) / seg;
+    }
+    if (t == 1023) item0[n_bands] = si[1023];
+}
+
 template <int D, int kBandThreads>
-__global__ __launch_bounds__(kBandThreads) void msda_bwd_band_kernel(const int32_t *__restrict__ shapes,
-                                                                     const int32_t *__restrict__ starts,
-                                                                     const float *__restrict__ g_out,
-                                                                     float *__restrict__ g_value,
-                                                                     const int16_t *__restrict__ keys,
-                                                                     const float4 *__restrict__ recs,
-                                                                     const int32_t *__restrict__ ranges, int nqb,
-                                                                     MsdaDims dm, MsdaBandPlan plan) {
+__global__ __launch_bounds__(kBandThreads) void msda_bwd_band_list_kernel(const int32_t *__restrict__ shapes,
+                                                                          const int32_t *__restrict__ starts,
+                                                                          const float *__restrict__ g_out,
+                                                                          float *__restrict__ g_value,
+                                                                          const float4 *__restrict__ recs,
+                                                                          const int32_t *__restrict__ cnt,
+                                                                          const int32_t *__restrict__ off,
+                                                                          const int32_t *__restrict__ item0,
+                                                                          const int32_t *__restrict__ list, int n_bands,
+                                                                          MsdaDims dm, MsdaBinPlan plan) {
     constexpr int ROWS = 64 / D;        // sampling points served per atomic instruction
     constexpr int NJ = 64 / ROWS;       // row steps per batch of 64 points (= D)
+    constexpr int NW = kBandThreads / 64;
     extern __shared__ __attribute__((aligned(16))) double tile[];
-    // hits wait in two wave-private rings: FULL (both corner rows inside the band: 4 adds) and EDGE
-    // (h_low is the row above the band or the band's last row: only one corner row, 2 adds) so that
-    // a batch emits exactly its corners, unconditionally (no per-corner tests or branches)
-    __shared__ int ring[kBandThreads / 64][2][128];
     __shared__ int4 recP[kBandThreads];     // band-local element offsets of the 4 (or 2) corners
     __shared__ float4 recW[kBandThreads];   // corner weight x attention weight
     __shared__ int recQ[kBandThreads];      // (b, q, h) group index: row of g_out
 
-    const int bh = blockIdx.x / plan.items, item = blockIdx.x - bh * plan.items;
+    const int item = blockIdx.x;
+    if (item >= item0[n_bands]) return;
+    int lo_b = 0, hi_b = n_bands;           // largest band id with item0[id] <= item (uniform: scalar loads)
+    while (hi_b - lo_b > 1) {
+        const int mid = (lo_b + hi_b) >> 1;
+        if (item0[mid] <= item) lo_b = mid; else hi_b = mid;
+    }
+    const int band_id = lo_b;
+    const int segi = item - item0[band_id];
+    const int bh = band_id / plan.nbands, rb = band_id - bh * plan.nbands;
     const int h = bh % dm.heads, b = bh / dm.heads;
     int l = 0;
-    for (int k = 1; k < dm.L; ++k) l += (item >= plan.prefix[k]);
-    int rows_l = plan.rows[0], chunks_l = plan.chunks[0], first = 0;
+    for (int k = 1; k < dm.L; ++k) l += (rb >= plan.band0[k]);
+    int rows_l = plan.rows[0], first = 0;
     for (int k = 1; k < 8; ++k)
-        if (k == l) { rows_l = plan.rows[k]; chunks_l = plan.chunks[k]; first = plan.prefix[k]; }
-    const int r = item - first;
-    const int band = r / chunks_l, chunk = r - band * chunks_l;
+        if (k == l) { rows_l = plan.rows[k]; first = plan.band0[k]; }
+    const int band = rb - first;
     const int Hl = shapes[2 * l], Wl = shapes[2 * l + 1];
     const int y0 = band * rows_l, y1 = min(Hl, y0 + rows_l);
     const int n_tile = (y1 - y0) * Wl * D;
-    const int qper = (dm.nq + chunks_l - 1) / chunks_l;
-    const int qa = min(dm.nq, chunk * qper), qb = min(dm.nq, qa + qper);
+    const int cF = cnt[2 * band_id], cE = cnt[2 * band_id + 1];
+    const int32_t *mine = list + off[2 * band_id];        // FULL entries [0, cF), EDGE entries [cF, cF + cE)
+    const int s0 = segi * plan.seg, s1 = min(cF + cE, s0 + plan.seg);
 
     for (int e = threadIdx.x; e < n_tile; e += kBandThreads) tile[e] = 0.0;
     __syncthreads();
@@ -1090,17 +1239,16 @@ __global__ __launch_bounds__(kBandThreads) void msda_bwd_band_kernel(const int32
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wave0 = threadIdx.x & ~63;
     const int sub = lane % D, row = lane / D;
     const long long kbase = (((long long)b * dm.heads + h) * dm.L + l) * (long long)dm.nq * dm.P;
-    int head0 = 0, head1 = 0, tail0 = 0, tail1 = 0;   // wave-uniform ring cursors (FULL, EDGE)
 
-    // the n <= 64 oldest hits of ring c -> band
-    auto process = [&](auto cls, int n) {
+    // n <= 64 list entries starting at `pos` -> band
+    auto process = [&](auto cls, int pos, int n) {
         constexpr int C = decltype(cls)::value;     // 0: FULL, 1: EDGE
         float4 w4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         int4 p4 = make_int4(0, 0, 0, 0);
         int gq32 = 0;
         if (lane < n) {
-            const int e = ring[wv][C][((C == 0 ? head0 : head1) + lane) & 127];
-            const int q = e / dm.P;
+            const int e = mine[pos + lane];
+            const int q = so_fastdiv(e, plan.divP);
             const float4 rc = recs[kbase + e];
             const int hw_ = __float_as_int(rc.w);
             const int h_low = hw_ >> 16, w_low = (int)(short)(hw_ & 0xffff);
@@ -1109,19 +1257,17 @@ __global__ __launch_bounds__(kBandThreads) void msda_bwd_band_kernel(const int32
             const bool c0 = w_low >= 0, c1 = w_low + 1 <= Wl - 1;
             const int x0 = max(w_low, 0), x1 = min(w_low + 1, Wl - 1);
             if (C == 0) {
-                // rows h_low and h_low + 1 are both inside [y0, y1) (hence inside the map)
                 const int r0 = (h_low - y0) * Wl, r1 = r0 + Wl;
                 w4 = make_float4(c0 ? (hh * hw) * aw : 0.0f, c1 ? (hh * lw) * aw : 0.0f,
                                  c0 ? (lh * hw) * aw : 0.0f, c1 ? (lh * lw) * aw : 0.0f);
                 p4 = make_int4((r0 + x0) * D, (r0 + x1) * D, (r1 + x0) * D, (r1 + x1) * D);
             } else {
-                // one corner row inside the band: the lower one (h_low + 1 == y0) or the upper one (h_low == y1 - 1)
+                // the one corner row inside the band: the lower one (h_low + 1 == y0) or the upper one (h_low == y1 - 1)
                 const bool lower = h_low < y0;
                 const int ry = lower ? h_low + 1 : h_low;
-                const bool rv = ry >= 0 && ry <= Hl - 1;                 // always true by construction of the key test
                 const float wy = lower ? lh : hh;
                 const int r0 = (ry - y0) * Wl;
-                w4 = make_float4((rv && c0) ? (wy * hw) * aw : 0.0f, (rv && c1) ? (wy * lw) * aw : 0.0f, 0.0f, 0.0f);
+                w4 = make_float4(c0 ? (wy * hw) * aw : 0.0f, c1 ? (wy * lw) * aw : 0.0f, 0.0f, 0.0f);
                 p4 = make_int4((r0 + x0) * D, (r0 + x1) * D, 0, 0);
             }
             gq32 = dm.go_shared ? q * dm.heads + h : (int)(((long long)b * dm.nq + q) * dm.heads + h);
@@ -1147,84 +1293,15 @@ __global__ __launch_bounds__(kBandThreads) void msda_bwd_band_kernel(const int32
                 unsafeAtomicAdd(&tile[ps.w + sub], (double)(ws.w * goc[j]));
             }
         }
-        __builtin_amdgcn_wave_barrier();
-    };
-    auto drain_full = [&](int n) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        process(std::integral_constant<int, 0>{}, n);
-        head0 += n;
     };
-    auto drain_edge = [&](int n) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        process(std::integral_constant<int, 1>{}, n);
-        head1 += n;
-    };
-
-    // stream this level's keys of the chunk's queries, 8 keys (16 bytes) per lane and step
-    const long long lo = kbase + (long long)qa * dm.P, hi = kbase + (long long)qb * dm.P;
-    const int klo = y0 - 1, khi = y1 - 1;
-    const int4 none = make_int4((int)0x80008000, (int)0x80008000, (int)0x80008000, (int)0x80008000);
-    const long long step = (long long)kBandThreads * 8;
-    long long pos = (lo & ~7LL) + (long long)threadIdx.x * 8;
-    // can the 512 keys this wave looks at in the step that starts at p touch the band?  (row range of the
-    // 64-query blocks they belong to; wave-uniform)
-    const int32_t *rng = ranges + (((long long)b * dm.heads + h) * dm.L + l) * nqb;
-    auto relevant = [&](long long p) -> bool {
-        const long long w0 = p + (long long)wave0 * 8;                 // first key of this wave in the step
-        if (w0 >= hi) return false;
-        const long long e0 = max(w0, lo) - kbase, e1 = min(w0 + 511, hi - 1) - kbase;
-        if (e1 < e0) return false;
-        const int b0 = (int)(e0 / dm.P) / kRangeQueries, b1 = (int)(e1 / dm.P) / kRangeQueries;
-        bool hit = false;
-        for (int qb = b0; qb <= b1; ++qb) {
-            const int r = __builtin_amdgcn_readfirstlane(rng[qb]);
-            const int mn = r >> 16, mx = (int)(short)(r & 0xffff);
-            hit |= (mx >= klo) && (mn <= khi);
-        }
-        return hit;
-    };
-    const long long p0 = lo & ~7LL;
-    bool rel_cur = relevant(p0);
-    int4 cur = (rel_cur && pos < hi) ? *(const int4 *)(keys + pos) : none;
-    for (long long bp = p0; bp < hi; bp += step) {   // uniform trip count
-        const bool rel_nxt = relevant(bp + step);
-        const int4 nxt = (rel_nxt && pos + step < hi) ? *(const int4 *)(keys + pos + step) : none;
-        if (!rel_cur) {   // wave-uniform: none of this wave's keys can touch the band
-            cur = nxt; rel_cur = rel_nxt; pos += step;
-            continue;
-        }
-        const unsigned long long k03 = ((unsigned long long)(unsigned)cur.y << 32) | (unsigned)cur.x;
-        const unsigned long long k47 = ((unsigned long long)(unsigned)cur.w << 32) | (unsigned)cur.z;
-#pragma unroll 1
-        for (int k = 0; k < 8; ++k) {   // not unrolled: process() is large
-            const int key = (int)(short)(((k & 4) ? k47 : k03) >> (16 * (k & 3)));
-            const long long gi = pos + k;
-            const bool hit = key >= klo && key <= khi && gi >= lo && gi < hi;
-            const bool edge = key == klo || key == khi;
-            const unsigned long long mf = __ballot(hit && !edge), me = __ballot(hit && edge);
-            if ((mf | me) == 0ULL) continue;   // uniform
-            if (hit) {
-                const unsigned long long mm = edge ? me : mf;
-                const int pre = __builtin_amdgcn_mbcnt_hi((unsigned)(mm >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mm, 0));
-                if (edge) ring[wv][1][(tail1 + pre) & 127] = (int)(gi - kbase);
-                else ring[wv][0][(tail0 + pre) & 127] = (int)(gi - kbase);
-            }
-            tail0 += __popcll(mf);
-            tail1 += __popcll(me);
-            if (tail0 - head0 >= 64) drain_full(64);
-            if (tail1 - head1 >= 64) drain_edge(64);
-        }
-        cur = nxt;
-        rel_cur = rel_nxt;
-        pos += step;
-    }
-    if (tail0 > head0) drain_full(tail0 - head0);
-    if (tail1 > head1) drain_edge(tail1 - head1);
+    const int f0 = s0, f1 = min(s1, cF);              // FULL part of the segment
+    for (int p = f0 + wv * 64; p < f1; p += NW * 64) process(std::integral_constant<int, 0>{}, p, min(64, f1 - p));
+    const int e0 = max(s0, cF), e1 = s1;              // EDGE part
+    for (int p = e0 + wv * 64; p < e1; p += NW * 64) process(std::integral_constant<int, 1>{}, p, min(64, e1 - p));
     __syncthreads();
 
-    // flush: consecutive lanes = consecutive channels of consecutive pixels of the band
     const int pix_stride = so_pix_stride(dm, D);
     float *gl = g_value + so_value_base(dm, D, b, h, (long long)starts[l] + (long long)y0 * Wl);
     for (int e = threadIdx.x; e < n_tile; e += kBandThreads) {
@@ -1452,12 +1529,15 @@ extern "C" int selfocc_msda_bwd(const float *value, const int32_t *shapes, const
 
 // ---- banded backward -------------------------------------------------------------------------
 static size_t so_band_key_bytes(long long n_pts) { return (size_t)((n_pts + 8) * 2 + 15) / 16 * 16; }
-static size_t so_band_range_bytes(int bs, int nq, int heads, int L) {
-    return ((size_t)bs * heads * L * ((nq + kRangeQueries - 1) / kRangeQueries) * 4 + 15) / 16 * 16;
+// counters of the binned scatter: cnt / cursor / off per bucket (2 per band), item0 per band (+ 1)
+static size_t so_bin_counter_bytes(int bs, int heads, int L) {
+    const size_t nb = (size_t)bs * heads * L * kMaxBands;
+    return ((7 * nb + 1) * 4 + 15) / 16 * 16;
 }
+// per point: 2 (key) + 16 (record) + 8 (index lists: a point is in <= 2 bands) bytes
 static size_t so_band_ws_bytes(int bs, int nq, int heads, int L, int P) {
     const long long n_pts = (long long)bs * nq * heads * L * P;
-    return so_band_key_bytes(n_pts) + (size_t)n_pts * 16 + so_band_range_bytes(bs, nq, heads, L);
+    return so_band_key_bytes(n_pts) + (size_t)n_pts * 16 + so_bin_counter_bytes(bs, heads, L) + (size_t)n_pts * 8;
 }
 
 extern "C" size_t selfocc_msda_bwd_banded_workspace(int32_t bs, int32_t nq, int32_t heads, int32_t L, int32_t P) {
@@ -1467,68 +1547,60 @@ extern "C" size_t selfocc_msda_bwd_banded_workspace(int32_t bs, int32_t nq, int3
 
 namespace {
 struct BandSetup {
-    MsdaBandPlan plan;
-    int max_tile_px;
+    MsdaBinPlan bin;
     int threads;   // block shape of the band kernel (512 / 1024)
-    bool ok;     // false: a level is wider than the LDS tile / the maps are huge relative to the points
+    int tile_px;   // pixels of the largest band
+    bool ok;       // false: a level is wider than the LDS tile or needs > kMaxBands bands, or the index space overflows
 };
 
-// work decomposition: bands of rows that fit the LDS tile, query chunks to even out the load
-int so_band_setup_shape(const int32_t *host_shapes, int bs, int nq, int heads, int d, int L, int P, int threads,
-                        BandSetup &bsu) {
-    MsdaBandPlan &plan = bsu.plan;
-    bsu.threads = threads;
-    const int cap_px = band_tile_bytes(threads) / (8 * d);
-    long long exam = 0;
-    int items = 0;
-    bsu.max_tile_px = 0;
+int so_env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+// bands: as many rows as the tile holds (the fewer bands, the fewer points straddle two)
+int so_band_setup(const int32_t *host_shapes, int bs, int nq, int heads, int d, int L, int P, BandSetup &bsu) {
+    // tuning switches (A/B runs): block shape 512 / 1024, list entries per block
+    static const int env_threads = so_env_int("SELFOCC_BAND_THREADS", 512), env_seg = so_env_int("SELFOCC_BAND_SEG", 4096);
+    MsdaBinPlan &bp = bsu.bin;
+    bsu.threads = env_threads == 1024 ? 1024 : 512;
+    const int cap_px = band_tile_bytes(bsu.threads) / (8 * d);
     bsu.ok = L <= 8;
-    for (int l = 0; l < 8; ++l) { plan.rows[l] = 1; plan.bands[l] = 0; plan.chunks[l] = 1; plan.prefix[l] = 0; }
+    bsu.tile_px = 0;
+    int nb = 0;
+    for (int l = 0; l < 8; ++l) { bp.rows[l] = 1; bp.bands[l] = 0; bp.band0[l] = 0; }
     for (int l = 0; l < L && bsu.ok; ++l) {
         const int Hl = host_shapes[2 * l], Wl = host_shapes[2 * l + 1];
         SO_REQUIRE(Hl >= 0 && Wl >= 0 && Hl < 32767 && Wl < 32767, "msda banded: bad level shape (%d, %d)", Hl, Wl);
-        plan.prefix[l] = items;
+        bp.band0[l] = nb;
         if (Hl == 0 || Wl == 0) continue;
         if (Wl > cap_px) { bsu.ok = false; break; }
-        plan.rows[l] = std::min(Hl, cap_px / Wl);
-        plan.bands[l] = (Hl + plan.rows[l] - 1) / plan.rows[l];
-        const double pts = (double)nq * P;   // points of this level per (batch, head)
-        const double hits = pts * std::min(1.0, (plan.rows[l] + 1.0) / Hl);
-        int ch = (int)(hits / 8192.0 + 0.5);
-        ch = std::max(1, std::min(ch, std::min(nq, 256)));
-        plan.chunks[l] = ch;
-        items += plan.bands[l] * ch;
-        exam += (long long)plan.bands[l] * nq * P;
-        bsu.max_tile_px = std::max(bsu.max_tile_px, plan.rows[l] * Wl);
+        bp.rows[l] = std::min(Hl, cap_px / Wl);
+        bp.bands[l] = (Hl + bp.rows[l] - 1) / bp.rows[l];
+        if (bp.bands[l] > kMaxBands) { bsu.ok = false; break; }
+        nb += bp.bands[l];
+        bsu.tile_px = std::max(bsu.tile_px, bp.rows[l] * Wl);
     }
-    for (int l = L; l <= 8; ++l) plan.prefix[std::min(l, 8)] = items;
-    plan.items = items;
-    // very large maps with few queries: scanning every band's keys would cost more than the atomics
-    if (items == 0 || exam > 256LL * L * nq * P || (long long)bs * heads * items >= (1LL << 31) ||
+    for (int l = L; l <= 8; ++l) bp.band0[std::min(l, 8)] = nb;
+    bp.nbands = nb;
+    bp.seg = std::max(64, env_seg);
+    int lg = 0;
+    while ((1LL << lg) < P) ++lg;
+    bp.divP.l = lg;
+    bp.divP.m = (unsigned)((((1ULL << lg) - (unsigned)P) << 32) / (unsigned)P + 1);
+    const long long n_pts = (long long)bs * nq * heads * L * P;
+    if (nb == 0 || (long long)bs * heads * nb >= (1LL << 28) || 2 * n_pts >= (1LL << 31) ||
         (long long)nq * P >= (1LL << 31))
         bsu.ok = false;
-    return 0;
-}
-
-// the small block shape unless a level then needs >= 100 bands (e.g. the 257 x 257 plane of the cross-view
-// self-attention: 257 one-row bands vs 86 three-row bands — every band scans the level's keys)
-int so_band_setup(const int32_t *host_shapes, int bs, int nq, int heads, int d, int L, int P, BandSetup &bsu) {
-    if (so_band_setup_shape(host_shapes, bs, nq, heads, d, L, P, 512, bsu)) return -1;
-    int most = 0;
-    for (int l = 0; l < std::min(L, 8); ++l) most = std::max(most, bsu.plan.bands[l]);
-    if (!bsu.ok || most >= 100) {
-        BandSetup big;
-        if (so_band_setup_shape(host_shapes, bs, nq, heads, d, L, P, 1024, big)) return -1;
-        if (big.ok) bsu = big;
-    }
     return 0;
 }
 
 struct BandWorkspace {
     int16_t *keys;
     float4 *recs;
-    int32_t *ranges;
-    int nqb;
+    int32_t *counters;   // cnt[2 nb] cursor[2 nb] off[2 nb] item0[nb + 1], nb = bands actually used
+    int32_t *list;       // 2 * n_pts entries
+    long long n_pts;
 };
 
 BandWorkspace so_band_workspace(void *workspace, int bs, int nq, int heads, int L, int P) {
@@ -1536,32 +1608,45 @@ BandWorkspace so_band_workspace(void *workspace, int bs, int nq, int heads, int 
     BandWorkspace w;
     w.keys = (int16_t *)workspace;
     w.recs = (float4 *)((char *)workspace + so_band_key_bytes(n_pts));
-    w.ranges = (int32_t *)((char *)w.recs + (size_t)n_pts * 16);
-    w.nqb = (nq + kRangeQueries - 1) / kRangeQueries;
+    w.counters = (int32_t *)((char *)w.recs + (size_t)n_pts * 16);
+    w.list = (int32_t *)((char *)w.counters + so_bin_counter_bytes(bs, heads, L));
+    w.n_pts = n_pts;
     return w;
 }
 
-// key ranges + band scatter (after a point kernel filled keys / recs)
+// counting sort + band scatter (after a point kernel filled keys / recs).  vis != NULL: camera loop, the keys of
+// invisible (camera, query) pairs are unwritten and must not be read (needs P >= 4, see msda_bin_kernel)
 int so_band_scatter(const int32_t *shapes, const int32_t *starts, const float *g_out, float *g_value,
-                    const BandWorkspace &w, const BandSetup &bsu, MsdaDims dm, int d, hipStream_t st) {
-    const long long rblocks = (long long)dm.bs * dm.heads * dm.L * w.nqb;
-    SO_REQUIRE(rblocks < (1LL << 31), "msda banded: grid too large");
-    const unsigned bblocks = (unsigned)((long long)dm.bs * dm.heads * bsu.plan.items);
-    const size_t shm = (size_t)bsu.max_tile_px * d * sizeof(double);
-    hipLaunchKernelGGL(msda_key_range_kernel, dim3((unsigned)((rblocks + 3) / 4)), dim3(256), 0, st, w.keys, w.ranges,
-                       dm.nq, dm.P, w.nqb, rblocks);
-#define SO_LAUNCH_T(DD, TT)                                                                                  \
-    {                                                                                                        \
-        static bool attr_set = false;                                                                        \
-        if (!attr_set) {                                                                                     \
-            (void)hipFuncSetAttribute((const void *)msda_bwd_band_kernel<DD, TT>,                            \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, band_tile_bytes(TT));      \
-            attr_set = true;                                                                                 \
-        }                                                                                                    \
-        hipLaunchKernelGGL((msda_bwd_band_kernel<DD, TT>), dim3(bblocks), dim3(TT), shm, st, shapes, starts,  \
-                           g_out, g_value, w.keys, w.recs, w.ranges, w.nqb, dm, bsu.plan);                   \
+                    const BandWorkspace &w, const BandSetup &bsu, MsdaDims dm, int d, const unsigned char *vis,
+                    hipStream_t st) {
+    const MsdaBinPlan &bp = bsu.bin;
+    const int nb = dm.bs * dm.heads * bp.nbands;                 // bands over all (batch, head)
+    int32_t *cnt = w.counters, *cursor = cnt + 2 * (size_t)nb, *off = cursor + 2 * (size_t)nb, *item0 = off + 2 * (size_t)nb;
+    const long long n = (long long)dm.nq * dm.P;
+    const int bpb = (int)((n + 3 + kBinKeysPerBlock - 1) / kBinKeysPerBlock);   // windows start 8-byte aligned: <= 3 keys early
+    const long long bin_blocks = (long long)dm.bs * dm.heads * dm.L * bpb;
+    const long long max_items = nb + (2 * w.n_pts) / bp.seg;
+    SO_REQUIRE(bin_blocks < (1LL << 31) && max_items < (1LL << 31), "msda banded: grid too large");
+    (void)hipMemsetAsync(cnt, 0, (size_t)nb * 4 * sizeof(int32_t), st);     // cnt and cursor
+    hipLaunchKernelGGL(msda_bin_kernel<false>, dim3((unsigned)bin_blocks), dim3(256), 0, st, w.keys, shapes, cnt,
+                       cursor, off, w.list, vis, bpb, dm, bp);
+    hipLaunchKernelGGL(msda_bin_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, off, item0, nb, bp.seg);
+    hipLaunchKernelGGL(msda_bin_kernel<true>, dim3((unsigned)bin_blocks), dim3(256), 0, st, w.keys, shapes, cnt,
+                       cursor, off, w.list, vis, bpb, dm, bp);
+    const size_t shm = (size_t)bsu.tile_px * d * sizeof(double);
+    // the grid is an upper bound (every point in two bands): blocks past item0[nb] return at once
+#define SO_LAUNCH_T(DD, TT)                                                                                      \
+    {                                                                                                            \
+        static bool attr_set = false;                                                                            \
+        if (!attr_set) {                                                                                         \
+            (void)hipFuncSetAttribute((const void *)msda_bwd_band_list_kernel<DD, TT>,                           \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, band_tile_bytes(TT));          \
+            attr_set = true;                                                                                     \
+        }                                                                                                        \
+        hipLaunchKernelGGL((msda_bwd_band_list_kernel<DD, TT>), dim3((unsigned)max_items), dim3(TT), shm, st,    \
+                           shapes, starts, g_out, g_value, w.recs, cnt, off, item0, w.list, nb, dm, bp);         \
     }
-#define SO_LAUNCH(DD)                                                                                        \
+#define SO_LAUNCH(DD)                                                                                            \
     if (bsu.threads == 512) SO_LAUNCH_T(DD, 512) else SO_LAUNCH_T(DD, 1024)
     switch (d) {
         case 4: SO_LAUNCH(4); break;
@@ -1622,7 +1707,7 @@ extern "C" int selfocc_msda_bwd_banded(const float *value, const int32_t *shapes
         default: SO_LAUNCH(32); break;
     }
 #undef SO_LAUNCH
-    return so_band_scatter(shapes, starts, g_out, g_value, w, bsu, dm, d, st);
+    return so_band_scatter(shapes, starts, g_out, g_value, w, bsu, dm, d, nullptr, st);
 }
 
 extern "C" int selfocc_msda_fused_bwd(const float *value, const int32_t *shapes, const int32_t *starts,
@@ -1681,7 +1766,7 @@ extern "C" int selfocc_msda_fused_bwd(const float *value, const int32_t *shapes,
     }
 #undef SO_LAUNCH
 #undef SO_LAUNCH_G
-    return so_band_scatter(shapes, starts, g_out, g_value, w, bsu, dm, d, st);
+    return so_band_scatter(shapes, starts, g_out, g_value, w, bsu, dm, d, nullptr, st);
 }
 
 
@@ -1717,8 +1802,10 @@ extern "C" int selfocc_msda_cross_bwd(const float *value, const int32_t *shapes,
     }
     MsdaDims dm{cams, nv, nq, heads, L, P, 1, 0, value_layout};
     const BandWorkspace w = so_band_workspace(workspace, cams, nq, heads, L, P);
-    // every (camera, query) the kernel does not visit stays "outside"
-    (void)hipMemsetD16Async((hipDeviceptr_t)w.keys, (unsigned short)0x8000, (size_t)n_pts, st);
+    // the point kernel writes the keys of every (camera, query) pair it visits; the bin kernels skip the others by
+    // `vis` (P >= 4), otherwise the unvisited keys are preset to "outside"
+    const unsigned char *bin_vis = P >= 4 ? vis : nullptr;
+    if (bin_vis == nullptr) (void)hipMemsetD16Async((hipDeviceptr_t)w.keys, (unsigned short)0x8000, (size_t)n_pts, st);
     int G = 1, logG = 0;
     so_pick_group_fused(LP, d, G, logG);
     const int gpb = 256 / G;
@@ -1745,5 +1832,5 @@ extern "C" int selfocc_msda_cross_bwd(const float *value, const int32_t *shapes,
     }
 #undef SO_LAUNCH
 #undef SO_LAUNCH_G
-    return so_band_scatter(shapes, starts, g_out, g_value, w, bsu, dm, d, st);
+    return so_band_scatter(shapes, starts, g_out, g_value, w, bsu, dm, d, bin_vis, st);
 }
