@@ -106,6 +106,27 @@ SO_DEVFN void so_split_group(long long gq, long long n_groups, int nq, int heads
     }
 }
 
+// Head-outer group order of the fused / camera-loop kernels: group g -> head g / (bs * nq), query g % (bs * nq), so
+// the groups of a block (and of an XCD's eighth of the grid) are CONSECUTIVE QUERIES OF ONE HEAD.  Neighbouring
+// queries sample neighbouring pixels, and only groups of the same head can share a 64-byte corner segment in L1;
+// in (query, head) order a block holds one or two queries x all heads.  Measured: camera-loop forward 0.87 -> 0.74 ms,
+// fused forward 0.50 -> 0.47 ms (scripts/bench_msda.py), eval encoder -1.3 %.  gq = (b, q, h) index (tensor order).
+SO_DEVFN void so_split_group_head_outer(long long g, const MsdaDims &dm, int &h, int &b, long long &bq, long long &gq) {
+    const long long nbq = (long long)dm.bs * dm.nq;
+    if (nbq * dm.heads < (1LL << 31)) {
+        const unsigned hh = (unsigned)g / (unsigned)nbq;
+        const unsigned q = (unsigned)g - hh * (unsigned)nbq;
+        h = (int)hh;
+        bq = q;
+        b = (int)(q / (unsigned)dm.nq);
+    } else {
+        h = (int)(g / nbq);
+        bq = g - h * nbq;
+        b = (int)(bq / dm.nq);
+    }
+    gq = bq * dm.heads + h;
+}
+
 // XCD-aware block order.  Workgroup b is observed to run on XCD b % 8, each XCD with its own 4 MB L2.  With the
 // plain order consecutive queries — which sample neighbouring pixels — are dealt round-robin to the 8 XCDs, so every
 // L2 sees the whole 10-60 MB value map; here XCD x works on ONE contiguous eighth of the (query, head) groups and
@@ -272,10 +293,9 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const float *__restrict__
     const long long gid = (long long)so_xcd_block() * groups_per_block + (threadIdx.x / G);
     const int gl = threadIdx.x & (G - 1);
     const bool live = gid < n_groups;  // whole groups are live or dead; exchanges stay in-group
-    const long long gq = live ? gid : 0;
     int h, b;
-    long long bq;
-    so_split_group(gq, n_groups, dm.nq, dm.heads, h, b, bq);
+    long long bq, gq;
+    so_split_group_head_outer(live ? gid : 0, dm, h, b, bq, gq);
     const int pix_stride = so_pix_stride(dm, D);
     const int s = gl & (QL - 1);
     const float *vb = value + so_value_base(dm, D, b, h, 0) + 4 * s;
@@ -327,10 +347,9 @@ __global__ __launch_bounds__(256, SO_MSDA_FWD_WAVES(D)) void msda_fused_fwd_kern
     const long long gid = (long long)so_xcd_block() * groups_per_block + (threadIdx.x / G);
     const int gl = threadIdx.x & (G - 1);
     const bool live = gid < n_groups;
-    const long long gq = live ? gid : 0;
     int h, b;
-    long long bq;                                       // b * nq + q
-    so_split_group(gq, n_groups, dm.nq, dm.heads, h, b, bq);
+    long long bq, gq;                                   // b * nq + q; (b, q, h) index of the group
+    so_split_group_head_outer(live ? gid : 0, dm, h, b, bq, gq);
     const int pix_stride = so_pix_stride(dm, D);
     const int s = gl & (QL - 1);
     const float *vb = value + so_value_base(dm, D, b, h, 0) + 4 * s;
@@ -415,8 +434,9 @@ __global__ __launch_bounds__(256, SO_MSDA_FWD_WAVES(D)) void msda_cross_fwd_kern
     const int gid = (int)so_xcd_block() * groups_per_block + (threadIdx.x / G);
     const int gl = threadIdx.x & (G - 1);
     const bool live = gid < n_groups;
-    const int gq = live ? gid : 0;
-    const int q = gq / dm.heads, h = gq - q * dm.heads;
+    const int gq0 = live ? gid : 0;                            // head-outer order, see so_split_group_head_outer
+    const int h = gq0 / dm.nq, q = gq0 - h * dm.nq;
+    const int gq = q * dm.heads + h;
     const int pix_stride = so_pix_stride(dm, D);     // `value` may be head-major or a column block of a wider matrix
     const int s = gl & (QL - 1);
     const float *vb = value + so_value_base(dm, D, 0, h, 0) + 4 * s;
@@ -782,10 +802,9 @@ __global__ __launch_bounds__(256) void msda_fused_bwd_point_kernel(const float *
     const long long gid = (long long)so_xcd_block() * groups_per_block + (threadIdx.x / G);
     const int gl = threadIdx.x & (G - 1);
     const bool live = gid < n_groups;
-    const long long gq = live ? gid : 0;
     int h, b;
-    long long bq;                                       // b * nq + q
-    so_split_group(gq, n_groups, dm.nq, dm.heads, h, b, bq);
+    long long bq, gq;                                   // b * nq + q; (b, q, h) index of the group
+    so_split_group_head_outer(live ? gid : 0, dm, h, b, bq, gq);
     const int q = (int)(bq - (long long)b * dm.nq);
     const int pix_stride = so_pix_stride(dm, D);
     const int s = gl & (QL - 1);
@@ -906,8 +925,9 @@ __global__ __launch_bounds__(256) void msda_cross_bwd_point_kernel(const float *
     const int gid = (int)so_xcd_block() * groups_per_block + (threadIdx.x / G);
     const int gl = threadIdx.x & (G - 1);
     const bool live = gid < n_groups;
-    const int gq = live ? gid : 0;
-    const int q = gq / dm.heads, h = gq - q * dm.heads;
+    const int gq0 = live ? gid : 0;                            // head-outer order, see so_split_group_head_outer
+    const int h = gq0 / dm.nq, q = gq0 - h * dm.nq;
+    const int gq = q * dm.heads + h;
     const int pix_stride = so_pix_stride(dm, D);
     const int s = gl & (QL - 1);
 
