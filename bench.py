@@ -43,12 +43,19 @@ def algorithmic_bytes(vol, n_rays, n_sem):
 
 
 def kernel_source_hash():
-    """sha1 (12 hex) of the render kernel's sources: ties a PMC record in profiles/pmc_traffic.json to the
-    kernel it was measured on (scripts/pmc.sh writes the same hash next to the counters)."""
+    """sha1 (12 hex) of what the render kernel is compiled from — render_fwd.hip, so_device.h and the part of the
+    public header it sees (the SO_FLAG_* enum and struct so_render_args): ties a PMC record in
+    profiles/pmc_traffic.json to the kernel it was measured on (scripts/pmc.sh writes the same hash next to the
+    counters).  Header changes for other entry points (MSDA, LayerNorm ...) do not change the render kernel."""
     import hashlib
+    import re
     h = hashlib.sha1()
-    for f in ("selfocc_amd/csrc/render_fwd.hip", "selfocc_amd/csrc/so_device.h", "include/selfocc_hip.h"):
+    for f in ("selfocc_amd/csrc/render_fwd.hip", "selfocc_amd/csrc/so_device.h"):
         h.update(open(os.path.join(ROOT, f), "rb").read())
+    hdr = open(os.path.join(ROOT, "include", "selfocc_hip.h")).read()
+    m = re.search(r"typedef struct so_render_args \{.*?\} so_render_args;", hdr, re.S)
+    h.update(m.group(0).encode())
+    h.update("\n".join(l for l in hdr.splitlines() if "SO_FLAG_" in l).encode())
     return h.hexdigest()[:12]
 
 
