@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SELFOCC_ABI_VERSION 18
+#define SELFOCC_ABI_VERSION 19
 
 int selfocc_abi_version(void);
 const char *selfocc_last_error(void);
@@ -390,6 +390,19 @@ size_t selfocc_layernorm_bwd_workspace(int64_t rows, int32_t C);
 int selfocc_layernorm_bwd(const float *x, const float *gamma, const float *mean, const float *rstd,
                           const float *dy, float *dx, float *dgamma, float *dbeta, int64_t rows, int32_t C,
                           void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Weight and bias gradient of a Linear layer with very many rows (the encoder's projections: 66 k - 180 k rows,
+ * K = 96 / 192 inputs, N = 96 .. 2304 outputs; torch autograd through mmcv / nn.Linear in the reference, e.g.
+ * model/encoder/tpvformer/attention/image_cross_attention.py:130-160) in one pass over dy and x:
+ *     dw (N, K) = dy (T, N)^T x (T, K)          db (N) = column sums of dy   (db may be NULL)
+ * float32 (MFMA f32 = exact fmaf chains), deterministic (fixed summation order).  K must be 32, 64, 96, 128 or 192
+ * (selfocc_linear_wgrad_supported); workspace = selfocc_linear_wgrad_workspace(T, N, K) bytes of device scratch.
+ * ---------------------------------------------------------------------------------- */
+int selfocc_linear_wgrad_supported(int64_t T, int32_t N, int32_t K);
+size_t selfocc_linear_wgrad_workspace(int64_t T, int32_t N, int32_t K);
+int selfocc_linear_wgrad(const float *dy, const float *x, float *dw, float *db, int64_t T, int32_t N, int32_t K,
+                         void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Fused temporal reprojection photometric term.  Replaces the per-sample part of

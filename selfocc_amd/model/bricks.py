@@ -9,6 +9,7 @@ import torch
 import torch.nn as nn
 
 from ..registry import MODELS
+from ..linear import linear_wgrad, wgrad_supported
 from ..msda import (MultiScaleDeformableAttnFunction, msda_fused_inference, MSDAFusedFunction, to_head_major,
                     msda_fused_supported)
 
@@ -108,6 +109,10 @@ def build_activation_layer(cfg):
     raise NotImplementedError(typ)
 
 
+# weight / bias gradients of _TallLinear through selfocc_linear_wgrad (False: batched GEMMs + torch reductions, A/B)
+FUSED_WGRAD = True
+
+
 class _TallLinear(torch.autograd.Function):
     """y = x W^T + b for x with millions of rows and a handful of output features.  The vendor
     GEMM picked for the weight gradient dW = dy^T x of such a shape (25 x 1.65 M x 96 at the shipped
@@ -128,6 +133,11 @@ class _TallLinear(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         dy = dy.contiguous().to(x.dtype)
         T = x.shape[0]
+        if (FUSED_WGRAD and dy.is_cuda and dy.dtype == torch.float32 and T > 0
+                and wgrad_supported(T, dy.shape[1], x.shape[1])):
+            # one MFMA pass over dy and x for dW and db (csrc/linear.hip) instead of batched GEMMs + two reductions
+            dw, db = linear_wgrad(dy, x, ctx.has_bias)
+            return dy @ weight, dw, db
         G = max(1, min(256, T // 2048))  # ~2 k+ rows per batched GEMM: enough workgroups, small partial-sum tensor
         R = T // G                       # rows per batched GEMM
         Tp = R * G
