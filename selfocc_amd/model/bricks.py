@@ -165,7 +165,7 @@ class TallLinear(nn.Linear):
     when the input has many rows: the encoder's projections see 66 k - 153 k rows x 96 features, and the
     vendor GEMM chosen for their weight gradients (K = rows, 96 x 96 .. 96 x 2304 outputs) runs on a
     handful of workgroups (MT32x32x256: 0.3 ms x 32 calls per nuscenes_occ iteration)."""
-    min_rows = 8192
+    min_rows = 4096
 
     def forward(self, x):
         rows = x.numel() // max(x.shape[-1], 1)
