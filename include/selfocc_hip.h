@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SELFOCC_ABI_VERSION 19
+#define SELFOCC_ABI_VERSION 20
 
 int selfocc_abi_version(void);
 const char *selfocc_last_error(void);
@@ -390,6 +390,20 @@ size_t selfocc_layernorm_bwd_workspace(int64_t rows, int32_t C);
 int selfocc_layernorm_bwd(const float *x, const float *gamma, const float *mean, const float *rstd,
                           const float *dy, float *dx, float *dgamma, float *dbeta, int64_t rows, int32_t C,
                           void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * point_sampling of the TPV / BEV encoders (model/encoder/bevformer/utils.py:114-170): project the pillar reference
+ * points into every camera.
+ *   ref (B, D, Q, 3) metres; lidar2img (B, N, 4, 4) row-major; focal_x / focal_y (N) or NULL (the reference's
+ *   optional `focal_ratios_*` metas); img_h / img_w = metas['img_shape'][:2]
+ *   cam (N, B, Q, D, 2): (u / img_w, v / img_h) (x focal ratios), u = c0 / max(c2, 1e-5), c = lidar2img (x, y, z, 1)
+ *   mask (N, B, Q, D) u8: c2 > 1e-5 and 0 < u, v < 1 (before the focal ratios, as in the reference)
+ *   visible (N, B, Q) u8 or NULL: mask.any(-1)
+ * The image-augmentation branch (post_rots / post_trans) stays host-side torch.
+ * ---------------------------------------------------------------------------------- */
+int selfocc_point_sampling(const float *ref, const float *lidar2img, const float *focal_x, const float *focal_y,
+                           float *cam, uint8_t *mask, uint8_t *visible, int32_t B, int32_t D, int32_t Q, int32_t N,
+                           float img_h, float img_w, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Weight and bias gradient of a Linear layer with very many rows (the encoder's projections: 66 k - 180 k rows,

@@ -175,7 +175,8 @@ class BEVCrossAttention(BaseModule):
                 v = to_head_major(v)
         off = da.sampling_offsets(query[0]).view(-1, heads, L, P, 2)
         logits = da.attention_weights(query[0]).view(-1, heads, L * P)
-        visible = bev_masks[:, 0].any(-1)                                   # (cams, Q), batch element 0 as the reference
+        vis_all = getattr(bev_masks, '_so_visible', None)                   # left by the HIP point_sampling
+        visible = vis_all[:, 0] if vis_all is not None else bev_masks[:, 0].any(-1)   # (cams, Q), batch element 0 as the reference
         if host_shapes is None:
             slots = msda_cross_inference(v, spatial_shapes, level_start_index, reference_points_cams[:, 0], visible,
                                          off, logits, hm)[None]

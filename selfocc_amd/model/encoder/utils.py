@@ -29,12 +29,39 @@ def _stack_meta(img_metas, key, like):
 
 
 @torch.autocast("cuda", enabled=False)
+def _point_sampling_hip(reference_points, lidar2img, img_metas):
+    """One HIP pass (selfocc_point_sampling, csrc/geometry.hip) instead of ~25 broadcast torch kernels; also
+    leaves ``mask._so_visible`` = mask.any(-1), which the camera-loop attention would otherwise reduce per layer."""
+    from ..._lib import lib, check, ptr, current_stream
+    B, D, Q, _ = reference_points.shape
+    N = lidar2img.shape[1]
+    ref = reference_points.contiguous()
+    l2i = lidar2img.contiguous()
+    dev = ref.device
+    cam = torch.empty(N, B, Q, D, 2, device=dev, dtype=torch.float32)
+    mask = torch.empty(N, B, Q, D, device=dev, dtype=torch.bool)
+    visible = torch.empty(N, B, Q, device=dev, dtype=torch.bool)
+    fx = fy = None
+    if 'focal_ratios_x' in img_metas[0]:
+        fx = torch.as_tensor(np.asarray(img_metas[0]['focal_ratios_x']), dtype=torch.float32).to(dev).contiguous()
+        fy = torch.as_tensor(np.asarray(img_metas[0]['focal_ratios_y']), dtype=torch.float32).to(dev).contiguous()
+        assert fx.numel() == N and fy.numel() == N
+    h, w = img_metas[0]['img_shape'][0], img_metas[0]['img_shape'][1]
+    check(lib().selfocc_point_sampling(ptr(ref), ptr(l2i), ptr(fx), ptr(fy), ptr(cam), ptr(mask), ptr(visible), B, D, Q, N,
+                                       float(h), float(w), current_stream(dev)), "selfocc_point_sampling")
+    mask._so_visible = visible
+    return cam, mask
+
+
 def point_sampling(reference_points, img_metas):
     """Project 3-D reference points (B, D, Q, 3) into every camera.
     Returns reference_points_cam (N, B, Q, D, 2) in [0,1] image coordinates and the
     visibility mask (N, B, Q, D).  Always float32 (bevformer/utils.py:114-117)."""
     reference_points = reference_points.float()
     lidar2img = _stack_meta(img_metas, 'lidar2img', reference_points).float()   # (B, N, 4, 4)
+    aug0 = img_metas[0].get('img_augmentation') if isinstance(img_metas[0], dict) else None
+    if reference_points.is_cuda and not (aug0 is not None and 'post_rots' in aug0 and 'post_trans' in aug0):
+        return _point_sampling_hip(reference_points, lidar2img, img_metas)
     pts = torch.cat((reference_points, torch.ones_like(reference_points[..., :1])), -1)
     pts = pts.permute(1, 0, 2, 3)                                               # (D, B, Q, 4)
     D, B, Q = pts.shape[:3]

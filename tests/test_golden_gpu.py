@@ -238,3 +238,33 @@ def test_segmentor_protocol_replay_over_our_modules(hip, mode):
             assert results['sdf'].shape == (32, 32, 7) and results['sem'].shape == (32, 32, 7)
     finally:
         os.environ['eval'] = 'false'
+
+
+def test_point_sampling_hip_vs_reference(hip):
+    """selfocc_point_sampling (one HIP pass, csrc/geometry.hip) == the reference's point_sampling
+    (model/encoder/bevformer/utils.py, fixtures from the imported reference function) incl. the focal ratios, and the
+    `visible` side output == mask.any(-1); also bit-identical to this repo's host-side torch path at a larger size."""
+    from selfocc_amd.model.encoder.utils import point_sampling
+    geo = np.load(os.path.join(G, "geometry.npz"))
+    metas = [dict(lidar2img=geo['ps.lidar2img'], img_shape=(224, 400))]
+    ref = torch.tensor(geo['ps.ref3d'])
+    cam, mask = point_sampling(ref.cuda(), metas)
+    assert cam.is_contiguous() and mask.is_contiguous() and mask.dtype == torch.bool
+    assert torch.equal(mask.cpu(), torch.tensor(geo['ps.mask']))
+    assert torch.allclose(cam.cpu(), torch.tensor(geo['ps.cam']), rtol=1e-6, atol=1e-6)
+    assert torch.equal(mask._so_visible.cpu(), torch.tensor(geo['ps.mask']).any(-1))
+    metas[0].update(focal_ratios_x=[1.0, 1.1, 0.9], focal_ratios_y=[1.0, 0.95, 1.05])
+    cam2, _ = point_sampling(ref.cuda(), metas)
+    assert torch.allclose(cam2.cpu(), torch.tensor(geo['ps.cam_focal']), rtol=1e-6, atol=1e-6)
+    # larger, random: HIP vs the torch path (same operation order => same bits)
+    g = torch.Generator().manual_seed(3)
+    B, D, Q, N = 2, 7, 1500, 5
+    ref = torch.rand(B, D, Q, 3, generator=g) * 80 - 40
+    l2i = torch.randn(B, N, 4, 4, generator=g)
+    l2i[..., 3, :] = torch.tensor([0.0, 0.0, 0.0, 1.0])
+    metas = [dict(lidar2img=l2i[b].numpy(), img_shape=(450, 800)) for b in range(B)]
+    c_cpu, m_cpu = point_sampling(ref, metas)
+    c_gpu, m_gpu = point_sampling(ref.cuda(), metas)
+    assert torch.equal(m_gpu.cpu(), m_cpu)
+    assert torch.equal(c_gpu.cpu(), c_cpu)
+    assert torch.equal(m_gpu._so_visible.cpu(), m_cpu.any(-1))
