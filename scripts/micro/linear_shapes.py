@@ -5,7 +5,8 @@ d = torch.device("cuda:0")
 shapes = [("self off", 78899, 96, 432), ("self aw", 78899, 96, 216), ("self val/out", 78899, 96, 96),
           ("hw off", 66049, 96, 384), ("hw aw", 66049, 96, 192), ("hw out", 66049, 96, 96),
           ("zh off", 7967, 96, 2304), ("zh aw", 7967, 96, 1152), ("zh out", 7967, 96, 96),
-          ("cross val x3", 178500, 96, 288), ("ffn1", 78899, 96, 192), ("ffn2", 78899, 192, 96)]
+          ("cross val x3", 178500, 96, 288), ("ffn1", 78899, 96, 192), ("ffn2", 78899, 192, 96),
+          ("self off+aw", 78899, 96, 648), ("hw off+aw", 66049, 96, 576), ("zh off+aw", 7967, 96, 3456)]
 tot = 0.0
 for name, T, K, N in shapes:
     x = torch.randn(T, K, device=d); w = torch.randn(N, K, device=d); b = torch.randn(N, device=d)
