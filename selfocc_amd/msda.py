@@ -24,8 +24,7 @@ def _prep(value, spatial_shapes, level_start_index, sampling_locations, attentio
     # mmcv casts locations / weights to value's dtype (amp switch = dtype of value)
     loc = sampling_locations.contiguous().float()
     aw = attention_weights.contiguous().float()
-    sh = spatial_shapes.to(device=value.device, dtype=torch.int32).contiguous()
-    st = level_start_index.to(device=value.device, dtype=torch.int32).contiguous()
+    sh, st = _i32(spatial_shapes, value.device), _i32(level_start_index, value.device)
     return value, sh, st, loc, aw, (bs, nv, nq, heads, d, L, P)
 
 
@@ -94,6 +93,27 @@ def multi_scale_deformable_attn(value, spatial_shapes, level_start_index, sampli
                                                   sampling_locations, attention_weights, 64)
 
 
+def _i32(t, device):
+    """int32 device copy of a small index tensor (level shapes / starts), cached on the tensor object: the same
+    constants go through 16 MSDA calls per frame and each conversion is a kernel launch."""
+    if t.dtype == torch.int32 and t.device == device and t.is_contiguous():
+        return t
+    c = getattr(t, '_so_i32', None)
+    if c is None or c[0] != t._version or c[1].device != device:
+        c = (t._version, t.to(device=device, dtype=torch.int32).contiguous())
+        try:
+            t._so_i32 = c
+        except AttributeError:
+            pass
+    return c[1]
+
+
+def _u8(mask):
+    """bool / uint8 mask as contiguous uint8 without a conversion kernel for bool (same storage)."""
+    mask = mask.contiguous()
+    return mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8)
+
+
 def to_head_major(value):
     """(bs, nv, h, d) -> a dense (bs, h, nv, d) copy: the layout the fused / camera-loop kernels gather fastest from
     (a cache line holds x-neighbours of one head instead of one pixel of two heads; include/selfocc_hip.h)."""
@@ -122,8 +142,7 @@ def msda_fused_inference(value, spatial_shapes, level_start_index, reference_poi
     off = sampling_offsets.contiguous().float()
     lg = attention_logits.contiguous().float()
     ref = reference_points.contiguous().float()
-    sh = spatial_shapes.to(device=value.device, dtype=torch.int32).contiguous()
-    st = level_start_index.to(device=value.device, dtype=torch.int32).contiguous()
+    sh, st = _i32(spatial_shapes, value.device), _i32(level_start_index, value.device)
     out = torch.empty(bs, nq, heads * d, device=value.device, dtype=torch.float32)
     check(lib().selfocc_msda_fused_fwd(ptr(value), ptr(sh), ptr(st), ptr(ref), int(ref_kind), ptr(off), ptr(lg),
                                        ptr(out), bs, nv, nq, heads, d, L, P, int(bool(head_major)),
@@ -152,10 +171,9 @@ def msda_cross_inference(value, spatial_shapes, level_start_index, reference_poi
     off = sampling_offsets.contiguous().float()
     lg = attention_logits.contiguous().float()
     ref = reference_points_cam.contiguous().float()
-    vis = visible.to(torch.uint8).contiguous()
+    vis = _u8(visible)
     assert ref.shape == (cams, nq, P, 2) and vis.shape == (cams, nq)
-    sh = spatial_shapes.to(device=value.device, dtype=torch.int32).contiguous()
-    st = level_start_index.to(device=value.device, dtype=torch.int32).contiguous()
+    sh, st = _i32(spatial_shapes, value.device), _i32(level_start_index, value.device)
     out = torch.empty(nq, heads * d, device=value.device, dtype=torch.float32)
     check(lib().selfocc_msda_cross_fwd(ptr(value), ptr(sh), ptr(st), ptr(ref), ptr(vis), ptr(off), ptr(lg),
                                        ptr(out), cams, nv, nq, heads, d, L, P, vstride, int(bool(head_major)),
@@ -176,8 +194,7 @@ class MSDAFusedFunction(torch.autograd.Function):
         out = msda_fused_inference(value, spatial_shapes, level_start_index, reference_points, ref_kind,
                                    sampling_offsets, attention_logits, head_major)
         ctx.head_major = bool(head_major)
-        sh = spatial_shapes.to(device=value.device, dtype=torch.int32).contiguous()
-        st = level_start_index.to(device=value.device, dtype=torch.int32).contiguous()
+        sh, st = _i32(spatial_shapes, value.device), _i32(level_start_index, value.device)
         ctx.save_for_backward(value, sh, st, reference_points, sampling_offsets, attention_logits)
         ctx.ref_kind, ctx.host_shapes = int(ref_kind), list(host_shapes)
         return out
@@ -225,9 +242,8 @@ class MSDACrossFunction(torch.autograd.Function):
         out = msda_cross_inference(value, spatial_shapes, level_start_index, reference_points_cam, visible,
                                    sampling_offsets, attention_logits, head_major)
         ctx.head_major = bool(head_major)
-        sh = spatial_shapes.to(device=value.device, dtype=torch.int32).contiguous()
-        st = level_start_index.to(device=value.device, dtype=torch.int32).contiguous()
-        ctx.save_for_backward(value, sh, st, reference_points_cam, visible.to(torch.uint8), sampling_offsets,
+        sh, st = _i32(spatial_shapes, value.device), _i32(level_start_index, value.device)
+        ctx.save_for_backward(value, sh, st, reference_points_cam, _u8(visible), sampling_offsets,
                               attention_logits)
         ctx.host_shapes = list(host_shapes)
         return out
