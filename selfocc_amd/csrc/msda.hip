@@ -222,6 +222,49 @@ SO_DEVFN void so_team_step(const float *vb, const MsdaPoint &mp, float (&acc)[4]
     for (int c = 0; c < 4; ++c) acc[c] = fmaf(aw, val[c], acc[c]);
 }
 
+// Whole-wave groups (G = 64): move the points that touch the map to the front, dealt round-robin over the teams, and
+// return how many team steps they need.  The pillar of a zh / wz query runs across the whole scene, so a camera that
+// sees the query sees only a fraction of its 48 points (the rest sample the zero padding: exactly 0); uncompacted every
+// point costs a gather slot.  One ballot + 9 ds_permute per round; skipped when >= 3/4 of the lanes are inside.
+template <int D>
+SO_DEVFN int so_compact_points(MsdaPoint &mp) {
+    constexpr int QL = D / 4, TEAMS = 64 / QL;
+    const bool ins = mp.aw != 0.0f;
+    const unsigned long long m = __ballot(ins);
+    const int cnt = __popcll(m);
+    if (cnt > 64 - TEAMS) return QL;           // wave-uniform
+    if (cnt == 0) return 0;
+    const int lane = threadIdx.x & 63;
+    const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+    const int k = ins ? below : cnt + (lane - below);          // stable partition: inside points first
+    const int dst = ((k % TEAMS) * QL + k / TEAMS) << 2;       // point k -> team k % TEAMS, sub-lane k / TEAMS
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        mp.off[c] = __builtin_amdgcn_ds_permute(dst, mp.off[c]);
+        mp.w[c] = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(mp.w[c])));
+    }
+    mp.aw = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(mp.aw)));
+    return (cnt + TEAMS - 1) / TEAMS;
+}
+
+// the first `steps` team steps only (wave-uniform; after so_compact_points)
+template <int D>
+SO_DEVFN void so_team_gather_steps(const float *vb, const MsdaPoint &mp, float (&acc)[4], int steps) {
+    constexpr int QL = D / 4;
+    if (steps > 0) so_team_step<D, 0>(vb, mp, acc);
+    if constexpr (QL > 1) { if (steps > 1) so_team_step<D, 1>(vb, mp, acc); }
+    if constexpr (QL > 2) {
+        if (steps > 2) so_team_step<D, 2>(vb, mp, acc);
+        if (steps > 3) so_team_step<D, 3>(vb, mp, acc);
+    }
+    if constexpr (QL > 4) {
+        if (steps > 4) so_team_step<D, 4>(vb, mp, acc);
+        if (steps > 5) so_team_step<D, 5>(vb, mp, acc);
+        if (steps > 6) so_team_step<D, 6>(vb, mp, acc);
+        if (steps > 7) so_team_step<D, 7>(vb, mp, acc);
+    }
+}
+
 template <int D>
 SO_DEVFN void so_team_gather(const float *vb, const MsdaPoint &mp, float (&acc)[4]) {
     constexpr int QL = D / 4;
@@ -490,7 +533,12 @@ __global__ __launch_bounds__(256, SO_MSDA_FWD_WAVES(D)) void msda_cross_fwd_kern
                 mp = so_point_setup(rf.x + ox[r], rf.y + oy[r], lg[r] * iden, shapes[2 * l], shapes[2 * l + 1],
                                     cam_off + starts[l] * pix_stride, pix_stride);
             }
-            so_team_gather<D>(vb, mp, acc);
+            if constexpr (LOGG == 6) {
+                const int steps = so_compact_points<D>(mp);
+                so_team_gather_steps<D>(vb, mp, acc, steps);
+            } else {
+                so_team_gather<D>(vb, mp, acc);
+            }
         }
     }
     // mean over the cameras that saw the query (image_cross_attention.py:133-135: count clamped to >= 1)
@@ -986,17 +1034,44 @@ __global__ __launch_bounds__(256) void msda_cross_bwd_point_kernel(const float *
 #pragma unroll
             for (int k = 0; k < 4; ++k) goff[k] = own ? vbase + bl.off[k] : 0;
             float dot[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-            so_bwd_team_step_g<D, 0>(value, go, s, goff, dot);
-            if constexpr (QL > 1) so_bwd_team_step_g<D, 1>(value, go, s, goff, dot);
+            // whole-wave groups: the points that touch the map move to the front (see so_compact_points), the teams
+            // compute their corner dots there, and the dots travel back to the lanes that own the points
+            int steps = QL, dst = 0;
+            bool moved = false;
+            if constexpr (LOGG == 6) {
+                constexpr int TEAMS = 64 / QL;
+                const bool ins = own && bl.any;
+                const unsigned long long m = __ballot(ins);
+                const int n_in = __popcll(m);
+                if (n_in == 0) {
+                    steps = 0;
+                } else if (n_in <= 64 - TEAMS) {
+                    const int lane = threadIdx.x & 63;
+                    const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+                    const int k = ins ? below : n_in + (lane - below);
+                    dst = ((k % TEAMS) * QL + k / TEAMS) << 2;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) goff[c] = __builtin_amdgcn_ds_permute(dst, goff[c]);
+                    steps = (n_in + TEAMS - 1) / TEAMS;
+                    moved = true;
+                }
+            }
+            if (steps > 0) so_bwd_team_step_g<D, 0>(value, go, s, goff, dot);
+            if constexpr (QL > 1) { if (steps > 1) so_bwd_team_step_g<D, 1>(value, go, s, goff, dot); }
             if constexpr (QL > 2) {
-                so_bwd_team_step_g<D, 2>(value, go, s, goff, dot);
-                so_bwd_team_step_g<D, 3>(value, go, s, goff, dot);
+                if (steps > 2) so_bwd_team_step_g<D, 2>(value, go, s, goff, dot);
+                if (steps > 3) so_bwd_team_step_g<D, 3>(value, go, s, goff, dot);
             }
             if constexpr (QL > 4) {
-                so_bwd_team_step_g<D, 4>(value, go, s, goff, dot);
-                so_bwd_team_step_g<D, 5>(value, go, s, goff, dot);
-                so_bwd_team_step_g<D, 6>(value, go, s, goff, dot);
-                so_bwd_team_step_g<D, 7>(value, go, s, goff, dot);
+                if (steps > 4) so_bwd_team_step_g<D, 4>(value, go, s, goff, dot);
+                if (steps > 5) so_bwd_team_step_g<D, 5>(value, go, s, goff, dot);
+                if (steps > 6) so_bwd_team_step_g<D, 6>(value, go, s, goff, dot);
+                if (steps > 7) so_bwd_team_step_g<D, 7>(value, go, s, goff, dot);
+            }
+            if (moved) {   // wave-uniform
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    dot[c] = __int_as_float(__builtin_amdgcn_ds_bpermute(dst, __float_as_int(dot[c])));
             }
             const size_t ki = ((((size_t)cam * dm.heads + h) * dm.L + l) * dm.nq + q) * dm.P + pp;
             if (own && !bl.any) keys[ki] = (int16_t)kKeyOutside;   // every key of a visited (camera, query) is written
