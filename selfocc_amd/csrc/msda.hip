@@ -222,29 +222,54 @@ SO_DEVFN void so_team_step(const float *vb, const MsdaPoint &mp, float (&acc)[4]
     for (int c = 0; c < 4; ++c) acc[c] = fmaf(aw, val[c], acc[c]);
 }
 
-// Whole-wave groups (G = 64): move the points that touch the map to the front, dealt round-robin over the teams, and
-// return how many team steps they need.  The pillar of a zh / wz query runs across the whole scene, so a camera that
+// Whole-wave / half-wave groups: move the points that touch the map to the front of their group, dealt round-robin over
+// its teams, and return how many team steps they need.  The pillar of a zh / wz query runs across the whole scene, so a camera that
 // sees the query sees only a fraction of its 48 points (the rest sample the zero padding: exactly 0); uncompacted every
 // point costs a gather slot.  One ballot + 9 ds_permute per round; skipped when >= 3/4 of the lanes are inside.
-template <int D>
-SO_DEVFN int so_compact_points(MsdaPoint &mp) {
-    constexpr int QL = D / 4, TEAMS = 64 / QL;
-    const bool ins = mp.aw != 0.0f;
+template <int D, int LOGG>
+SO_DEVFN int so_compact_plan(bool ins, int &dst, bool &moved) {
+    // -> team steps needed; moved: the caller permutes its per-point values with ds_permute(dst, .) (and brings results
+    // back with ds_bpermute(dst, .)).  Points stay inside their group (whole wave or half wave).  Wave-uniform result.
+    constexpr int G = 1 << LOGG, QL = D / 4, TEAMS = G / QL;
+    static_assert(LOGG == 5 || LOGG == 6, "whole-wave or half-wave groups");
     const unsigned long long m = __ballot(ins);
-    const int cnt = __popcll(m);
-    if (cnt > 64 - TEAMS) return QL;           // wave-uniform
-    if (cnt == 0) return 0;
     const int lane = threadIdx.x & 63;
-    const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-    const int k = ins ? below : cnt + (lane - below);          // stable partition: inside points first
-    const int dst = ((k % TEAMS) * QL + k / TEAMS) << 2;       // point k -> team k % TEAMS, sub-lane k / TEAMS
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        mp.off[c] = __builtin_amdgcn_ds_permute(dst, mp.off[c]);
-        mp.w[c] = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(mp.w[c])));
+    moved = false;
+    dst = 0;
+    int cnt, below, most;
+    if constexpr (LOGG == 6) {
+        cnt = most = __popcll(m);
+        below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+    } else {
+        const unsigned lo = (unsigned)m, hi = (unsigned)(m >> 32);
+        const int c0 = __popc(lo), c1 = __popc(hi);
+        most = max(c0, c1);
+        cnt = lane < 32 ? c0 : c1;
+        below = __popc((lane < 32 ? lo : hi) & ((1u << (lane & 31)) - 1u));
     }
-    mp.aw = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(mp.aw)));
-    return (cnt + TEAMS - 1) / TEAMS;
+    if (most > G - TEAMS) return QL;              // (nearly) every team step is needed anyway
+    if (most == 0) return 0;
+    const int gl = lane & (G - 1);
+    const int k = ins ? below : cnt + (gl - below);                            // stable partition: inside points first
+    dst = ((lane & ~(G - 1)) | ((k % TEAMS) * QL + k / TEAMS)) << 2;           // point k -> team k % TEAMS, sub-lane k / TEAMS
+    moved = true;
+    return (most + TEAMS - 1) / TEAMS;
+}
+
+template <int D, int LOGG>
+SO_DEVFN int so_compact_points(MsdaPoint &mp) {
+    int dst;
+    bool moved;
+    const int steps = so_compact_plan<D, LOGG>(mp.aw != 0.0f, dst, moved);
+    if (moved) {   // wave-uniform
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            mp.off[c] = __builtin_amdgcn_ds_permute(dst, mp.off[c]);
+            mp.w[c] = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(mp.w[c])));
+        }
+        mp.aw = __int_as_float(__builtin_amdgcn_ds_permute(dst, __float_as_int(mp.aw)));
+    }
+    return steps;
 }
 
 // the first `steps` team steps only (wave-uniform; after so_compact_points)
@@ -533,8 +558,8 @@ __global__ __launch_bounds__(256, SO_MSDA_FWD_WAVES(D)) void msda_cross_fwd_kern
                 mp = so_point_setup(rf.x + ox[r], rf.y + oy[r], lg[r] * iden, shapes[2 * l], shapes[2 * l + 1],
                                     cam_off + starts[l] * pix_stride, pix_stride);
             }
-            if constexpr (LOGG == 6) {
-                const int steps = so_compact_points<D>(mp);
+            if constexpr (LOGG >= 5) {
+                const int steps = so_compact_points<D, LOGG>(mp);
                 so_team_gather_steps<D>(vb, mp, acc, steps);
             } else {
                 so_team_gather<D>(vb, mp, acc);
@@ -1038,22 +1063,11 @@ __global__ __launch_bounds__(256) void msda_cross_bwd_point_kernel(const float *
             // compute their corner dots there, and the dots travel back to the lanes that own the points
             int steps = QL, dst = 0;
             bool moved = false;
-            if constexpr (LOGG == 6) {
-                constexpr int TEAMS = 64 / QL;
-                const bool ins = own && bl.any;
-                const unsigned long long m = __ballot(ins);
-                const int n_in = __popcll(m);
-                if (n_in == 0) {
-                    steps = 0;
-                } else if (n_in <= 64 - TEAMS) {
-                    const int lane = threadIdx.x & 63;
-                    const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-                    const int k = ins ? below : n_in + (lane - below);
-                    dst = ((k % TEAMS) * QL + k / TEAMS) << 2;
+            if constexpr (LOGG >= 5) {
+                steps = so_compact_plan<D, LOGG>(own && bl.any, dst, moved);
+                if (moved) {   // wave-uniform
 #pragma unroll
                     for (int c = 0; c < 4; ++c) goff[c] = __builtin_amdgcn_ds_permute(dst, goff[c]);
-                    steps = (n_in + TEAMS - 1) / TEAMS;
-                    moved = true;
                 }
             }
             if (steps > 0) so_bwd_team_step_g<D, 0>(value, go, s, goff, dot);
