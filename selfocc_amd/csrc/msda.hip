@@ -155,6 +155,9 @@ SO_DEVFN unsigned so_xcd_block() {
 // hw-plane shape).  The point record travels through the team with DPP quad permutes (no LDS).
 // ---------------------------------------------------------------------------------------
 constexpr int so_ilog2(int v) { return v <= 1 ? 0 : 1 + so_ilog2(v >> 1); }
+// fused kernels: points a lane may own (rounds of its group): small groups take more rounds (L * P = 36 on 8 lanes x 5
+// rounds keeps 90 % of the lanes busy; 16 x 3: 75 %)
+constexpr int so_maxr(int logg) { return logg >= 4 ? 4 : 8; }
 
 struct MsdaPoint {
     int off[4];   // corner element offsets relative to the (b, head) base, level start included
@@ -408,7 +411,7 @@ __global__ __launch_bounds__(256, SO_MSDA_FWD_WAVES(D)) void msda_fused_fwd_kern
     constexpr int G = 1 << LOGG;
     constexpr int QL = D / 4, LOGQ = so_ilog2(QL);
     constexpr int NJ = LOGG > LOGQ ? LOGG - LOGQ : 0;
-    constexpr int MAXR = 4;   // points per lane (host guarantees L * P <= MAXR * G)
+    constexpr int MAXR = so_maxr(LOGG);   // points per lane (host guarantees L * P <= MAXR * G)
     const int LP = dm.L * dm.P;
     const int groups_per_block = 256 / G;
     const long long n_groups = (long long)dm.bs * dm.nq * dm.heads;
@@ -495,7 +498,7 @@ __global__ __launch_bounds__(256, SO_MSDA_FWD_WAVES(D)) void msda_cross_fwd_kern
     constexpr int G = 1 << LOGG;
     constexpr int QL = D / 4, LOGQ = so_ilog2(QL);
     constexpr int NJ = LOGG > LOGQ ? LOGG - LOGQ : 0;
-    constexpr int MAXR = 4;   // points per lane (host guarantees L * P <= MAXR * G)
+    constexpr int MAXR = so_maxr(LOGG);   // points per lane (host guarantees L * P <= MAXR * G)
     const int LP = dm.L * dm.P;
     const int groups_per_block = 256 / G;
     const int n_groups = dm.nq * dm.heads;                       // < 2^31 (validated)
@@ -868,7 +871,7 @@ __global__ __launch_bounds__(256) void msda_fused_bwd_point_kernel(const float *
                                                                    MsdaDims dm) {
     constexpr int G = 1 << LOGG;
     constexpr int QL = D / 4;
-    constexpr int MAXR = 4;
+    constexpr int MAXR = so_maxr(LOGG);
     const int LP = dm.L * dm.P;
     const int groups_per_block = 256 / G;
     const long long n_groups = (long long)dm.bs * dm.nq * dm.heads;
@@ -904,7 +907,9 @@ __global__ __launch_bounds__(256) void msda_fused_bwd_point_kernel(const float *
 
     float4 go = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (live) go = *(const float4 *)(g_out + (size_t)gq * D + 4 * s);
-    float ga[MAXR] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float ga[MAXR];
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) ga[r] = 0.0f;
     float sum_l = 0.0f;
 #pragma unroll
     for (int r = 0; r < MAXR; ++r) {
@@ -991,7 +996,7 @@ __global__ __launch_bounds__(256) void msda_cross_bwd_point_kernel(const float *
                                                                    int cams, MsdaDims dm) {
     constexpr int G = 1 << LOGG;
     constexpr int QL = D / 4;
-    constexpr int MAXR = 4;
+    constexpr int MAXR = so_maxr(LOGG);
     const int LP = dm.L * dm.P;
     const int groups_per_block = 256 / G;
     const int n_groups = dm.nq * dm.heads;
@@ -1038,7 +1043,9 @@ __global__ __launch_bounds__(256) void msda_cross_bwd_point_kernel(const float *
 
     float4 go = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     if (live) go = *(const float4 *)(g_out + (size_t)gq * D + 4 * s);
-    float ga[MAXR] = {0.0f, 0.0f, 0.0f, 0.0f}, gxs[MAXR] = {0.0f, 0.0f, 0.0f, 0.0f}, gys[MAXR] = {0.0f, 0.0f, 0.0f, 0.0f};
+    float ga[MAXR], gxs[MAXR], gys[MAXR];
+#pragma unroll
+    for (int r = 0; r < MAXR; ++r) ga[r] = gxs[r] = gys[r] = 0.0f;
     for (int cam = 0; cam < cams; ++cam) {
         const bool seen = live && vis[(size_t)cam * dm.nq + q] != 0;
         if (!__any(seen)) continue;                      // no group of this wave sees the camera
@@ -1452,9 +1459,9 @@ static void so_pick_group(int LP, int d, int max_rounds, int &G, int &logG) {
     G = 1 << best_l;
 }
 
-// Fused kernels: a lane holds at most 4 points (MAXR), so rounds <= 4; among those the best lane utilisation
-// LP / (rounds * G), ties to the larger group (fewest rounds: the softmax exchanges are per group, the prologue per
-// round).  L * P = 36 (the shipped self-attention) -> G = 16, 3 rounds, 75 % live lanes instead of 56 % at G = 64.
+// Fused kernels: a lane holds at most so_maxr(log2 G) points; among the group sizes that allows, the best lane
+// utilisation LP / (rounds * G), ties to the larger group (fewest rounds: the softmax exchanges are per group, the
+// prologue per round).  L * P = 36 (the shipped self-attention) -> G = 8, 5 rounds, 90 % live lanes (64 lanes: 56 %).
 static void so_pick_group_fused(int LP, int d, int &G, int &logG) {
     int best_l = 6;
     double best_u = -1.0;
@@ -1462,7 +1469,7 @@ static void so_pick_group_fused(int LP, int d, int &G, int &logG) {
         const int g = 1 << lg;
         if (g < d / 4) break;
         const int rounds = (LP + g - 1) / g;
-        if (rounds > 4) break;
+        if (rounds > so_maxr(lg)) { if (lg >= 4) continue; else break; }
         const double u = (double)LP / ((double)rounds * g);
         if (u > best_u + 1e-12) { best_u = u; best_l = lg; }
     }
