@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SELFOCC_ABI_VERSION 20
+#define SELFOCC_ABI_VERSION 21
 
 int selfocc_abi_version(void);
 const char *selfocc_last_error(void);
@@ -202,15 +202,20 @@ int selfocc_msda_fwd(const float *value, const int32_t *shapes, const int32_t *s
  *   both x-corners of a bilinear footprint; the gathers of the hw-plane cross-attention run 0.34 ms instead of 0.50. */
 enum { SO_VALUE_PIXEL_MAJOR = 0, SO_VALUE_HEAD_MAJOR = 1 };
 
+/* value_dtype of the same entry points: SO_DTYPE_F32, or SO_DTYPE_BF16 = bfloat16 STORAGE of `value` (the arithmetic
+ * is float32 on the exactly widened values; g_value stays float32): halves the 64-byte corner segments the gathers move.
+ * Results equal the float32 kernels run on bf16-rounded values; against unrounded float32 values the relative error is
+ * the bf16 rounding of `value`, ~2^-9 (opt-in: BASELINE configs[1] allows bf16 storage, the reference computes MSDA in f32). */
+
 /* Inference form with the reference's prologue fused in (softmax over the L*P logits of a
  * (query, head); loc = ref + off / (W_l, H_l); image_cross_attention.py:314-328,
  * cross_view_hybrid_attention.py:88-99): the sampling_locations / attention_weights tensors are
  * never materialised.   off_raw (bs,nq,heads,L,P,2)  logits (bs,nq,heads,L*P)
  *   ref_kind 0: ref (bs,nq,L,2)   1: ref (bs,nq,P,2)   2: ref (bs,nq,L,P,2)        L*P <= 256 */
-int selfocc_msda_fused_fwd(const float *value, const int32_t *shapes, const int32_t *starts,
+int selfocc_msda_fused_fwd(const void *value, const int32_t *shapes, const int32_t *starts,
                            const float *ref, int32_t ref_kind, const float *off_raw, const float *logits,
                            float *out, int32_t bs, int32_t nv, int32_t nq, int32_t heads, int32_t d,
-                           int32_t L, int32_t P, int32_t value_layout, void *stream);
+                           int32_t L, int32_t P, int32_t value_layout, int32_t value_dtype, void *stream);
 
 /* Camera-loop inference form: BEVCrossAttention's re-batch -> offset / weight linears -> MSDA ->
  * scatter-add -> divide-by-count (bevformer/attention/image_cross_attention.py:90-136) as ONE launch.
@@ -222,22 +227,23 @@ int selfocc_msda_fused_fwd(const float *value, const int32_t *shapes, const int3
  *   logits (nq,heads,L*P)  out (nq,heads*d)            batch size 1 (as the reference's masks), L*P <= 256
  * value_stride: floats between consecutive pixels of `value` (0 = dense, heads*d): lets `value` be a column block
  * of a wider matrix, e.g. the three TPV planes' value projections computed by ONE GEMM with N = 3 * heads * d. */
-int selfocc_msda_cross_fwd(const float *value, const int32_t *shapes, const int32_t *starts,
+int selfocc_msda_cross_fwd(const void *value, const int32_t *shapes, const int32_t *starts,
                            const float *ref, const uint8_t *vis, const float *off_raw, const float *logits,
                            float *out, int32_t cams, int32_t nv, int32_t nq, int32_t heads, int32_t d,
-                           int32_t L, int32_t P, int32_t value_stride, int32_t value_layout, void *stream);
+                           int32_t L, int32_t P, int32_t value_stride, int32_t value_layout, int32_t value_dtype,
+                           void *stream);
 
 /* Training counterpart of selfocc_msda_cross_fwd: g_out (nq, heads*d) is the gradient of the camera MEAN;
  * returns g_value (cams,nv,heads,d; zero-initialised by the caller), g_off (nq,heads,L,P,2) and
  * g_logits (nq,heads,L*P) — sums over the visible cameras / count.  host_shapes and workspace as for
  * selfocc_msda_bwd_banded with bs = cams (selfocc_msda_bwd_banded_workspace(cams, nq, heads, L, P));
  * requires selfocc_msda_banded_supported(host_shapes, cams, nq, heads, d, L, P) == 1 and L*P <= 256. */
-int selfocc_msda_cross_bwd(const float *value, const int32_t *shapes, const int32_t *starts,
+int selfocc_msda_cross_bwd(const void *value, const int32_t *shapes, const int32_t *starts,
                            const int32_t *host_shapes, const float *ref, const uint8_t *vis,
                            const float *off_raw, const float *logits, const float *g_out,
                            float *g_value, float *g_off, float *g_logits, int32_t cams, int32_t nv,
                            int32_t nq, int32_t heads, int32_t d, int32_t L, int32_t P, int32_t value_layout,
-                           void *workspace, size_t workspace_bytes, void *stream);
+                           int32_t value_dtype, void *workspace, size_t workspace_bytes, void *stream);
 
 /* g_value must be zero-initialised by the caller (atomically accumulated). */
 int selfocc_msda_bwd(const float *value, const int32_t *shapes, const int32_t *starts,
@@ -271,12 +277,12 @@ int selfocc_msda_bwd_banded(const float *value, const int32_t *shapes, const int
  * g_value must be zero-initialised by the caller. */
 int selfocc_msda_banded_supported(const int32_t *host_shapes, int32_t bs, int32_t nq, int32_t heads,
                                   int32_t d, int32_t L, int32_t P);
-int selfocc_msda_fused_bwd(const float *value, const int32_t *shapes, const int32_t *starts,
+int selfocc_msda_fused_bwd(const void *value, const int32_t *shapes, const int32_t *starts,
                            const int32_t *host_shapes, const float *ref, int32_t ref_kind,
                            const float *off_raw, const float *logits, const float *g_out,
                            float *g_value, float *g_off, float *g_logits, int32_t bs, int32_t nv,
                            int32_t nq, int32_t heads, int32_t d, int32_t L, int32_t P, int32_t value_layout,
-                           void *workspace, size_t workspace_bytes, void *stream);
+                           int32_t value_dtype, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Dense SDF / semantic query on a regular metre lattice + Occ3D occupancy tail.

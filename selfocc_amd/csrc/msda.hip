@@ -205,9 +205,19 @@ SO_DEVFN float so_team_bcastf(float x) {
     return __int_as_float(so_team_bcast<QL, I>(__float_as_int(x)));
 }
 
+// 4 consecutive channels of `value`: float32, or bfloat16 storage (the bits, as uint16_t) widened exactly.  The bf16
+// option of the fused / camera-loop entry points halves the corner segments the gathers move (64 -> 32 bytes); the
+// arithmetic stays float32 on the widened values.
+SO_DEVFN float4 so_ld4(const float *p) { return *(const float4 *)p; }
+SO_DEVFN float4 so_ld4(const uint16_t *p) {
+    const uint2 t = *(const uint2 *)p;
+    return make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16),
+                       __uint_as_float(t.y & 0xffff0000u));
+}
+
 // the team adds the point owned by its sub-lane I: acc[0..3] are this lane's 4 channels
-template <int D, int I>
-SO_DEVFN void so_team_step(const float *vb, const MsdaPoint &mp, float (&acc)[4]) {
+template <int D, int I, typename VT>
+SO_DEVFN void so_team_step(const VT *vb, const MsdaPoint &mp, float (&acc)[4]) {
     constexpr int QL = D / 4;
     const float aw = so_team_bcastf<QL, I>(mp.aw);
     float val[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -215,7 +225,7 @@ SO_DEVFN void so_team_step(const float *vb, const MsdaPoint &mp, float (&acc)[4]
     for (int k = 0; k < 4; ++k) {
         const int off = so_team_bcast<QL, I>(mp.off[k]);
         const float w = so_team_bcastf<QL, I>(mp.w[k]);
-        const float4 t = *(const float4 *)(vb + off);
+        const float4 t = so_ld4(vb + off);
         val[0] = fmaf(w, t.x, val[0]);
         val[1] = fmaf(w, t.y, val[1]);
         val[2] = fmaf(w, t.z, val[2]);
@@ -276,8 +286,8 @@ SO_DEVFN int so_compact_points(MsdaPoint &mp) {
 }
 
 // the first `steps` team steps only (wave-uniform; after so_compact_points)
-template <int D>
-SO_DEVFN void so_team_gather_steps(const float *vb, const MsdaPoint &mp, float (&acc)[4], int steps) {
+template <int D, typename VT>
+SO_DEVFN void so_team_gather_steps(const VT *vb, const MsdaPoint &mp, float (&acc)[4], int steps) {
     constexpr int QL = D / 4;
     if (steps > 0) so_team_step<D, 0>(vb, mp, acc);
     if constexpr (QL > 1) { if (steps > 1) so_team_step<D, 1>(vb, mp, acc); }
@@ -293,8 +303,8 @@ SO_DEVFN void so_team_gather_steps(const float *vb, const MsdaPoint &mp, float (
     }
 }
 
-template <int D>
-SO_DEVFN void so_team_gather(const float *vb, const MsdaPoint &mp, float (&acc)[4]) {
+template <int D, typename VT>
+SO_DEVFN void so_team_gather(const VT *vb, const MsdaPoint &mp, float (&acc)[4]) {
     constexpr int QL = D / 4;
     so_team_step<D, 0>(vb, mp, acc);
     if constexpr (QL > 1) so_team_step<D, 1>(vb, mp, acc);
@@ -400,8 +410,8 @@ __global__ __launch_bounds__(256) void msda_fwd_kernel(const float *__restrict__
 // 4 waves / SIMD (<= 128 VGPRs) for the shipped head width: the camera-loop kernel otherwise takes 144 VGPRs (3 waves);
 // measured -1.5 % on the eval encoder, 5 / 6 waves spill (+20 % / +39 %)
 #define SO_MSDA_FWD_WAVES(D) ((D) <= 16 ? 4 : 1)
-template <int D, int LOGG>
-__global__ __launch_bounds__(256, SO_MSDA_FWD_WAVES(D)) void msda_fused_fwd_kernel(const float *__restrict__ value,
+template <int D, int LOGG, typename VT>
+__global__ __launch_bounds__(256, SO_MSDA_FWD_WAVES(D)) void msda_fused_fwd_kernel(const VT *__restrict__ value,
                                                              const int32_t *__restrict__ shapes,
                                                              const int32_t *__restrict__ starts,
                                                              const float *__restrict__ ref, int ref_kind,
@@ -423,7 +433,7 @@ __global__ __launch_bounds__(256, SO_MSDA_FWD_WAVES(D)) void msda_fused_fwd_kern
     so_split_group_head_outer(live ? gid : 0, dm, h, b, bq, gq);
     const int pix_stride = so_pix_stride(dm, D);
     const int s = gl & (QL - 1);
-    const float *vb = value + so_value_base(dm, D, b, h, 0) + 4 * s;
+    const VT *vb = value + so_value_base(dm, D, b, h, 0) + 4 * s;
 
     // softmax over the group's L * P logits
     float lg[MAXR];
@@ -486,8 +496,8 @@ __global__ __launch_bounds__(256, SO_MSDA_FWD_WAVES(D)) void msda_fused_fwd_kern
 //   value (cams, nv, heads, D)   ref (cams, nq, P, 2)   vis (cams, nq) u8   off_raw (nq, heads, L, P, 2)
 //   logits (nq, heads, L*P)      out (nq, heads*D) = sum_{cam visible} msda_cam(q) / max(#visible, 1)
 // ---------------------------------------------------------------------------------------
-template <int D, int LOGG>
-__global__ __launch_bounds__(256, SO_MSDA_FWD_WAVES(D)) void msda_cross_fwd_kernel(const float *__restrict__ value,
+template <int D, int LOGG, typename VT>
+__global__ __launch_bounds__(256, SO_MSDA_FWD_WAVES(D)) void msda_cross_fwd_kernel(const VT *__restrict__ value,
                                                              const int32_t *__restrict__ shapes,
                                                              const int32_t *__restrict__ starts,
                                                              const float *__restrict__ ref,
@@ -510,7 +520,7 @@ __global__ __launch_bounds__(256, SO_MSDA_FWD_WAVES(D)) void msda_cross_fwd_kern
     const int gq = q * dm.heads + h;
     const int pix_stride = so_pix_stride(dm, D);     // `value` may be head-major or a column block of a wider matrix
     const int s = gl & (QL - 1);
-    const float *vb = value + so_value_base(dm, D, 0, h, 0) + 4 * s;
+    const VT *vb = value + so_value_base(dm, D, 0, h, 0) + 4 * s;
     const int cam_stride = (int)(so_value_base(dm, D, 1, h, 0) - so_value_base(dm, D, 0, h, 0));   // < 2^31 (validated)
 
     // softmax over the group's L * P logits; raw offsets of the lane's own points, already / (W_l, H_l)
@@ -826,15 +836,15 @@ __global__ __launch_bounds__(256) void msda_bwd_point_kernel(const float *__rest
 }
 
 // team step I with the g_out quarter already in registers (all lanes of a team share the group)
-template <int D, int I>
-SO_DEVFN void so_bwd_team_step_g(const float *__restrict__ value, const float4 &go, int s, const int (&goff)[4],
+template <int D, int I, typename VT>
+SO_DEVFN void so_bwd_team_step_g(const VT *__restrict__ value, const float4 &go, int s, const int (&goff)[4],
                                  float (&dot)[4]) {
     constexpr int QL = D / 4;
     float part[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int off = so_team_bcast<QL, I>(goff[k]);
-        const float4 t = *(const float4 *)(value + off + 4 * s);
+        const float4 t = so_ld4(value + off + 4 * s);
         part[k] = t.x * go.x;
         part[k] = fmaf(t.y, go.y, part[k]);
         part[k] = fmaf(t.z, go.z, part[k]);
@@ -858,8 +868,8 @@ SO_DEVFN void so_bwd_team_step_g(const float *__restrict__ value, const float4 &
 // softmax, off / normalizer, + ref and their three backward kernels, and the 100-400 MB loc / weight
 // tensors with their gradients.
 // ---------------------------------------------------------------------------------------
-template <int D, int LOGG>
-__global__ __launch_bounds__(256) void msda_fused_bwd_point_kernel(const float *__restrict__ value,
+template <int D, int LOGG, typename VT>
+__global__ __launch_bounds__(256) void msda_fused_bwd_point_kernel(const VT *__restrict__ value,
                                                                    const int32_t *__restrict__ shapes,
                                                                    const int32_t *__restrict__ starts,
                                                                    const float *__restrict__ ref, int ref_kind,
@@ -982,8 +992,8 @@ __global__ __launch_bounds__(256) void msda_fused_bwd_point_kernel(const float *
 // (cam, h, level, q, p) for the visible cameras only (the key array is pre-filled with "outside"), the
 // record's weight already divided by cnt, and the band kernel reads the shared g_out row (go_shared).
 // ---------------------------------------------------------------------------------------
-template <int D, int LOGG>
-__global__ __launch_bounds__(256) void msda_cross_bwd_point_kernel(const float *__restrict__ value,
+template <int D, int LOGG, typename VT>
+__global__ __launch_bounds__(256) void msda_cross_bwd_point_kernel(const VT *__restrict__ value,
                                                                    const int32_t *__restrict__ shapes,
                                                                    const int32_t *__restrict__ starts,
                                                                    const float *__restrict__ ref,
@@ -1520,14 +1530,15 @@ extern "C" int selfocc_msda_fwd(const float *value, const int32_t *shapes, const
 }
 
 
-extern "C" int selfocc_msda_fused_fwd(const float *value, const int32_t *shapes, const int32_t *starts,
+extern "C" int selfocc_msda_fused_fwd(const void *value, const int32_t *shapes, const int32_t *starts,
                                       const float *ref, int32_t ref_kind, const float *off_raw, const float *logits,
                                       float *out, int32_t bs, int32_t nv, int32_t nq, int32_t heads, int32_t d,
-                                      int32_t L, int32_t P, int32_t value_layout, void *stream) {
-    if (validate(value, shapes, starts, off_raw, logits, bs, nv, nq, heads, d, L, P)) return -1;
+                                      int32_t L, int32_t P, int32_t value_layout, int32_t value_dtype, void *stream) {
+    if (validate((const float *)value, shapes, starts, off_raw, logits, bs, nv, nq, heads, d, L, P)) return -1;
     const long long n_groups = (long long)bs * nq * heads;
     if (n_groups == 0) return 0;
     SO_REQUIRE(out != nullptr && ref != nullptr, "msda_fused_fwd: NULL pointer");
+    SO_REQUIRE(value_dtype == SO_DTYPE_F32 || value_dtype == SO_DTYPE_BF16, "msda_fused_fwd: bad value_dtype");
     SO_REQUIRE(value_layout == SO_VALUE_PIXEL_MAJOR || value_layout == SO_VALUE_HEAD_MAJOR, "msda_fused_fwd: bad value_layout");
     SO_REQUIRE(ref_kind >= 0 && ref_kind <= 2, "msda_fused_fwd: ref_kind must be 0, 1 or 2");
     if (nv == 0)
@@ -1542,8 +1553,12 @@ extern "C" int selfocc_msda_fused_fwd(const float *value, const int32_t *shapes,
     MsdaDims dm{bs, nv, nq, heads, L, P, 0, 0, value_layout};
     hipStream_t st = (hipStream_t)stream;
 #define SO_LAUNCH_G(DD, LG)                                                                             \
-    hipLaunchKernelGGL((msda_fused_fwd_kernel<DD, LG>), dim3((unsigned)blocks), dim3(256), 0, st, value, \
-                       shapes, starts, ref, ref_kind, off_raw, logits, out, dm)
+    if (value_dtype == SO_DTYPE_BF16)                                                                   \
+        hipLaunchKernelGGL((msda_fused_fwd_kernel<DD, LG, uint16_t>), dim3((unsigned)blocks), dim3(256), 0, st,   \
+                           (const uint16_t *)value, shapes, starts, ref, ref_kind, off_raw, logits, out, dm);      \
+    else                                                                                                \
+        hipLaunchKernelGGL((msda_fused_fwd_kernel<DD, LG, float>), dim3((unsigned)blocks), dim3(256), 0, st,       \
+                           (const float *)value, shapes, starts, ref, ref_kind, off_raw, logits, out, dm)
 #define SO_LAUNCH(DD)                                                                                   \
     switch (logG) {                                                                                     \
         case 0: SO_LAUNCH_G(DD, 0); break;                                                              \
@@ -1565,19 +1580,20 @@ extern "C" int selfocc_msda_fused_fwd(const float *value, const int32_t *shapes,
     return so_launch_status();
 }
 
-extern "C" int selfocc_msda_cross_fwd(const float *value, const int32_t *shapes, const int32_t *starts,
+extern "C" int selfocc_msda_cross_fwd(const void *value, const int32_t *shapes, const int32_t *starts,
                                       const float *ref, const uint8_t *vis, const float *off_raw,
                                       const float *logits, float *out, int32_t cams, int32_t nv, int32_t nq,
                                       int32_t heads, int32_t d, int32_t L, int32_t P, int32_t value_stride,
-                                      int32_t value_layout, void *stream) {
+                                      int32_t value_layout, int32_t value_dtype, void *stream) {
     SO_REQUIRE(cams >= 1, "msda_cross_fwd: cams must be >= 1");
+    SO_REQUIRE(value_dtype == SO_DTYPE_F32 || value_dtype == SO_DTYPE_BF16, "msda_cross_fwd: bad value_dtype");
     SO_REQUIRE(value_layout == SO_VALUE_PIXEL_MAJOR || (value_layout == SO_VALUE_HEAD_MAJOR && value_stride == 0),
                "msda_cross_fwd: bad value_layout (head-major values are dense: value_stride must be 0)");
     SO_REQUIRE(value_stride == 0 || (value_stride >= heads * d && value_stride % 4 == 0),
                "msda_cross_fwd: value_stride must be 0 or a multiple of 4 >= heads * d");
     SO_REQUIRE((long long)cams * nv * (value_stride ? value_stride : heads * d) < (1LL << 31),
                "msda_cross_fwd: value must span < 2^31 floats");
-    if (validate(value, shapes, starts, off_raw, logits, cams, nv, nq, heads, d, L, P)) return -1;
+    if (validate((const float *)value, shapes, starts, off_raw, logits, cams, nv, nq, heads, d, L, P)) return -1;
     const long long n_groups = (long long)nq * heads;
     if (n_groups == 0) return 0;
     SO_REQUIRE(out != nullptr && ref != nullptr && vis != nullptr, "msda_cross_fwd: NULL pointer");
@@ -1593,8 +1609,12 @@ extern "C" int selfocc_msda_cross_fwd(const float *value, const int32_t *shapes,
     MsdaDims dm{1, nv, nq, heads, L, P, 0, value_stride, value_layout};
     hipStream_t st = (hipStream_t)stream;
 #define SO_LAUNCH_G(DD, LG)                                                                             \
-    hipLaunchKernelGGL((msda_cross_fwd_kernel<DD, LG>), dim3((unsigned)blocks), dim3(256), 0, st, value, \
-                       shapes, starts, ref, vis, off_raw, logits, out, cams, dm)
+    if (value_dtype == SO_DTYPE_BF16)                                                                   \
+        hipLaunchKernelGGL((msda_cross_fwd_kernel<DD, LG, uint16_t>), dim3((unsigned)blocks), dim3(256), 0, st,   \
+                           (const uint16_t *)value, shapes, starts, ref, vis, off_raw, logits, out, cams, dm);     \
+    else                                                                                                \
+        hipLaunchKernelGGL((msda_cross_fwd_kernel<DD, LG, float>), dim3((unsigned)blocks), dim3(256), 0, st,       \
+                           (const float *)value, shapes, starts, ref, vis, off_raw, logits, out, cams, dm)
 #define SO_LAUNCH(DD)                                                                                   \
     switch (logG) {                                                                                     \
         case 0: SO_LAUNCH_G(DD, 0); break;                                                              \
@@ -1826,13 +1846,14 @@ extern "C" int selfocc_msda_bwd_banded(const float *value, const int32_t *shapes
     return so_band_scatter(shapes, starts, g_out, g_value, w, bsu, dm, d, nullptr, st);
 }
 
-extern "C" int selfocc_msda_fused_bwd(const float *value, const int32_t *shapes, const int32_t *starts,
+extern "C" int selfocc_msda_fused_bwd(const void *value, const int32_t *shapes, const int32_t *starts,
                                       const int32_t *host_shapes, const float *ref, int32_t ref_kind,
                                       const float *off_raw, const float *logits, const float *g_out,
                                       float *g_value, float *g_off, float *g_logits, int32_t bs, int32_t nv,
                                       int32_t nq, int32_t heads, int32_t d, int32_t L, int32_t P, int32_t value_layout,
-                                      void *workspace, size_t workspace_bytes, void *stream) {
-    if (validate(value, shapes, starts, off_raw, logits, bs, nv, nq, heads, d, L, P)) return -1;
+                                      int32_t value_dtype, void *workspace, size_t workspace_bytes, void *stream) {
+    if (validate((const float *)value, shapes, starts, off_raw, logits, bs, nv, nq, heads, d, L, P)) return -1;
+    SO_REQUIRE(value_dtype == SO_DTYPE_F32 || value_dtype == SO_DTYPE_BF16, "msda_fused_bwd: bad value_dtype");
     const long long n_groups = (long long)bs * nq * heads;
     if (n_groups == 0) return 0;
     SO_REQUIRE(ref && g_out && g_value && g_off && g_logits, "msda_fused_bwd: NULL pointer");
@@ -1862,8 +1883,14 @@ extern "C" int selfocc_msda_fused_bwd(const float *value, const int32_t *shapes,
     const long long blocks = (n_groups + gpb - 1) / gpb;
     SO_REQUIRE(blocks < (1LL << 31), "msda_fused_bwd: grid too large");
 #define SO_LAUNCH_G(DD, LG)                                                                                  \
-    hipLaunchKernelGGL((msda_fused_bwd_point_kernel<DD, LG>), dim3((unsigned)blocks), dim3(256), 0, st, value, \
-                       shapes, starts, ref, ref_kind, off_raw, logits, g_out, g_off, g_logits, w.keys, w.recs, dm)
+    if (value_dtype == SO_DTYPE_BF16)                                                                        \
+        hipLaunchKernelGGL((msda_fused_bwd_point_kernel<DD, LG, uint16_t>), dim3((unsigned)blocks), dim3(256), 0, st,  \
+                           (const uint16_t *)value, shapes, starts, ref, ref_kind, off_raw, logits, g_out, g_off,      \
+                           g_logits, w.keys, w.recs, dm);                                                    \
+    else                                                                                                     \
+        hipLaunchKernelGGL((msda_fused_bwd_point_kernel<DD, LG, float>), dim3((unsigned)blocks), dim3(256), 0, st,     \
+                           (const float *)value, shapes, starts, ref, ref_kind, off_raw, logits, g_out, g_off,         \
+                           g_logits, w.keys, w.recs, dm)
 #define SO_LAUNCH(DD)                                                                                        \
     switch (logG) {                                                                                          \
         case 0: SO_LAUNCH_G(DD, 0); break;                                                                   \
@@ -1886,15 +1913,16 @@ extern "C" int selfocc_msda_fused_bwd(const float *value, const int32_t *shapes,
 }
 
 
-extern "C" int selfocc_msda_cross_bwd(const float *value, const int32_t *shapes, const int32_t *starts,
+extern "C" int selfocc_msda_cross_bwd(const void *value, const int32_t *shapes, const int32_t *starts,
                                       const int32_t *host_shapes, const float *ref, const uint8_t *vis,
                                       const float *off_raw, const float *logits, const float *g_out,
                                       float *g_value, float *g_off, float *g_logits, int32_t cams, int32_t nv,
                                       int32_t nq, int32_t heads, int32_t d, int32_t L, int32_t P, int32_t value_layout,
-                                      void *workspace, size_t workspace_bytes, void *stream) {
+                                      int32_t value_dtype, void *workspace, size_t workspace_bytes, void *stream) {
     SO_REQUIRE(cams >= 1, "msda_cross_bwd: cams must be >= 1");
+    SO_REQUIRE(value_dtype == SO_DTYPE_F32 || value_dtype == SO_DTYPE_BF16, "msda_cross_bwd: bad value_dtype");
     SO_REQUIRE(value_layout == SO_VALUE_PIXEL_MAJOR || value_layout == SO_VALUE_HEAD_MAJOR, "msda_cross_bwd: bad value_layout");
-    if (validate(value, shapes, starts, off_raw, logits, cams, nv, nq, heads, d, L, P)) return -1;
+    if (validate((const float *)value, shapes, starts, off_raw, logits, cams, nv, nq, heads, d, L, P)) return -1;
     const long long n_groups = (long long)nq * heads;
     if (n_groups == 0) return 0;
     SO_REQUIRE(ref && vis && g_out && g_value && g_off && g_logits, "msda_cross_bwd: NULL pointer");
@@ -1928,8 +1956,14 @@ extern "C" int selfocc_msda_cross_bwd(const float *value, const int32_t *shapes,
     const long long blocks = (n_groups + gpb - 1) / gpb;
     SO_REQUIRE(blocks < (1LL << 31), "msda_cross_bwd: grid too large");
 #define SO_LAUNCH_G(DD, LG)                                                                                  \
-    hipLaunchKernelGGL((msda_cross_bwd_point_kernel<DD, LG>), dim3((unsigned)blocks), dim3(256), 0, st, value, \
-                       shapes, starts, ref, vis, off_raw, logits, g_out, g_off, g_logits, w.keys, w.recs, cams, dm)
+    if (value_dtype == SO_DTYPE_BF16)                                                                        \
+        hipLaunchKernelGGL((msda_cross_bwd_point_kernel<DD, LG, uint16_t>), dim3((unsigned)blocks), dim3(256), 0, st,  \
+                           (const uint16_t *)value, shapes, starts, ref, vis, off_raw, logits, g_out, g_off, g_logits, \
+                           w.keys, w.recs, cams, dm);                                                        \
+    else                                                                                                     \
+        hipLaunchKernelGGL((msda_cross_bwd_point_kernel<DD, LG, float>), dim3((unsigned)blocks), dim3(256), 0, st,     \
+                           (const float *)value, shapes, starts, ref, vis, off_raw, logits, g_out, g_off, g_logits,    \
+                           w.keys, w.recs, cams, dm)
 #define SO_LAUNCH(DD)                                                                                        \
     switch (logG) {                                                                                          \
         case 0: SO_LAUNCH_G(DD, 0); break;                                                                   \

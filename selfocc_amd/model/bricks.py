@@ -213,6 +213,12 @@ FUSED_TRAINING = True
 # forward 0.50 -> 0.47 ms, but the transposing copy per call costs more than that (eval encoder 12.5 -> 12.9 ms), so
 # the default stays mmcv's (bs, nv, heads, d) as projected; the layout pays only if `value` is produced head-major.
 HEAD_MAJOR_VALUE = False
+# True: the projected `value` of the deformable attentions is STORED as bfloat16 for the gathers (forward and backward
+# point kernels); arithmetic and gradients stay float32.  Halves the corner segments the L1-bound gathers move
+# (BASELINE configs[1]: "bf16"); deviates from the reference's float32 MSDA by the bf16 rounding of value (~2^-9
+# relative), so it is opt-in: the default reproduces the reference to 1e-4.  env SELFOCC_VALUE_BF16=1 sets it.
+import os as _os
+VALUE_BF16 = _os.environ.get('SELFOCC_VALUE_BF16', '0') == '1'
 
 
 def deformable_sampling(module, query, value, reference_points, spatial_shapes, level_start_index,
@@ -245,6 +251,8 @@ def deformable_sampling(module, query, value, reference_points, spatial_shapes, 
         kind = {'level': 0, 'point': 1, 'level_point': 2}[per_level_reference]
         if HEAD_MAJOR_VALUE:
             value = to_head_major(value)
+        if VALUE_BF16:
+            value = value.to(torch.bfloat16)
         return msda_fused_inference(value, spatial_shapes, level_start_index, reference_points, kind, off, logits,
                                     HEAD_MAJOR_VALUE)
     if FUSED_TRAINING and value.is_cuda and LP <= 256:
@@ -259,7 +267,7 @@ def deformable_sampling(module, query, value, reference_points, spatial_shapes, 
             if HEAD_MAJOR_VALUE:
                 value = to_head_major(value)
             return MSDAFusedFunction.apply(value, spatial_shapes, level_start_index, reference_points, kind, off,
-                                           logits, host, HEAD_MAJOR_VALUE)
+                                           logits, host, HEAD_MAJOR_VALUE, VALUE_BF16)
     aw = module.attention_weights(query).view(bs, num_query, module.num_heads,
                                               module.num_levels * module.num_points).softmax(-1)
     aw = aw.view(bs, num_query, module.num_heads, module.num_levels, module.num_points)

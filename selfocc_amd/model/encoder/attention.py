@@ -178,11 +178,13 @@ class BEVCrossAttention(BaseModule):
         vis_all = getattr(bev_masks, '_so_visible', None)                   # left by the HIP point_sampling
         visible = vis_all[:, 0] if vis_all is not None else bev_masks[:, 0].any(-1)   # (cams, Q), batch element 0 as the reference
         if host_shapes is None:
+            if bricks.VALUE_BF16 and v.dtype != torch.bfloat16:
+                v = v.to(torch.bfloat16)
             slots = msda_cross_inference(v, spatial_shapes, level_start_index, reference_points_cams[:, 0], visible,
                                          off, logits, hm)[None]
         else:
             slots = MSDACrossFunction.apply(v, spatial_shapes, level_start_index, reference_points_cams[:, 0], visible,
-                                            off, logits, host_shapes, hm)[None]
+                                            off, logits, host_shapes, hm, bricks.VALUE_BF16)[None]
         slots = self.output_proj(slots)
         if out is not None and not self.training and not torch.is_grad_enabled():
             return torch.add(slots, residual, out=out)      # eval: dropout is the identity; `out` = the caller's slice
@@ -229,6 +231,8 @@ class TPVCrossAttention(BaseModule):
                 w, b = self._merged_value_proj()
                 cams, l = value.shape[0], value.shape[1]
                 v_all = torch.addmm(b, value.permute(2, 0, 1, 3).reshape(cams * l, C), w.t()).view(cams, l, 3 * C)
+                if bricks.VALUE_BF16:
+                    v_all = v_all.to(torch.bfloat16)       # one cast for the three planes
                 if bricks.HEAD_MAJOR_VALUE:
                     # one transposing copy for the three planes: (plane, cams, heads, l, d), each plane dense
                     heads = self.attns[0].deformable_attention.num_heads

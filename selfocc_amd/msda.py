@@ -9,6 +9,7 @@ import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
 
+from . import abi
 from ._lib import lib, check, ptr, current_stream
 
 
@@ -120,6 +121,13 @@ def to_head_major(value):
     return value.permute(0, 2, 1, 3).contiguous()
 
 
+def _value_arg(value):
+    """(contiguous tensor, SO_DTYPE): bfloat16 storage is passed through, everything else as float32."""
+    if value.dtype == torch.bfloat16:
+        return value.contiguous(), abi.DTYPE_BF16
+    return value.contiguous().float(), abi.DTYPE_F32
+
+
 def _value_dims(value, head_major):
     if head_major:
         bs, heads, nv, d = value.shape
@@ -138,14 +146,14 @@ def msda_fused_inference(value, spatial_shapes, level_start_index, reference_poi
         raise RuntimeError("msda_fused_inference needs CUDA(HIP) tensors: selfocc_amd has no CPU fallback")
     bs, nv, heads, d = _value_dims(value, head_major)
     _, nq, _, L, P, _ = sampling_offsets.shape
-    value = value.contiguous().float()
+    value, vdt = _value_arg(value)
     off = sampling_offsets.contiguous().float()
     lg = attention_logits.contiguous().float()
     ref = reference_points.contiguous().float()
     sh, st = _i32(spatial_shapes, value.device), _i32(level_start_index, value.device)
     out = torch.empty(bs, nq, heads * d, device=value.device, dtype=torch.float32)
     check(lib().selfocc_msda_fused_fwd(ptr(value), ptr(sh), ptr(st), ptr(ref), int(ref_kind), ptr(off), ptr(lg),
-                                       ptr(out), bs, nv, nq, heads, d, L, P, int(bool(head_major)),
+                                       ptr(out), bs, nv, nq, heads, d, L, P, int(bool(head_major)), vdt,
                                        current_stream(value.device)),
           "selfocc_msda_fused_fwd")
     return out
@@ -163,11 +171,13 @@ def msda_cross_inference(value, spatial_shapes, level_start_index, reference_poi
     cams, nv, heads, d = _value_dims(value, head_major)
     nq, _, L, P, _ = sampling_offsets.shape
     vstride = 0
-    if (not head_major and value.dtype == torch.float32 and not value.is_contiguous() and value.stride(3) == 1 and value.stride(2) == d
+    vdt = abi.DTYPE_BF16 if value.dtype == torch.bfloat16 else abi.DTYPE_F32
+    if (not head_major and value.dtype in (torch.float32, torch.bfloat16) and not value.is_contiguous()
+            and value.stride(3) == 1 and value.stride(2) == d
             and value.stride(1) % 4 == 0 and value.stride(0) == nv * value.stride(1)):
         vstride = value.stride(1)        # a column block of a wider (cams * nv, N) matrix: no copy
     else:
-        value = value.contiguous().float()
+        value, vdt = _value_arg(value)
     off = sampling_offsets.contiguous().float()
     lg = attention_logits.contiguous().float()
     ref = reference_points_cam.contiguous().float()
@@ -176,7 +186,7 @@ def msda_cross_inference(value, spatial_shapes, level_start_index, reference_poi
     sh, st = _i32(spatial_shapes, value.device), _i32(level_start_index, value.device)
     out = torch.empty(nq, heads * d, device=value.device, dtype=torch.float32)
     check(lib().selfocc_msda_cross_fwd(ptr(value), ptr(sh), ptr(st), ptr(ref), ptr(vis), ptr(off), ptr(lg),
-                                       ptr(out), cams, nv, nq, heads, d, L, P, vstride, int(bool(head_major)),
+                                       ptr(out), cams, nv, nq, heads, d, L, P, vstride, int(bool(head_major)), vdt,
                                        current_stream(value.device)),
           "selfocc_msda_cross_fwd")
     return out
@@ -190,7 +200,9 @@ class MSDAFusedFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, value, spatial_shapes, level_start_index, reference_points, ref_kind, sampling_offsets,
-                attention_logits, host_shapes, head_major=False):
+                attention_logits, host_shapes, head_major=False, value_bf16=False):
+        if value_bf16:      # bfloat16 STORAGE of value for the gathers (forward and backward); gradients stay float32
+            value = value.to(torch.bfloat16)
         out = msda_fused_inference(value, spatial_shapes, level_start_index, reference_points, ref_kind,
                                    sampling_offsets, attention_logits, head_major)
         ctx.head_major = bool(head_major)
@@ -204,11 +216,12 @@ class MSDAFusedFunction(torch.autograd.Function):
     def backward(ctx, grad_output):
         import ctypes
         value, sh, st, ref, off, lg = ctx.saved_tensors
-        value, ref, off, lg = (t.contiguous().float() for t in (value, ref, off, lg))
+        ref, off, lg = (t.contiguous().float() for t in (ref, off, lg))
+        value, vdt = _value_arg(value)
         bs, nv, heads, d = _value_dims(value, ctx.head_major)
         _, nq, _, L, P, _ = off.shape
         g_out = grad_output.contiguous().float()
-        g_value = torch.zeros_like(value)
+        g_value = torch.zeros(value.shape, device=value.device, dtype=torch.float32)
         g_off = torch.empty_like(off)
         g_lg = torch.empty_like(lg)
         arr = (ctypes.c_int32 * len(ctx.host_shapes))(*ctx.host_shapes)
@@ -216,10 +229,10 @@ class MSDAFusedFunction(torch.autograd.Function):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=value.device)
         check(lib().selfocc_msda_fused_bwd(ptr(value), ptr(sh), ptr(st), ctypes.cast(arr, ctypes.c_void_p), ptr(ref),
                                            ctx.ref_kind, ptr(off), ptr(lg), ptr(g_out), ptr(g_value), ptr(g_off),
-                                           ptr(g_lg), bs, nv, nq, heads, d, L, P, int(ctx.head_major), ptr(ws), nbytes,
+                                           ptr(g_lg), bs, nv, nq, heads, d, L, P, int(ctx.head_major), vdt, ptr(ws), nbytes,
                                            current_stream(value.device)),
               "selfocc_msda_fused_bwd")
-        return g_value, None, None, None, None, g_off, g_lg, None, None
+        return g_value, None, None, None, None, g_off, g_lg, None, None, None
 
 
 def msda_fused_supported(host_shapes, bs, nq, heads, d, L, P):
@@ -238,7 +251,9 @@ class MSDACrossFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, value, spatial_shapes, level_start_index, reference_points_cam, visible, sampling_offsets,
-                attention_logits, host_shapes, head_major=False):
+                attention_logits, host_shapes, head_major=False, value_bf16=False):
+        if value_bf16:
+            value = value.to(torch.bfloat16)
         out = msda_cross_inference(value, spatial_shapes, level_start_index, reference_points_cam, visible,
                                    sampling_offsets, attention_logits, head_major)
         ctx.head_major = bool(head_major)
@@ -253,12 +268,13 @@ class MSDACrossFunction(torch.autograd.Function):
     def backward(ctx, grad_output):
         import ctypes
         value, sh, st, ref, vis, off, lg = ctx.saved_tensors
-        value, ref, off, lg = (t.contiguous().float() for t in (value, ref, off, lg))
+        ref, off, lg = (t.contiguous().float() for t in (ref, off, lg))
+        value, vdt = _value_arg(value)
         vis = vis.contiguous()
         cams, nv, heads, d = _value_dims(value, ctx.head_major)
         nq, _, L, P, _ = off.shape
         g_out = grad_output.contiguous().float()
-        g_value = torch.zeros_like(value)
+        g_value = torch.zeros(value.shape, device=value.device, dtype=torch.float32)
         g_off = torch.empty_like(off)
         g_lg = torch.empty_like(lg)
         arr = (ctypes.c_int32 * len(ctx.host_shapes))(*ctx.host_shapes)
@@ -266,7 +282,7 @@ class MSDACrossFunction(torch.autograd.Function):
         ws = torch.empty(nbytes, dtype=torch.uint8, device=value.device)
         check(lib().selfocc_msda_cross_bwd(ptr(value), ptr(sh), ptr(st), ctypes.cast(arr, ctypes.c_void_p), ptr(ref),
                                            ptr(vis), ptr(off), ptr(lg), ptr(g_out), ptr(g_value), ptr(g_off),
-                                           ptr(g_lg), cams, nv, nq, heads, d, L, P, int(ctx.head_major), ptr(ws),
+                                           ptr(g_lg), cams, nv, nq, heads, d, L, P, int(ctx.head_major), vdt, ptr(ws),
                                            nbytes, current_stream(value.device)),
               "selfocc_msda_cross_bwd")
-        return g_value, None, None, None, None, g_off, g_lg, None, None
+        return g_value, None, None, None, None, g_off, g_lg, None, None, None

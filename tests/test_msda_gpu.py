@@ -327,3 +327,56 @@ def test_msda_head_major_value_layout(hip, P, L, D):
         return (v.grad.permute(0, 2, 1, 3) if hm else v.grad), o.grad, lg.grad
     for x, y in zip(run_cross(True), run_cross(False)):
         assert torch.allclose(x, y, rtol=1e-5, atol=1e-5 * y.abs().max().item())
+
+
+@pytest.mark.parametrize("P,L,D", [(8, 4, 16), (48, 4, 16), (5, 2, 8), (3, 1, 32)])
+def test_msda_bf16_value_storage(hip, P, L, D):
+    """value_dtype = SO_DTYPE_BF16 (bfloat16 STORAGE of value, float32 arithmetic): the fused and camera-loop ops give
+    exactly what the float32 kernels give on bf16-rounded values (forward: same bits; backward: same gradients, g_value
+    float32), and stay within the bf16 rounding of value (2^-8 relative, stated tolerance) of the float32 result."""
+    from selfocc_amd.msda import MSDAFusedFunction, MSDACrossFunction, msda_fused_inference, msda_cross_inference
+    g = torch.Generator().manual_seed(P * 13 + L)
+    shapes = torch.tensor([[24, 50], [12, 25], [6, 13], [3, 7]][:L])
+    starts = torch.cat([torch.zeros(1, dtype=torch.int64), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    nv = int((shapes[:, 0] * shapes[:, 1]).sum())
+    cams, nq, H = 3, 260, 3
+    host = [int(v) for v in shapes.reshape(-1)]
+    d = torch.device("cuda:0")
+    sh, st = shapes.to(d), starts.to(d)
+    value = torch.randn(cams, nv, H, D, generator=g).to(d)
+    v_bf = value.to(torch.bfloat16)
+    v_rt = v_bf.float()                                     # what the bf16 kernels see, as float32
+    off = (torch.randn(cams, nq, H, L, P, 2, generator=g) * 3).to(d)
+    logits = (torch.randn(cams, nq, H, L * P, generator=g) * 2).to(d)
+    ref = (torch.rand(cams, nq, P, 2, generator=g) * 1.3 - 0.15).to(d)
+    a = msda_fused_inference(v_bf, sh, st, ref, 1, off, logits)
+    b = msda_fused_inference(v_rt, sh, st, ref, 1, off, logits)
+    full = msda_fused_inference(value, sh, st, ref, 1, off, logits)
+    assert a.dtype == torch.float32 and torch.equal(a, b)
+    assert (a - full).abs().max().item() <= 2.0 ** -8 * value.abs().max().item()
+    gout = torch.randn(cams, nq, H * D, generator=g).to(d)
+
+    def run_fused(bf):
+        v, o, lg = ((value if bf else v_rt).clone().requires_grad_(True), off.clone().requires_grad_(True),
+                    logits.clone().requires_grad_(True))
+        MSDAFusedFunction.apply(v, sh, st, ref, 1, o, lg, host, False, bf).backward(gout)
+        assert v.grad.dtype == torch.float32
+        return v.grad, o.grad, lg.grad
+    for x, y in zip(run_fused(True), run_fused(False)):
+        assert torch.allclose(x, y, rtol=1e-5, atol=1e-5 * y.abs().max().item())
+
+    offc, lgc = off[0].contiguous(), logits[0].contiguous()
+    refc = (torch.rand(cams, nq, P, 2, generator=g) * 1.4 - 0.2).to(d)
+    vis = (torch.rand(cams, nq, generator=g) < 0.5).to(d)
+    a = msda_cross_inference(v_bf, sh, st, refc, vis, offc, lgc)
+    b = msda_cross_inference(v_rt, sh, st, refc, vis, offc, lgc)
+    assert torch.equal(a, b)
+    goutc = torch.randn(nq, H * D, generator=g).to(d)
+
+    def run_cross(bf):
+        v, o, lg = ((value if bf else v_rt).clone().requires_grad_(True), offc.clone().requires_grad_(True),
+                    lgc.clone().requires_grad_(True))
+        MSDACrossFunction.apply(v, sh, st, refc, vis, o, lg, host, False, bf).backward(goutc)
+        return v.grad, o.grad, lg.grad
+    for x, y in zip(run_cross(True), run_cross(False)):
+        assert torch.allclose(x, y, rtol=1e-5, atol=1e-5 * y.abs().max().item())
