@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SELFOCC_ABI_VERSION 21
+#define SELFOCC_ABI_VERSION 22
 
 int selfocc_abi_version(void);
 const char *selfocc_last_error(void);
@@ -423,6 +423,24 @@ int selfocc_linear_wgrad_supported(int64_t T, int32_t N, int32_t K);
 size_t selfocc_linear_wgrad_workspace(int64_t T, int32_t N, int32_t K);
 int selfocc_linear_wgrad(const float *dy, const float *x, float *dw, float *db, int64_t T, int32_t N, int32_t K,
                          void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------------------
+ * Forward of the same tall-skinny projections with the elementwise steps that follow them in TPVFormerLayer /
+ * BEVFormerLayer folded into the epilogue (mmcv Linear / FFN / build_norm_layer(dict(type='LN')) under torch in the
+ * reference: model/encoder/bevformer/attention/image_cross_attention.py:130-136 `output_proj` + `dropout(slots) +
+ * residual`, mmcv FFN `identity + layers(x)`, tpvformer/tpvformer_encoder_layer.py:150-219 `norm`):
+ *     y (T, N; row stride ldy) = LN?( relu?( x (T, K) w (N, K)^T + bias ) + residual (T, N; row stride ldr) )
+ *   bias, residual: NULL = absent.  flags: SO_LINEAR_RELU (applied before the residual, as FFN does).
+ *   ln_gamma / ln_beta (N) non-NULL: LayerNorm over the N outputs (biased variance, eps = ln_eps), N <= 96; then the
+ *   optional outputs y_pre (T, N: the LayerNorm input), mean / rstd (T) are what selfocc_layernorm_bwd consumes.
+ * float32 (MFMA f32 = exact fmaf chains; only the summation order differs from a BLAS).  K must be 32, 64, 96, 128
+ * or 192 (selfocc_linear_fwd_supported).
+ * ---------------------------------------------------------------------------------- */
+enum { SO_LINEAR_RELU = 1 };
+int selfocc_linear_fwd_supported(int64_t T, int32_t N, int32_t K);
+int selfocc_linear_fwd(const float *x, const float *w, const float *bias, const float *residual, int32_t ldr,
+                       const float *ln_gamma, const float *ln_beta, float ln_eps, float *y, int32_t ldy, float *y_pre,
+                       float *mean, float *rstd, int64_t T, int32_t N, int32_t K, uint32_t flags, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Fused temporal reprojection photometric term.  Replaces the per-sample part of

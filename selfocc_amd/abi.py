@@ -6,7 +6,7 @@ its exported symbols being callable with these layouts.
 """
 import ctypes as C
 
-ABI_VERSION = 21
+ABI_VERSION = 22
 
 # enums ---------------------------------------------------------------------------
 RAYS_EXPLICIT, RAYS_PIXEL_GRID = 0, 1
@@ -16,6 +16,7 @@ JITTER_NONE, JITTER_SINGLE, JITTER_PER_BIN = 0, 1, 2
 FLAG_DEPTH_DIV_NORM, FLAG_CLAMP_RGB, FLAG_EXACT, FLAG_NO_SKIP, FLAG_NO_FACE_SAFE, FLAG_NO_AHEAD, FLAG_RAY_PER_LANE = 1, 2, 4, 8, 16, 32, 64
 VALUE_PIXEL_MAJOR, VALUE_HEAD_MAJOR = 0, 1
 DTYPE_F32, DTYPE_BF16 = 0, 1
+LINEAR_RELU = 1
 
 _f, _i, _p = C.c_float, C.c_int32, C.c_void_p
 
@@ -126,6 +127,8 @@ SYMBOLS = {
     "selfocc_linear_wgrad_supported": (C.c_int, [C.c_int64, _i, _i]),
     "selfocc_linear_wgrad_workspace": (C.c_size_t, [C.c_int64, _i, _i]),
     "selfocc_linear_wgrad": (C.c_int, [_p] * 4 + [C.c_int64, _i, _i, _p, C.c_size_t, _p]),
+    "selfocc_linear_fwd_supported": (C.c_int, [C.c_int64, _i, _i]),
+    "selfocc_linear_fwd": (C.c_int, [_p] * 4 + [_i, _p, _p, C.c_float, _p, _i, _p, _p, _p, C.c_int64, _i, _i, C.c_uint32, _p]),
     "selfocc_ssim_fwd": (C.c_int, [_p] * 4 + [_i] * 4 + [_p, _p]),
     "selfocc_ssim_bwd": (C.c_int, [_p] * 4 + [_i] * 4 + [_p, _p, _p, _p]),
     "selfocc_reproj_fwd": (C.c_int, [C.POINTER(SoReprojArgs), _p]),

@@ -24,3 +24,49 @@ def linear_wgrad(dy, x, with_bias=True):
     check(lib().selfocc_linear_wgrad(ptr(dy), ptr(x), ptr(dw), ptr(db), T, N, K, ptr(ws), nbytes,
                                      current_stream(dy.device)), "selfocc_linear_wgrad")
     return dw, db
+
+
+def linear_fwd_supported(rows, n_out, n_in):
+    return lib().selfocc_linear_fwd_supported(int(rows), int(n_out), int(n_in)) == 1
+
+
+def linear_fwd(x, weight, bias=None, relu=False, residual=None, ln=None, out=None, want_stats=False):
+    """y = LN?(relu?(x W^T + b) + residual) in one MFMA-f32 pass (csrc/linear_fwd.hip).
+
+    x (T, K), weight (N, K), bias (N) | None, residual (T, N) | None (row stride free, unit column stride),
+    ln = (gamma (N), beta (N), eps) | None, out (T, N) | None (row stride free: a column / row slice of a larger buffer).
+    -> y, or (y, y_pre, mean, rstd) with ``want_stats`` (the LayerNorm input and statistics selfocc_layernorm_bwd needs)."""
+    from .abi import LINEAR_RELU
+    if not x.is_cuda:
+        raise RuntimeError("linear_fwd needs CUDA(HIP) tensors: selfocc_amd has no CPU fallback")
+    T, K = x.shape
+    N = weight.shape[0]
+    assert weight.shape[1] == K and x.dtype == torch.float32 and weight.dtype == torch.float32
+    x, weight = x.contiguous(), weight.contiguous()
+    if bias is not None:
+        bias = bias.contiguous()
+    if out is None:
+        out = torch.empty(T, N, device=x.device, dtype=torch.float32)
+    assert out.shape == (T, N) and out.stride(1) == 1 and out.dtype == torch.float32
+    ldr = 0
+    if residual is not None:
+        assert residual.shape == (T, N) and residual.dtype == torch.float32
+        if residual.stride(1) != 1:
+            residual = residual.contiguous()
+        ldr = residual.stride(0) if T > 1 else N
+    g = b = y_pre = mean = rstd = None
+    eps = 0.0
+    if ln is not None:
+        g, b, eps = ln
+        g, b = g.contiguous(), b.contiguous()
+        if want_stats:
+            y_pre = torch.empty(T, N, device=x.device, dtype=torch.float32)
+            mean = torch.empty(T, device=x.device, dtype=torch.float32)
+            rstd = torch.empty(T, device=x.device, dtype=torch.float32)
+    elif want_stats:
+        raise ValueError("want_stats needs ln")
+    ldy = out.stride(0) if T > 1 else N
+    check(lib().selfocc_linear_fwd(ptr(x), ptr(weight), ptr(bias), ptr(residual), int(ldr), ptr(g), ptr(b), float(eps),
+                                   ptr(out), int(ldy), ptr(y_pre), ptr(mean), ptr(rstd), T, N, K,
+                                   LINEAR_RELU if relu else 0, current_stream(x.device)), "selfocc_linear_fwd")
+    return (out, y_pre, mean, rstd) if want_stats else out

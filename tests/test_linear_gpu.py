@@ -54,3 +54,69 @@ def test_tall_linear_backward_uses_fused_wgrad(hip):
     assert torch.allclose(xa.grad, xb.grad, rtol=1e-4, atol=1e-5)
     assert torch.allclose(lin.weight.grad, ref.weight.grad, rtol=1e-4, atol=1e-3)
     assert torch.allclose(lin.bias.grad, ref.bias.grad, rtol=1e-4, atol=1e-3)
+
+
+# ---- selfocc_linear_fwd (csrc/linear_fwd.hip): y = LN?(relu?(x W^T + b) + residual) -------------------------------
+FWD_SHAPES = [(66049, 384, 96), (78899, 432, 96), (7967, 2304, 96), (78899, 96, 192), (78899, 216, 96), (8200, 25, 96),
+              (9000, 96, 32), (8192, 70, 64), (8193, 33, 128), (70, 96, 96), (1, 5, 96), (129, 288, 96), (4099, 192, 96)]
+
+
+@pytest.mark.parametrize("T,N,K", FWD_SHAPES)
+def test_linear_fwd_matches_f64(hip, T, N, K):
+    """float32 MFMA = exact fmaf chains: within a few ulp of the float64 product; bias / ReLU / residual epilogues;
+    strided output (a column block of a wider buffer) and strided residual."""
+    from selfocc_amd.linear import linear_fwd, linear_fwd_supported
+    assert linear_fwd_supported(T, N, K)
+    g = torch.Generator().manual_seed(T + N + K)
+    x = torch.randn(T, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    want = x.double() @ w.double().t() + b.double()
+    y = linear_fwd(x, w, b)
+    tol = 2e-6 * max(1.0, want.abs().max().item())
+    assert (y.double() - want).abs().max().item() < tol
+    assert (linear_fwd(x, w, None).double() - (want - b.double())).abs().max().item() < tol
+    assert torch.equal(linear_fwd(x, w, b), y)          # deterministic
+    y = linear_fwd(x, w, b, relu=True)
+    assert (y.double() - want.clamp_min(0)).abs().max().item() < tol
+    wide = torch.randn(T, N + 40, generator=g).cuda()
+    res = wide[:, 7:7 + N]                              # row stride N + 40
+    buf = torch.full((T, 2 * N + 3), 7.0).cuda()
+    out = buf[:, N:2 * N]
+    r = linear_fwd(x, w, b, relu=True, residual=res, out=out)
+    assert r.data_ptr() == out.data_ptr()
+    assert (out.double() - (want.clamp_min(0) + res.double())).abs().max().item() < 2 * tol
+    assert torch.all(buf[:, :N] == 7.0) and torch.all(buf[:, 2 * N:] == 7.0)      # nothing written outside the block
+
+
+@pytest.mark.parametrize("T,N,K", [(78899, 96, 96), (78899, 96, 192), (7967, 96, 96), (130, 96, 96), (4100, 64, 96),
+                                   (4100, 40, 64), (33, 96, 128)])
+def test_linear_fwd_layernorm_epilogue(hip, T, N, K):
+    """output_proj + residual + norm of a TPVFormerLayer step in one launch == torch float64; the saved statistics are
+    what selfocc_layernorm_bwd takes."""
+    from selfocc_amd.linear import linear_fwd
+    g = torch.Generator().manual_seed(T * 3 + N)
+    x = torch.randn(T, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    res = torch.randn(T, N, generator=g).cuda()
+    gamma = (1 + 0.1 * torch.randn(N, generator=g)).cuda()
+    beta = (0.1 * torch.randn(N, generator=g)).cuda()
+    pre = x.double() @ w.double().t() + b.double() + res.double()
+    want = torch.nn.functional.layer_norm(pre, (N,), gamma.double(), beta.double(), 1e-5)
+    y, y_pre, mean, rstd = linear_fwd(x, w, b, residual=res, ln=(gamma, beta, 1e-5), want_stats=True)
+    assert (y_pre.double() - pre).abs().max().item() < 4e-6 * max(1.0, pre.abs().max().item())
+    assert (y.double() - want).abs().max().item() < 2e-5
+    assert (mean.double() - pre.mean(1)).abs().max().item() < 1e-5
+    assert (rstd.double() - 1 / (pre.var(1, unbiased=False) + 1e-5).sqrt()).abs().max().item() < 1e-4
+    y2 = linear_fwd(x, w, b, residual=res, ln=(gamma, beta, 1e-5))
+    assert torch.equal(y, y2)
+
+
+def test_linear_fwd_unsupported_shape_is_loud(hip):
+    from selfocc_amd.linear import linear_fwd, linear_fwd_supported
+    assert not linear_fwd_supported(1000, 96, 100)
+    with pytest.raises(RuntimeError):
+        linear_fwd(torch.randn(1000, 100).cuda(), torch.randn(96, 100).cuda())
+    with pytest.raises(RuntimeError):       # LayerNorm epilogue needs the whole row in one column block
+        linear_fwd(torch.randn(1000, 96).cuda(), torch.randn(192, 96).cuda(), ln=(torch.ones(192).cuda(), torch.zeros(192).cuda(), 1e-5))
