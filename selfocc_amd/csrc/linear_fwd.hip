@@ -7,26 +7,29 @@
 // tpvformer/tpvformer_encoder_layer.py:150-219).
 //
 // Shapes: 6 k - 180 k rows, K = 96 (192) inputs, N = 96 .. 2304 outputs, float32.  The vendor GEMMs picked for
-// these shapes run at 35 - 50 TFLOP/s and ~1 TB/s of output (profiles/r2_c_eval_kernel_trace.txt: 3.7 ms of the
-// 8.9 ms eval encoder), then a residual add and a LayerNorm stream the same rows twice more.  The work is bound by
-// the OUTPUT write (N >= K) and by the f32 MFMA rate at the same time (66 049 x 384 x 96: 101 MB out = 25 us at
-// 4 TB/s, 4.9 GFLOP = 31 us at 155 TFLOP/s), so the kernel keeps both busy and does nothing else:
-//   * a block owns a 96-column slice of W in LDS (row stride K + 4 floats: conflict-free ds_read_b128) and walks
-//     over 128-row tiles; a wave owns 32 rows x 96 columns = three v_mfma_f32_32x32x2_f32 accumulators;
-//   * the A operand (32 rows x K) is loaded ONCE per tile straight into MFMA layout: the reduction index is
-//     permuted so that lane (row i, half h) holds x[row][h K/2 .. (h+1) K/2) — K/8 float4 loads per lane — and the
-//     B operand read from LDS uses the same permutation (W[n][h K/2 + j]);
-//   * the epilogue works on the accumulator layout (a lane holds one column of 16 rows; the 32 lanes of a half wave
-//     hold 32 consecutive columns of a row): bias / ReLU / residual per element, LayerNorm by two 5-step shuffle
-//     reductions per row, every store a 128-byte row segment.
+// these shapes run at 35 - 65 TFLOP/s (profiles/r2_c_eval_kernel_trace.txt: 3.7 ms of the 8.9 ms eval encoder), then a
+// residual add and a LayerNorm stream the same rows twice more.  The work is bound by the OUTPUT write (N >= K) and by
+// the f32 MFMA rate at the same time (66 049 x 384 x 96: 101 MB out = 25 us at 4 TB/s, 4.9 GFLOP = 31 us at the
+// 155 TFLOP/s of f32 MFMA — 38 us at the ~1.95 GHz the chip sustains under dense MFMA), so the kernel does nothing else:
+//   * a persistent block owns a 96-column slice of W in LDS (row stride K + 4 floats: conflict-free ds_read_b128,
+//     staged with all loads in flight) and its waves walk over 16-row tiles of x;
+//   * the A operand (16 rows x K) is loaded ONCE per tile straight into MFMA layout: the reduction index is
+//     permuted so that lane (row m, quarter kq) holds x[row][kq K/4 .. (kq+1) K/4) — K/16 float4 loads per lane — and
+//     the B operand read from LDS uses the same permutation (W[n][kq K/4 + j]);
+//   * the epilogue works on the accumulator layout (a lane holds one column of 4 rows; 16 lanes hold 16 consecutive
+//     columns of a row): bias / ReLU / residual per element, LayerNorm by two 4-step shuffle reductions per row.
 // f32 MFMA on gfx950 is an exact fmaf chain: float32 arithmetic, only the summation order differs from a BLAS.
+// Measured (scripts/micro/linear_fwd_bench.py, one layer's twelve projections): hipBLASLt 742 us -> 543 us; output_proj +
+// residual + LayerNorm of a 78 899 x 96 plane tensor 124 us (three torch kernels) -> 34 us.  What was tried on the way
+// (gpurun_out/linear_fwd_bench_*.txt): 32-row tiles on v_mfma_f32_32x32x2_f32 with three 16-register accumulators
+// (118 - 164 VGPRs, 2 - 3 waves per SIMD, half as many work units: 576 - 672 us); more resident waves (4 per SIMD:
+// 612 us, 8-wave blocks 664 us) — fewer, longer-lived waves win because every extra resident block re-stages its
+// slice of W and scatters the output stream over more DRAM pages at once.
 #include "so_device.h"
 #include <algorithm>
 #include <cstdlib>
 
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct LinearFwdArgs {
     const float *x, *w, *bias, *residual, *gamma, *beta;
@@ -44,165 +47,157 @@ SO_DEVFN unsigned so_lin_xcd_block() {   // workgroup b runs on XCD b % 8: give 
     return x * q + (x < r ? x : r) + k;
 }
 
-// Epilogue of one wave's 32-row x (32 NT)-column tile.  FULL: all 32 rows and every column of the NT tiles exist
-// — no per-element predicates (the predicated form compiles to a branch per load / store and keeps every value alive:
-// 230 registers); the ragged edge blocks take the predicated instantiation.
-template <bool LN, bool FULL, int NT>
-SO_DEVFN void so_linear_epilogue(f32x16 (&acc)[NT], const float (&bv)[NT], const float (&gv)[NT], const float (&bt)[NT],
-                                 const bool (&cok)[NT], float relu_lo, const float *rb, int ldr, float *yb, int ldy,
-                                 float *pb, float *mb, float *sb, int N, float eps, int rem, int i, int half) {
+// 16-row wave tiles on v_mfma_f32_16x16x4_f32 (same f32 rate as 32x32x2, half the registers per wave: A operand K / 4,
+// six 4-register accumulators for 96 columns; twice as many work units to balance over the 1 024 SIMDs).
+//   A[m][k]: lane (m = l % 16, kq = l / 16) holds x[row m][kq K/4 .. (kq+1) K/4)     (K / 16 float4 loads per lane)
+//   B[k][n]: lane (n = l % 16, kq) reads W[n0 + 16 t + n][kq K/4 + j] from LDS (row stride K + 4: conflict-free b128)
+//   D[m][n]: lane holds column n = l % 16 of rows 4 kq + j, j = 0..3
+// Two column tiles are interleaved so that no MFMA waits for its own accumulator (40 cycles dependent latency vs 32 issue).
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <bool LN, bool FULL, int NT16>
+SO_DEVFN void so_linear_epilogue16(f32x4 (&acc)[NT16], const float (&bv)[NT16], const float (&gv)[NT16],
+                                   const float (&bt)[NT16], const bool (&cok)[NT16], float relu_lo, const float *rb, int ldr,
+                                   float *yb, int ldy, float *pb, float *mb, float *sb, int N, float eps, int rem, int n,
+                                   int kq) {
     const float inv_n = 1.0f / (float)N;
 #pragma unroll
-    for (int v = 0; v < 16; ++v) {
-        const int rl = (v & 3) + 8 * (v >> 2) + 4 * half;
+    for (int j = 0; j < 4; ++j) {
+        const int rl = 4 * kq + j;
         const bool rok = FULL || rl < rem;
-        float o[NT];
+        float o[NT16];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) o[t] = fmaxf(acc[t][v] + bv[t], relu_lo);
+        for (int t = 0; t < NT16; ++t) o[t] = fmaxf(acc[t][j] + bv[t], relu_lo);
         if (rb) {
-            const unsigned ro = (unsigned)(rl * ldr + i);
+            const unsigned ro = (unsigned)(rl * ldr + n);
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                if (FULL) o[t] += rb[ro + 32 * t];
-                else o[t] += (rok && cok[t]) ? rb[ro + 32 * t] : 0.0f;
+            for (int t = 0; t < NT16; ++t) {
+                if (FULL) o[t] += rb[ro + 16 * t];
+                else o[t] += (rok && cok[t]) ? rb[ro + 16 * t] : 0.0f;
             }
         }
-        const unsigned yo = (unsigned)(rl * ldy + i);
+        const unsigned yo = (unsigned)(rl * ldy + n);
         if (LN) {
             if (pb) {
-                const unsigned po = (unsigned)(rl * N + i);
+                const unsigned po = (unsigned)(rl * N + n);
 #pragma unroll
-                for (int t = 0; t < NT; ++t)
-                    if (FULL || (rok && cok[t])) pb[po + 32 * t] = o[t];
+                for (int t = 0; t < NT16; ++t)
+                    if (FULL || (rok && cok[t])) pb[po + 16 * t] = o[t];
             }
             float s = 0.0f;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) s += cok[t] ? o[t] : 0.0f;
+            for (int t = 0; t < NT16; ++t) s += cok[t] ? o[t] : 0.0f;
 #pragma unroll
-            for (int m = 1; m < 32; m <<= 1) s += __shfl_xor(s, m, 64);
+            for (int m = 1; m < 16; m <<= 1) s += __shfl_xor(s, m, 64);
             const float mean = s * inv_n;
-            float d[NT], q2 = 0.0f;
+            float d[NT16], q2 = 0.0f;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
+            for (int t = 0; t < NT16; ++t) {
                 d[t] = cok[t] ? o[t] - mean : 0.0f;
                 q2 += d[t] * d[t];
             }
 #pragma unroll
-            for (int m = 1; m < 32; m <<= 1) q2 += __shfl_xor(q2, m, 64);
+            for (int m = 1; m < 16; m <<= 1) q2 += __shfl_xor(q2, m, 64);
             const float rstd = 1.0f / sqrtf(q2 * inv_n + eps);
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-                if (FULL || (rok && cok[t])) yb[yo + 32 * t] = fmaf(d[t] * rstd, gv[t], bt[t]);
-            if (mb && i == 0 && rok) { mb[rl] = mean; sb[rl] = rstd; }
+            for (int t = 0; t < NT16; ++t)
+                if (FULL || (rok && cok[t])) yb[yo + 16 * t] = fmaf(d[t] * rstd, gv[t], bt[t]);
+            if (mb && n == 0 && rok) { mb[rl] = mean; sb[rl] = rstd; }
         } else {
 #pragma unroll
-            for (int t = 0; t < NT; ++t)
-                if (FULL || (rok && cok[t])) yb[yo + 32 * t] = o[t];
+            for (int t = 0; t < NT16; ++t)
+                if (FULL || (rok && cok[t])) yb[yo + 16 * t] = o[t];
         }
     }
 }
 
-template <int KH, bool LN, int NT>
-__global__ __launch_bounds__(256, ((KH <= 64 && !LN) ? 3 : 2)) void linear_fwd_kernel(LinearFwdArgs a) {
-    constexpr int K = 2 * KH, KP = K + 4;
-    extern __shared__ __attribute__((aligned(16))) float wl[];    // [96][KP]
+template <int KQ /* K / 4 */, bool LN, int NT /* 32-column tiles per block */, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void linear_fwd16_kernel(LinearFwdArgs a) {
+    constexpr int K = 4 * KQ, KP = K + 4, NT16 = 2 * NT, THREADS = WAVES * 64;
+    extern __shared__ __attribute__((aligned(16))) float wl[];    // [32 NT][KP]
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int i = lane & 31, half = lane >> 5;
+    const int n = lane & 15, kq = lane >> 4;
     const unsigned logical = so_lin_xcd_block();
-    // (the division runs on the vector ALU; readfirstlane brings the results back to scalar registers so that every
-    // base pointer below is scalar and the loads / stores take the saddr + 32-bit lane offset form)
     const int cb = __builtin_amdgcn_readfirstlane((int)(logical % (unsigned)a.ncb));
     const long long rc = __builtin_amdgcn_readfirstlane((int)(logical / (unsigned)a.ncb));
     const int n0 = a.col0 + cb * 96;
-
-    {   // stage the block's slice of W: all of a thread's loads in flight, then the LDS writes (a dependent
-        // load -> write chain per float4 cost ~5 us per block)
-        constexpr int NV = NT * 32 * (K / 4), PER = (NV + 255) / 256;
+    {
+        constexpr int NV = NT * 32 * (K / 4), PER = (NV + THREADS - 1) / THREADS;
         float4 wv[PER];
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
-            const int idx = threadIdx.x + 256 * j;
-            const int n = idx / (K / 4), k4 = idx - n * (K / 4);
+            const int idx = threadIdx.x + THREADS * j;
+            const int r = idx / (K / 4), k4 = idx - r * (K / 4);
             wv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (idx < NV && n0 + n < a.N) wv[j] = ((const float4 *)(a.w + (size_t)(n0 + n) * K))[k4];
+            if (idx < NV && n0 + r < a.N) wv[j] = ((const float4 *)(a.w + (size_t)(n0 + r) * K))[k4];
         }
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
-            const int idx = threadIdx.x + 256 * j;
-            const int n = idx / (K / 4), k4 = idx - n * (K / 4);
-            if (idx < NV) *(float4 *)(wl + n * KP + 4 * k4) = wv[j];
+            const int idx = threadIdx.x + THREADS * j;
+            const int r = idx / (K / 4), k4 = idx - r * (K / 4);
+            if (idx < NV) *(float4 *)(wl + r * KP + 4 * k4) = wv[j];
         }
     }
     __syncthreads();
 
-    const bool full_cols = a.N - n0 >= 32 * NT;          // every column of the block's NT tiles exists
+    const bool full_cols = a.N - n0 >= 32 * NT;
     const float relu_lo = a.relu ? 0.0f : -__builtin_huge_valf();
-    float bv[NT], gv[NT], bt[NT];
-    bool cok[NT];
+    float bv[NT16], gv[NT16], bt[NT16];
+    bool cok[NT16];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int col = n0 + 32 * t + i;
+    for (int t = 0; t < NT16; ++t) {
+        const int col = n0 + 16 * t + n;
         cok[t] = col < a.N;
         bv[t] = (a.bias && cok[t]) ? a.bias[col] : 0.0f;
         gv[t] = (LN && cok[t]) ? a.gamma[col] : 0.0f;
         bt[t] = (LN && cok[t]) ? a.beta[col] : 0.0f;
     }
 
-    // persistent: block (column block cb, row group rc) walks over the 32-row wave tiles rc * 4 + wave + 4 G j.
-    // Everything is addressed as (wave-uniform 64-bit base) + (32-bit lane offset): saddr-form loads / stores, no
-    // 64-bit address per element in registers.
-    const long long nwt = (a.T + 31) / 32, wt_step = 4LL * a.groups;
-    long long wt = rc * 4 + wave;
-    float av[KH];
-    auto load_a = [&](long long wtile) {
-        const long long r0 = wtile * 32;
-        const int rm = (int)min(32LL, a.T - r0);
-        const float *xb = a.x + r0 * K;
-        const unsigned xoff = (unsigned)(min(i, rm - 1) * K + half * KH);
+    const long long nwt = (a.T + 15) / 16, wt_step = (long long)WAVES * a.groups;
+    for (long long wt = rc * WAVES + wave; wt < nwt; wt += wt_step) {
+        const long long row0 = wt * 16;
+        const int rem = (int)min(16LL, a.T - row0);
+        const float *xb = a.x + row0 * K;
+        const unsigned xoff = (unsigned)(min(n, rem - 1) * K + kq * KQ);
+        float av[KQ];
 #pragma unroll
-        for (int q = 0; q < KH / 4; ++q) {
+        for (int q = 0; q < KQ / 4; ++q) {
             const float4 v = *(const float4 *)(xb + xoff + 4 * q);
             av[4 * q] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
         }
-    };
-    if (wt < nwt) load_a(wt);
-    for (; wt < nwt; wt += wt_step) {
-        const long long row0 = wt * 32;
-        const int rem = (int)min(32LL, a.T - row0);                   // live rows of this wave's tile
-        f32x16 acc[NT];
+        f32x4 acc[NT16];
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+        for (int t = 0; t < NT16; ++t)
 #pragma unroll
-            for (int v = 0; v < 16; ++v) acc[t][v] = 0.0f;
+            for (int j = 0; j < 4; ++j) acc[t][j] = 0.0f;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const float *bp = wl + (32 * t + i) * KP + half * KH;
+        for (int tp = 0; tp < NT; ++tp) {
+            const float *b0p = wl + (32 * tp + n) * KP + kq * KQ, *b1p = b0p + 16 * KP;
 #pragma unroll
-            for (int q = 0; q < KH / 4; ++q) {
-                const float4 b = *(const float4 *)(bp + 4 * q);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[4 * q], b.x, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[4 * q + 1], b.y, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[4 * q + 2], b.z, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[4 * q + 3], b.w, acc[t], 0, 0, 0);
+            for (int q = 0; q < KQ / 4; ++q) {
+                const float4 b0 = *(const float4 *)(b0p + 4 * q), b1 = *(const float4 *)(b1p + 4 * q);
+                acc[2 * tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q], b0.x, acc[2 * tp], 0, 0, 0);
+                acc[2 * tp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q], b1.x, acc[2 * tp + 1], 0, 0, 0);
+                acc[2 * tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q + 1], b0.y, acc[2 * tp], 0, 0, 0);
+                acc[2 * tp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q + 1], b1.y, acc[2 * tp + 1], 0, 0, 0);
+                acc[2 * tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q + 2], b0.z, acc[2 * tp], 0, 0, 0);
+                acc[2 * tp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q + 2], b1.z, acc[2 * tp + 1], 0, 0, 0);
+                acc[2 * tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q + 3], b0.w, acc[2 * tp], 0, 0, 0);
+                acc[2 * tp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q + 3], b1.w, acc[2 * tp + 1], 0, 0, 0);
             }
         }
-        // the A registers are dead now: the next tile's loads fly while this tile's epilogue runs
-        if (wt + wt_step < nwt) load_a(wt + wt_step);
-        // epilogue on the accumulator layout: element v of tile t = row (v & 3) + 8 (v >> 2) + 4 half, column 32 t + i
         const float *rb = a.residual ? a.residual + row0 * a.ldr + n0 : nullptr;
         float *yb = a.y + row0 * a.ldy + n0;
         float *pb = (LN && a.y_pre) ? a.y_pre + row0 * a.N : nullptr;
         float *mb = (LN && a.mean) ? a.mean + row0 : nullptr, *sb = (LN && a.mean) ? a.rstd + row0 : nullptr;
-        // the per-row offsets of the epilogue are loop-invariant; hoisted out of the tile loop they would occupy
-        // 30 - 60 registers across the MFMA phase — an opaque copy of the lane index keeps them inside
-        int io = i;
-        asm volatile("" : "+v"(io));
-        if (rem == 32 && full_cols)
-            so_linear_epilogue<LN, true, NT>(acc, bv, gv, bt, cok, relu_lo, rb, a.ldr, yb, a.ldy, pb, mb, sb, a.N, a.eps, rem,
-                                             io, half);
+        int no = n;
+        asm volatile("" : "+v"(no));      // keeps the loop-invariant row offsets of the epilogue inside the loop
+        if (rem == 16 && full_cols)
+            so_linear_epilogue16<LN, true, NT16>(acc, bv, gv, bt, cok, relu_lo, rb, a.ldr, yb, a.ldy, pb, mb, sb, a.N, a.eps,
+                                                 rem, no, kq);
         else
-            so_linear_epilogue<LN, false, NT>(acc, bv, gv, bt, cok, relu_lo, rb, a.ldr, yb, a.ldy, pb, mb, sb, a.N, a.eps, rem,
-                                              io, half);
+            so_linear_epilogue16<LN, false, NT16>(acc, bv, gv, bt, cok, relu_lo, rb, a.ldr, yb, a.ldy, pb, mb, sb, a.N, a.eps,
+                                                  rem, no, kq);
     }
 }
 
@@ -243,51 +238,49 @@ extern "C" int selfocc_linear_fwd(const float *x, const float *w, const float *b
         a.ncb = pass == 0 ? ncb_full : 1;
         a.col0 = pass == 0 ? 0 : 96 * ncb_full;
         if ((pass == 0 && ncb_full == 0) || (pass == 1 && tail_nt == 0)) continue;
-        // persistent grid: as many blocks as the chip holds at once (LDS: 160 KB per CU), split evenly over the column
-        // blocks; each block keeps its slice of W and walks over its share of the 32-row wave tiles
         const size_t lds_blk = (size_t)nt * 32 * (K + 4) * sizeof(float);
-        // blocks per CU: registers allow 3 waves per SIMD (2 with the LayerNorm epilogue or K = 192), LDS 160 KB
-        const long long by_regs = (K <= 128 && !ln) ? 3 : 2;
-        const long long per_cu = std::max<long long>(1, std::min<long long>(by_regs, (160 * 1024) / (long long)(lds_blk + 512)));
-        static const long long slots_env = getenv("SELFOCC_LINEAR_SLOTS") ? atoll(getenv("SELFOCC_LINEAR_SLOTS")) : 0;   // dev A/B
-        const long long slots = slots_env > 0 ? slots_env : 256 * per_cu;
-        const long long nwt = (T + 31) / 32;
-        long long groups = std::max(1LL, slots / a.ncb);
+        static const long long percu_env = getenv("SELFOCC_LINEAR_PERCU") ? atoll(getenv("SELFOCC_LINEAR_PERCU")) : 0;  // dev A/B
+        // persistent grid: two 4-wave blocks per CU (measured best: 1 / 2 / 3 / 4 per CU = 561 / 543 / 595 / 612 us over
+        // the encoder's twelve shapes), split evenly over the column blocks; a block's waves take the 16-row tiles
+        // (group * 4 + wave) + 4 groups j
+        long long per_cu = std::max<long long>(1, std::min<long long>(2, (160 * 1024) / (long long)(lds_blk + 512)));
+        if (percu_env > 0) per_cu = percu_env;
+        const long long nwt = (T + 15) / 16;
+        long long groups = std::max(1LL, 256 * per_cu / a.ncb);
         groups = std::min(groups, (nwt + 3) / 4);
         a.groups = (int)groups;
         const long long nblk = groups * a.ncb;
-        const size_t lds = (size_t)nt * 32 * (K + 4) * sizeof(float);
-#define SO_LAUNCH1(KH_, LN_, NT_)                                                                                    \
+#define SO_L16_1(KQ_, LN_, NT_)                                                                                       \
     do {                                                                                                             \
         static bool attr_set = false;                                                                                \
-        if (!attr_set && lds > 48 * 1024) {                                                                          \
-            (void)hipFuncSetAttribute((const void *)linear_fwd_kernel<KH_, LN_, NT_>,                                \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+        if (!attr_set && lds_blk > 48 * 1024) {                                                                      \
+            (void)hipFuncSetAttribute((const void *)linear_fwd16_kernel<KQ_, LN_, NT_, 4>,                           \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_blk);                     \
             attr_set = true;                                                                                         \
         }                                                                                                            \
-        hipLaunchKernelGGL((linear_fwd_kernel<KH_, LN_, NT_>), dim3((unsigned)nblk), dim3(256), lds, st, a);         \
+        hipLaunchKernelGGL((linear_fwd16_kernel<KQ_, LN_, NT_, 4>), dim3((unsigned)nblk), dim3(256), lds_blk, st, a); \
     } while (0)
-#define SO_LAUNCH2(KH_, LN_)                                                                                         \
+#define SO_L16_2(KQ_, LN_)                                                                                            \
     do {                                                                                                             \
-        if (nt == 3) SO_LAUNCH1(KH_, LN_, 3);                                                                        \
-        else if (nt == 2) SO_LAUNCH1(KH_, LN_, 2);                                                                   \
-        else SO_LAUNCH1(KH_, LN_, 1);                                                                                \
+        if (nt == 3) SO_L16_1(KQ_, LN_, 3);                                                                          \
+        else if (nt == 2) SO_L16_1(KQ_, LN_, 2);                                                                     \
+        else SO_L16_1(KQ_, LN_, 1);                                                                                  \
     } while (0)
-#define SO_LAUNCH(KH_)                                                                                               \
+#define SO_L16_3(KQ_)                                                                                                 \
     do {                                                                                                             \
-        if (ln) SO_LAUNCH2(KH_, true);                                                                               \
-        else SO_LAUNCH2(KH_, false);                                                                                 \
+        if (ln) SO_L16_2(KQ_, true);                                                                                 \
+        else SO_L16_2(KQ_, false);                                                                                   \
     } while (0)
         switch (K) {
-            case 32: SO_LAUNCH(16); break;
-            case 64: SO_LAUNCH(32); break;
-            case 96: SO_LAUNCH(48); break;
-            case 128: SO_LAUNCH(64); break;
-            default: SO_LAUNCH(96); break;
+            case 32: SO_L16_3(8); break;
+            case 64: SO_L16_3(16); break;
+            case 96: SO_L16_3(24); break;
+            case 128: SO_L16_3(32); break;
+            default: SO_L16_3(48); break;
         }
-#undef SO_LAUNCH
-#undef SO_LAUNCH2
-#undef SO_LAUNCH1
+#undef SO_L16_3
+#undef SO_L16_2
+#undef SO_L16_1
     }
     return so_launch_status();
 }

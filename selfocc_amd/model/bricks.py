@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from ..registry import MODELS
-from ..linear import linear_wgrad, wgrad_supported
+from ..linear import linear_wgrad, wgrad_supported, linear_fwd, linear_fwd_supported
 from ..msda import (MultiScaleDeformableAttnFunction, msda_fused_inference, MSDAFusedFunction, to_head_major,
                     msda_fused_supported)
 
@@ -111,6 +111,56 @@ def build_activation_layer(cfg):
 
 # weight / bias gradients of _TallLinear through selfocc_linear_wgrad (False: batched GEMMs + torch reductions, A/B)
 FUSED_WGRAD = True
+# forward of the tall projections (and, in inference, the residual add / LayerNorm that follow them) through
+# selfocc_linear_fwd (csrc/linear_fwd.hip); False: torch.addmm + separate elementwise kernels (A/B)
+import os as _os0
+FUSED_LINEAR_FWD = _os0.environ.get('SELFOCC_FUSED_LINEAR', '1') == '1'
+LINEAR_FWD_MIN_ROWS = 1024
+
+
+def _linear_fwd_ok(x2d, weight):
+    return (x2d.is_cuda and x2d.dtype == torch.float32 and weight.dtype == torch.float32
+            and x2d.shape[0] >= LINEAR_FWD_MIN_ROWS and linear_fwd_supported(x2d.shape[0], weight.shape[0], x2d.shape[1]))
+
+
+def fused_linear(lin, x, relu=False, residual=None, norm=None, out=None):
+    """Inference form of ``norm(relu(lin(x)) + residual)`` (each part optional) for (..., K) activations: ONE
+    selfocc_linear_fwd launch when the shape qualifies (CUDA float32, >= LINEAR_FWD_MIN_ROWS rows, K in 32 / 64 / 96 /
+    128 / 192, LayerNorm width <= 96), else the separate torch / HIP steps in the reference's order (mmcv FFN:
+    ``identity + layers(x)``; image_cross_attention.py:136 ``dropout(slots) + residual``; then the layer's `norm`).
+    ``out``: optional (..., N) destination with unit column stride (a slice of a larger buffer)."""
+    N, K = lin.weight.shape
+    lead = x.shape[:-1]
+    rows = x.numel() // max(K, 1)
+    x2 = x.reshape(rows, K)
+    ln_ok = norm is None or (isinstance(norm, nn.LayerNorm) and norm.elementwise_affine and norm.bias is not None
+                             and tuple(norm.normalized_shape) == (N,) and N <= 96)
+    if (FUSED_LINEAR_FWD and not torch.is_grad_enabled() and ln_ok and _linear_fwd_ok(x2, lin.weight)
+            and not torch.is_autocast_enabled()):
+        r2 = residual.reshape(rows, N) if residual is not None else None
+        o2 = None
+        if out is not None and out.stride(-1) == 1:
+            o2 = out.view(rows, N) if out.is_contiguous() else (out[0] if out.dim() == 3 and out.shape[0] == 1 else None)
+        ln = (norm.weight, norm.bias, norm.eps) if norm is not None else None
+        y = linear_fwd(x2, lin.weight, lin.bias, relu=relu, residual=r2, ln=ln, out=o2)
+        if o2 is not None:
+            return out
+        y = y.view(*lead, N)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
+    y = lin(x)
+    if relu:
+        y = torch.relu(y)
+    if residual is not None:
+        y = y + residual
+    if norm is not None:
+        y = norm(y)
+    if out is not None:
+        out.copy_(y)
+        return out
+    return y
 
 
 class _TallLinear(torch.autograd.Function):
@@ -125,6 +175,8 @@ class _TallLinear(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        if FUSED_LINEAR_FWD and _linear_fwd_ok(x, weight):
+            return linear_fwd(x, weight, bias)
         return torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t()
 
     @staticmethod
@@ -172,6 +224,10 @@ class TallLinear(nn.Linear):
         if torch.is_grad_enabled() and rows >= self.min_rows and (x.requires_grad or self.weight.requires_grad):
             y = _TallLinear.apply(x.reshape(rows, x.shape[-1]), self.weight, self.bias)
             return y.view(*x.shape[:-1], self.weight.shape[0])
+        if not torch.is_grad_enabled() and FUSED_LINEAR_FWD and x.is_cuda and not torch.is_autocast_enabled():
+            x2 = x.reshape(rows, x.shape[-1])
+            if _linear_fwd_ok(x2, self.weight):
+                return linear_fwd(x2, self.weight, self.bias).view(*x.shape[:-1], self.weight.shape[0])
         return super().forward(x)
 
 
@@ -197,7 +253,18 @@ class FFN(BaseModule):
         self.dropout_layer = nn.Identity()
         self.add_identity = add_identity
 
-    def forward(self, x, identity=None):
+    def forward(self, x, identity=None, post_norm=None):
+        """``post_norm``: the layer's next `norm` module, applied to the result (TPVFormerLayer hands it over so that
+        inference runs Linear + ReLU and Linear + identity + LayerNorm as two launches)."""
+        if (not torch.is_grad_enabled() and self.num_fcs == 2 and self.add_identity and x.is_cuda
+                and isinstance(self.layers[0][1], nn.ReLU) and isinstance(self.dropout_layer, nn.Identity)
+                and not (self.training and (self.layers[0][2].p > 0 or self.layers[2].p > 0))):
+            h = fused_linear(self.layers[0][0], x, relu=True)
+            return fused_linear(self.layers[1], h, residual=x if identity is None else identity, norm=post_norm)
+        out = self._forward_plain(x, identity)
+        return post_norm(out) if post_norm is not None else out
+
+    def _forward_plain(self, x, identity=None):
         out = self.layers(x)
         if not self.add_identity:
             return self.dropout_layer(out)
@@ -340,7 +407,11 @@ class MultiScaleDeformableAttention(BaseModule):
             query, value = query.permute(1, 0, 2), value.permute(1, 0, 2)
         output = deformable_sampling(self, query, value, reference_points, spatial_shapes, level_start_index,
                                      self._reference_kind, key_padding_mask)
+        post_norm = kwargs.get('post_norm')
+        if not torch.is_grad_enabled() and not self.training and self.batch_first and output.is_cuda:
+            return fused_linear(self.output_proj, output, residual=identity, norm=post_norm)
         output = self.output_proj(output)
         if not self.batch_first:
             output = output.permute(1, 0, 2)
-        return self.dropout(output) + identity
+        output = self.dropout(output) + identity
+        return post_norm(output) if post_norm is not None else output

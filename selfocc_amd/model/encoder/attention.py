@@ -15,7 +15,7 @@ import torch.nn as nn
 
 from ...registry import MODELS, build_attention
 from ..bricks import (BaseModule, MultiScaleDeformableAttention, TallLinear, constant_init, xavier_init,
-                      deformable_sampling)
+                      deformable_sampling, fused_linear)
 from ...msda import msda_cross_inference, MSDACrossFunction, msda_fused_supported, to_head_major
 from .. import bricks
 
@@ -129,7 +129,7 @@ class BEVCrossAttention(BaseModule):
             if host is not False:
                 return self._forward_camera_loop(query, value, residual, spatial_shapes, reference_points_cams,
                                                  bev_masks, level_start_index, host, out=kwargs.get('out'),
-                                                 value_pre=kwargs.get('value_pre'))
+                                                 value_pre=kwargs.get('value_pre'), post_norm=kwargs.get('post_norm'))
         plan = kwargs.get('rebatch_plan')
         if plan is None:
             plan = self.rebatch_plan(bev_masks)
@@ -152,11 +152,13 @@ class BEVCrossAttention(BaseModule):
         slots.index_add_(1, q_idx, sampled[:, cam_idx, slot])
         slots = slots / count[..., None]
         slots = self.output_proj(slots)
-        return self.dropout(slots) + residual
+        slots = self.dropout(slots) + residual
+        post_norm = kwargs.get('post_norm')
+        return post_norm(slots) if post_norm is not None else slots
 
 
     def _forward_camera_loop(self, query, value, residual, spatial_shapes, reference_points_cams, bev_masks,
-                             level_start_index, host_shapes=None, out=None, value_pre=None):
+                             level_start_index, host_shapes=None, out=None, value_pre=None, post_norm=None):
         """No re-batch (inference: plain op; training: MSDACrossFunction under autograd).  The offset / weight linears depend on the query only, so they run once
         on the num_query rows; one HIP launch loops over the cameras that see each query and averages
         (selfocc_msda_cross_fwd) — same arithmetic as the re-batched path, camera order preserved."""
@@ -185,10 +187,13 @@ class BEVCrossAttention(BaseModule):
         else:
             slots = MSDACrossFunction.apply(v, spatial_shapes, level_start_index, reference_points_cams[:, 0], visible,
                                             off, logits, host_shapes, hm, bricks.VALUE_BF16)[None]
+        if not self.training and not torch.is_grad_enabled():
+            # eval: dropout is the identity; output_proj + residual (+ the layer's next norm) in one launch, written
+            # straight into the caller's slice of the concatenated plane buffer (`out`)
+            return fused_linear(self.output_proj, slots, residual=residual, norm=post_norm, out=out)
         slots = self.output_proj(slots)
-        if out is not None and not self.training and not torch.is_grad_enabled():
-            return torch.add(slots, residual, out=out)      # eval: dropout is the identity; `out` = the caller's slice
-        return self.dropout(slots) + residual
+        slots = self.dropout(slots) + residual
+        return post_norm(slots) if post_norm is not None else slots
 
 
 @MODELS.register_module()
@@ -230,7 +235,11 @@ class TPVCrossAttention(BaseModule):
                 C = self.embed_dims
                 w, b = self._merged_value_proj()
                 cams, l = value.shape[0], value.shape[1]
-                v_all = torch.addmm(b, value.permute(2, 0, 1, 3).reshape(cams * l, C), w.t()).view(cams, l, 3 * C)
+                vin = value.permute(2, 0, 1, 3).reshape(cams * l, C)
+                if bricks.FUSED_LINEAR_FWD and bricks._linear_fwd_ok(vin, w):
+                    v_all = bricks.linear_fwd(vin, w, b).view(cams, l, 3 * C)
+                else:
+                    v_all = torch.addmm(b, vin, w.t()).view(cams, l, 3 * C)
                 if bricks.VALUE_BF16:
                     v_all = v_all.to(torch.bfloat16)       # one cast for the three planes
                 if bricks.HEAD_MAJOR_VALUE:
@@ -242,7 +251,7 @@ class TPVCrossAttention(BaseModule):
         return [self.attns[i](query[i], key, value, residual[i] if residual is not None else None,
                               spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                               reference_points_cams=reference_points_cams[i], bev_masks=tpv_masks[i],
-                              rebatch_plan=plans[i], out=outs[i], value_pre=vpre[i])
+                              rebatch_plan=plans[i], out=outs[i], value_pre=vpre[i], post_norm=kwargs.get('post_norm'))
                 for i in range(3)]
 
     def _merged_value_proj(self):

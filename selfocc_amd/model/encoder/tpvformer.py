@@ -185,28 +185,42 @@ class TPVFormerLayer(_FormerLayerBase):
         device = query[0].device
         cat = lambda planes: planes if self.multi_plane_ffn_norm else cat_planes(list(planes))
         split = lambda t: t if self.multi_plane_ffn_norm else torch.split(t, sizes, 1)
-        for op in self.operation_order:
+        # inference: a `norm` that directly follows an attention / ffn step rides in that step's last projection
+        # (selfocc_linear_fwd: output_proj + residual + LayerNorm in one launch) instead of re-reading the planes
+        # (post-norm layers only: with pre_norm the un-normalised tensor is still needed as the next identity)
+        fuse_norm = (not torch.is_grad_enabled() and not self.training and not self.multi_plane_ffn_norm
+                     and not self.pre_norm and query[0].is_cuda)
+        skip_norm = False
+        ops = self.operation_order
+        for k, op in enumerate(ops):
+            post_norm = None
+            if fuse_norm and op != 'norm' and k + 1 < len(ops) and ops[k + 1] == 'norm':
+                post_norm = self.norms[norm_i]
+                skip_norm = True
             if op == 'self_attn':   # cross-view hybrid attention: the 3 planes are the 3 "levels"
                 ss, lsi = _plane_shapes(H, W, Z, device)     # constants: uploaded once, not once per layer call
                 q = cat_planes(list(query))
                 q = self.attentions[attn_i](q, q, q, cat_planes(list(identity)) if self.pre_norm else None,
                                             query_pos=tpv_pos_cat, reference_points=ref_2d,
-                                            spatial_shapes=ss, level_start_index=lsi, **kwargs)
+                                            spatial_shapes=ss, level_start_index=lsi, post_norm=post_norm, **kwargs)
                 query = torch.split(q, sizes, 1)
                 attn_i += 1
                 identity = query
             elif op == 'norm':
-                query = split(self.norms[norm_i](cat(query)))
+                if skip_norm:       # already applied inside the previous step
+                    skip_norm = False
+                else:
+                    query = split(self.norms[norm_i](cat(query)))
                 norm_i += 1
             elif op == 'cross_attn':  # image cross-attention, per plane
                 query = self.attentions[attn_i](query, key, value, identity if self.pre_norm else None,
                                                 spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                                                 reference_points_cams=reference_points_cams, tpv_masks=tpv_masks,
-                                                **kwargs)
+                                                post_norm=post_norm, **kwargs)
                 attn_i += 1
                 identity = query
             elif op == 'ffn':
-                query = split(self.ffns[ffn_i](cat(query), cat(identity) if self.pre_norm else None))
+                query = split(self.ffns[ffn_i](cat(query), cat(identity) if self.pre_norm else None, post_norm=post_norm))
                 ffn_i += 1
         return query
 

@@ -82,6 +82,26 @@ def test_tpvformer_encoder_vs_reference_class(hip):
         ref = torch.tensor(enc_np[key])
         assert got.shape == ref.shape
         assert torch.allclose(got.cpu(), ref, rtol=1e-4, atol=1e-4), (key, (got.cpu() - ref).abs().max())
+    # the same with every projection (and the residual + LayerNorm steps that follow them) through selfocc_linear_fwd:
+    # the golden planes are smaller than the row threshold the modules apply, so lower it and count the launches
+    from selfocc_amd.model import bricks
+    calls = {'n': 0, 'ln': 0, 'res': 0}
+    real, old_min = bricks.linear_fwd, bricks.LINEAR_FWD_MIN_ROWS
+
+    def counting(x, w, b=None, relu=False, residual=None, ln=None, out=None, want_stats=False):
+        calls['n'] += 1; calls['ln'] += ln is not None; calls['res'] += residual is not None
+        return real(x, w, b, relu=relu, residual=residual, ln=ln, out=out, want_stats=want_stats)
+    bricks.linear_fwd, bricks.LINEAR_FWD_MIN_ROWS = counting, 1
+    try:
+        with torch.no_grad():
+            out_f = enc(lifter(feats)['representation'], ms_img_feats=feats, metas=metas)['representation']
+    finally:
+        bricks.linear_fwd, bricks.LINEAR_FWD_MIN_ROWS = real, old_min
+    n_layers = len(enc.layers)
+    assert calls['ln'] >= 3 * n_layers and calls['res'] >= calls['ln'] and calls['n'] > 10 * n_layers, calls
+    for got, key in zip(out_f, ('out_hw', 'out_zh', 'out_wz')):
+        ref = torch.tensor(enc_np[key])
+        assert torch.allclose(got.cpu(), ref, rtol=1e-4, atol=1e-4), (key, (got.cpu() - ref).abs().max())
     # the inference path above went through the camera-loop kernel (selfocc_msda_cross_fwd); the re-batch path
     # (what training uses) and the autograd path must agree with the reference as well
     from selfocc_amd.model.encoder.attention import BEVCrossAttention
