@@ -331,6 +331,19 @@ def main():
         except Exception as e:
             roofline_msda = {"error": repr(e)[:300]}
 
+    roofline_linear = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        # the encoder's projections (selfocc_linear_fwd): float32 MFMA rate against its peak, next to hipBLASLt
+        import subprocess
+        torch.cuda.empty_cache()
+        try:
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "bench_linear.py"), "--json"],
+                               capture_output=True, text=True, timeout=240)
+            last = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+            roofline_linear = json.loads(last[-1]) if last else {"error": (r.stderr or "no output")[-300:]}
+        except Exception as e:
+            roofline_linear = {"error": repr(e)[:300]}
+
     strong = None
     if world > 1 and not split:
         # the same ranks, ONE frame split into row blocks (SURVEY cfg3), after the timed region
@@ -375,6 +388,8 @@ def main():
             line["gpu_torch_baseline"] = gpu_torch_baseline
         if roofline_msda:
             line["roofline_msda"] = roofline_msda
+        if roofline_linear:
+            line["roofline_linear"] = roofline_linear
         if strong:
             line["strong_scaling"] = strong
         if extras:

@@ -24,7 +24,12 @@
 // (gpurun_out/linear_fwd_bench_*.txt): 32-row tiles on v_mfma_f32_32x32x2_f32 with three 16-register accumulators
 // (118 - 164 VGPRs, 2 - 3 waves per SIMD, half as many work units: 576 - 672 us); more resident waves (4 per SIMD:
 // 612 us, 8-wave blocks 664 us) — fewer, longer-lived waves win because every extra resident block re-stages its
-// slice of W and scatters the output stream over more DRAM pages at once.
+// slice of W and scatters the output stream over more DRAM pages at once.  Then: the next tile's x operand loaded
+// before the current tile's MFMAs and the W operand double-buffered in registers across MFMA groups (543 -> 483 us =
+// 85 TFLOP/s over the twelve shapes; PMC: the MFMA pipes are busy 64 % of the kernel on the 178 500 x 288 shape).  Tried
+// without gain: W as the MFMA's A operand so that a lane owns four consecutive columns of a row and the epilogue is
+// float4 loads / stores (512 us; the SGPR budget overflows), a contiguous range of row tiles per block (504 us).
+// The HBM side is far from its limit (torch fill_ writes the same 100 MB in 16 us = 6 TB/s).
 #include "so_device.h"
 #include <algorithm>
 #include <cstdlib>
@@ -154,37 +159,57 @@ __global__ __launch_bounds__(WAVES * 64) void linear_fwd16_kernel(LinearFwdArgs 
     }
 
     const long long nwt = (a.T + 15) / 16, wt_step = (long long)WAVES * a.groups;
-    for (long long wt = rc * WAVES + wave; wt < nwt; wt += wt_step) {
-        const long long row0 = wt * 16;
-        const int rem = (int)min(16LL, a.T - row0);
-        const float *xb = a.x + row0 * K;
-        const unsigned xoff = (unsigned)(min(n, rem - 1) * K + kq * KQ);
-        float av[KQ];
+    // the A operand of the NEXT tile is loaded before the MFMAs of the current one (24 - 48 more registers; the kernel
+    // runs 2 waves per SIMD by choice, so they are free): a wave never waits for HBM between its tiles
+    float av[KQ], an[KQ];
+    auto load_a = [&](long long wtile, float (&dst)[KQ]) {
+        const long long r0 = wtile * 16;
+        const int rm = (int)min(16LL, a.T - r0);
+        const float *xb = a.x + r0 * K;
+        const unsigned xoff = (unsigned)(min(n, rm - 1) * K + kq * KQ);
 #pragma unroll
         for (int q = 0; q < KQ / 4; ++q) {
             const float4 v = *(const float4 *)(xb + xoff + 4 * q);
-            av[4 * q] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
+            dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
         }
+    };
+    long long wt = rc * WAVES + wave;
+    if (wt < nwt) load_a(wt, av);
+    for (; wt < nwt; wt += wt_step) {
+        const long long row0 = wt * 16;
+        const int rem = (int)min(16LL, a.T - row0);
+        const bool more = wt + wt_step < nwt;
+        if (more) load_a(wt + wt_step, an);
         f32x4 acc[NT16];
 #pragma unroll
         for (int t = 0; t < NT16; ++t)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[t][j] = 0.0f;
+        // B operand double-buffered in registers: the ds_read_b128 pair of group s + 1 is issued before the eight MFMAs
+        // of group s (with one or two waves per SIMD nothing else hides the LDS latency)
+        constexpr int QN = KQ / 4, NS = NT * QN;
+        const float *bbase = wl + n * KP + kq * KQ;
+        float4 b0 = *(const float4 *)(bbase), b1 = *(const float4 *)(bbase + 16 * KP);
 #pragma unroll
-        for (int tp = 0; tp < NT; ++tp) {
-            const float *b0p = wl + (32 * tp + n) * KP + kq * KQ, *b1p = b0p + 16 * KP;
-#pragma unroll
-            for (int q = 0; q < KQ / 4; ++q) {
-                const float4 b0 = *(const float4 *)(b0p + 4 * q), b1 = *(const float4 *)(b1p + 4 * q);
-                acc[2 * tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q], b0.x, acc[2 * tp], 0, 0, 0);
-                acc[2 * tp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q], b1.x, acc[2 * tp + 1], 0, 0, 0);
-                acc[2 * tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q + 1], b0.y, acc[2 * tp], 0, 0, 0);
-                acc[2 * tp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q + 1], b1.y, acc[2 * tp + 1], 0, 0, 0);
-                acc[2 * tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q + 2], b0.z, acc[2 * tp], 0, 0, 0);
-                acc[2 * tp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q + 2], b1.z, acc[2 * tp + 1], 0, 0, 0);
-                acc[2 * tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q + 3], b0.w, acc[2 * tp], 0, 0, 0);
-                acc[2 * tp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q + 3], b1.w, acc[2 * tp + 1], 0, 0, 0);
+        for (int sidx = 0; sidx < NS; ++sidx) {
+            const int tp = sidx / QN, q = sidx - tp * QN;
+            float4 nb0 = b0, nb1 = b1;
+            if (sidx + 1 < NS) {
+                const int tp2 = (sidx + 1) / QN, q2 = (sidx + 1) - tp2 * QN;
+                nb0 = *(const float4 *)(bbase + 32 * tp2 * KP + 4 * q2);
+                nb1 = *(const float4 *)(bbase + (32 * tp2 + 16) * KP + 4 * q2);
             }
+            __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise sinks the reads next to their first use)
+            acc[2 * tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q], b0.x, acc[2 * tp], 0, 0, 0);
+            acc[2 * tp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q], b1.x, acc[2 * tp + 1], 0, 0, 0);
+            acc[2 * tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q + 1], b0.y, acc[2 * tp], 0, 0, 0);
+            acc[2 * tp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q + 1], b1.y, acc[2 * tp + 1], 0, 0, 0);
+            acc[2 * tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q + 2], b0.z, acc[2 * tp], 0, 0, 0);
+            acc[2 * tp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q + 2], b1.z, acc[2 * tp + 1], 0, 0, 0);
+            acc[2 * tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q + 3], b0.w, acc[2 * tp], 0, 0, 0);
+            acc[2 * tp + 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q + 3], b1.w, acc[2 * tp + 1], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            b0 = nb0; b1 = nb1;
         }
         const float *rb = a.residual ? a.residual + row0 * a.ldr + n0 : nullptr;
         float *yb = a.y + row0 * a.ldy + n0;
@@ -198,6 +223,10 @@ __global__ __launch_bounds__(WAVES * 64) void linear_fwd16_kernel(LinearFwdArgs 
         else
             so_linear_epilogue16<LN, false, NT16>(acc, bv, gv, bt, cok, relu_lo, rb, a.ldr, yb, a.ldy, pb, mb, sb, a.N, a.eps,
                                                   rem, no, kq);
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < KQ; ++j) av[j] = an[j];
+        }
     }
 }
 
@@ -240,8 +269,8 @@ extern "C" int selfocc_linear_fwd(const float *x, const float *w, const float *b
         if ((pass == 0 && ncb_full == 0) || (pass == 1 && tail_nt == 0)) continue;
         const size_t lds_blk = (size_t)nt * 32 * (K + 4) * sizeof(float);
         static const long long percu_env = getenv("SELFOCC_LINEAR_PERCU") ? atoll(getenv("SELFOCC_LINEAR_PERCU")) : 0;  // dev A/B
-        // persistent grid: two 4-wave blocks per CU (measured best: 1 / 2 / 3 / 4 per CU = 561 / 543 / 595 / 612 us over
-        // the encoder's twelve shapes), split evenly over the column blocks; a block's waves take the 16-row tiles
+        // persistent grid: two 4-wave blocks per CU (measured with the prefetches: 1 / 2 / 3 per CU = 495 / 483 / 527 us over
+        // the encoder's twelve shapes; 4 per CU 607 us), split evenly over the column blocks; a block's waves take the 16-row tiles
         // (group * 4 + wave) + 4 groups j
         long long per_cu = std::max<long long>(1, std::min<long long>(2, (160 * 1024) / (long long)(lds_blk + 512)));
         if (percu_env > 0) per_cu = percu_env;
