@@ -231,27 +231,38 @@ class BEVFormerLayer(_FormerLayerBase):
                 level_start_index=None, reference_points_cams=None, bev_masks=None, bev_size=None, **kwargs):
         norm_i = attn_i = ffn_i = 0
         identity = query
-        for op in self.operation_order:
+        # inference, post-norm layers: a `norm` that follows an attention / ffn step rides in that step's last
+        # projection (selfocc_linear_fwd), as in TPVFormerLayer
+        fuse_norm = not torch.is_grad_enabled() and not self.training and not self.pre_norm and query.is_cuda
+        skip_norm = False
+        ops = self.operation_order
+        for k, op in enumerate(ops):
+            post_norm = None
+            if fuse_norm and op != 'norm' and k + 1 < len(ops) and ops[k + 1] == 'norm':
+                post_norm = self.norms[norm_i]
+                skip_norm = True
             if op == 'self_attn':
-                ss = torch.tensor([bev_size], device=query.device)
-                lsi = torch.tensor([0], device=query.device)
+                ss, lsi = _level_shapes((tuple(int(v) for v in bev_size),), query.device)   # cached: no upload per call
                 query = self.attentions[attn_i](query, query, query, identity if self.pre_norm else None,
                                                 query_pos=bev_pos, reference_points=ref_2d, spatial_shapes=ss,
-                                                level_start_index=lsi, **kwargs)
+                                                level_start_index=lsi, post_norm=post_norm, **kwargs)
                 attn_i += 1
                 identity = query
             elif op == 'norm':
-                query = self.norms[norm_i](query)
+                if skip_norm:
+                    skip_norm = False
+                else:
+                    query = self.norms[norm_i](query)
                 norm_i += 1
             elif op == 'cross_attn':
                 query = self.attentions[attn_i](query, key, value, identity if self.pre_norm else None,
                                                 spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                                                 reference_points_cams=reference_points_cams, bev_masks=bev_masks,
-                                                **kwargs)
+                                                post_norm=post_norm, **kwargs)
                 attn_i += 1
                 identity = query
             elif op == 'ffn':
-                query = self.ffns[ffn_i](query, identity if self.pre_norm else None)
+                query = self.ffns[ffn_i](query, identity if self.pre_norm else None, post_norm=post_norm)
                 ffn_i += 1
         return query
 

@@ -117,6 +117,36 @@ def install_stubs():
         def init_weights(self):
             pass
 
+        def forward(self, query, key=None, value=None, identity=None, query_pos=None, key_padding_mask=None,
+                    reference_points=None, spatial_shapes=None, level_start_index=None, **kwargs):
+            """mmcv==2.0.1 mmcv/ops/multi_scale_deform_attn.py MultiScaleDeformableAttention.forward, restated from
+            the published algorithm (mmcv is absent here; the reference's BEVFormerLayer uses this class as its
+            self-attention, config/nuscenes/nuscenes_occ_bev.py:222): value_proj, offset / weight linears, softmax over
+            levels x points, loc = ref + off / (W_l, H_l), MSDA, output_proj, dropout + identity."""
+            value = query if value is None else value
+            identity = query if identity is None else identity
+            if query_pos is not None:
+                query = query + query_pos
+            if not self.batch_first:
+                query, value = query.permute(1, 0, 2), value.permute(1, 0, 2)
+            bs, nq, _ = query.shape
+            nv = value.shape[1]
+            assert int((spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum()) == nv
+            value = self.value_proj(value)
+            if key_padding_mask is not None:
+                value = value.masked_fill(key_padding_mask[..., None], 0.0)
+            value = value.view(bs, nv, self.num_heads, -1)
+            off = self.sampling_offsets(query).view(bs, nq, self.num_heads, self.num_levels, self.num_points, 2)
+            aw = self.attention_weights(query).view(bs, nq, self.num_heads, self.num_levels * self.num_points).softmax(-1)
+            aw = aw.view(bs, nq, self.num_heads, self.num_levels, self.num_points)
+            assert reference_points.shape[-1] == 2
+            normalizer = torch.stack([spatial_shapes[..., 1], spatial_shapes[..., 0]], -1)
+            loc = reference_points[:, :, None, :, None, :] + off / normalizer[None, None, None, :, None, :]
+            out = self.output_proj(msda_port(value, spatial_shapes, loc, aw))
+            if not self.batch_first:
+                out = out.permute(1, 0, 2)
+            return self.dropout(out) + identity
+
     def deprecated_api_warning(*a, **k):
         return lambda f: f
 
@@ -539,6 +569,71 @@ def golden_encoder(REG):
         json.dump(dict(encoder=cfg, lifter=dict(tpv_h=H, tpv_w=W, tpv_z=Z, dim=dim), img_shape=[48, 80]), f, indent=1)
 
 
+def golden_bev_encoder(REG):
+    """The BEV lifter family (config/nuscenes/nuscenes_occ_bev.py): the REAL BEVFormerEncoder / BEVFormerLayer /
+    BEVPositionalEncoding / BEVCrossAttention / BEVQueryLifter; the layer's self-attention is mmcv's
+    MultiScaleDeformableAttention, restated in install_stubs (mmcv is absent)."""
+    for p in ('model', 'model.encoder', 'model.encoder.bevformer', 'model.encoder.bevformer.attention', 'model.lifter'):
+        if p not in sys.modules:
+            namespace(p)
+    ica = ref_import('model.encoder.bevformer.attention.image_cross_attention')
+    sys.modules['model.encoder.bevformer.attention'].BEVCrossAttention = ica.BEVCrossAttention
+    sys.modules['model.encoder.bevformer.attention'].BEVDeformableAttention = ica.BEVDeformableAttention
+    ref_import('model.encoder.bevformer.bevformer_pos_embed')
+    ref_import('model.encoder.bevformer.bevformer_encoder_layer')
+    enc_mod = ref_import('model.encoder.bevformer.bevformer_encoder')
+    lift = ref_import('model.lifter.bev_query_lifter')
+    REG.register_module(name='MultiScaleDeformableAttention', module=sys.modules['mmcv.ops.multi_scale_deform_attn'].MultiScaleDeformableAttention, force=True)
+
+    torch.manual_seed(3)
+    dim, heads = 32, 2
+    mapping_args = dict(nonlinear_mode='linear', h_size=[4, 0], h_range=[8.0, 0], h_half=False, w_size=[3, 0],
+                        w_range=[6.0, 0], w_half=False, d_size=[2, 0], d_range=[-1.0, 3.0, 3.0])
+    H, W = 9, 7
+    layer = dict(type='BEVFormerLayer',
+                 attn_cfgs=[dict(type='MultiScaleDeformableAttention', embed_dims=dim, num_heads=heads, num_levels=1,
+                                 num_points=4, dropout=0.1, batch_first=True),
+                            dict(type='BEVCrossAttention', embed_dims=dim, num_cams=2, dropout=0.1, batch_first=True,
+                                 deformable_attention=dict(type='BEVDeformableAttention', embed_dims=dim, num_heads=heads,
+                                                           num_levels=2, num_points=3, dropout=0.1, batch_first=True))],
+                 feedforward_channels=2 * dim, ffn_dropout=0.1,
+                 operation_order=('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm'))
+    cfg = dict(mapping_args=mapping_args, embed_dims=dim, num_cams=2, num_feature_levels=2,
+               positional_encoding=dict(type='BEVPositionalEncoding', num_freqs=3, embed_dims=dim,
+                                        tot_range=[-6.0, -8.0, -1.0, 6.0, 8.0, 3.0]),
+               num_points_cross=3, num_points_self=4, transformerlayers=[layer, layer], num_layers=2)
+    import copy
+    enc = enc_mod.BEVFormerEncoder(**copy.deepcopy(cfg))
+    enc.init_weights()
+    g = torch.Generator().manual_seed(4)
+    for n, p in enc.named_parameters():
+        if 'sampling_offsets.weight' in n or 'attention_weights' in n:
+            p.data = 0.2 * torch.randn(p.shape, generator=g)
+        if n.endswith('attentions.0.sampling_offsets.bias'):      # the stub's init_weights leaves these at nn.Linear's
+            p.data = torch.randn(p.shape, generator=g)
+    enc.eval()
+    lifter = lift.BEVQueryLifter(H, W, dim)
+    feats = [torch.randn(1, 2, dim, 6, 10, generator=g), torch.randn(1, 2, dim, 3, 5, generator=g)]
+    l2i = []
+    for i in range(2):
+        yaw = 0.7 + 3.1 * i
+        R = np.array([[np.sin(yaw), -np.cos(yaw), 0, 0.1], [0, 0, -1, 1.2], [np.cos(yaw), np.sin(yaw), 0, 0.4], [0, 0, 0, 1]])
+        K = np.array([[40.0, 0, 40, 0], [0, 40.0, 24, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+        l2i.append(K @ R)
+    metas = [dict(lidar2img=np.stack(l2i), img_shape=(48, 80))]
+    rep = lifter(feats)['representation']
+    with torch.no_grad():
+        out = enc(rep, ms_img_feats=feats, metas=metas)['representation']
+    arrs = {f'enc.{k}': v for k, v in to_np(enc.state_dict()).items()}
+    arrs.update({f'lift.{k}': v for k, v in to_np(lifter.state_dict()).items()})
+    arrs.update(feat0=feats[0].numpy(), feat1=feats[1].numpy(), lidar2img=np.stack(l2i), out=out.numpy(),
+                ref_3d=enc.ref_3d.numpy(), ref_2d=enc.ref_2d.numpy())
+    save('bev_encoder.npz', **arrs)
+    import json
+    with open(os.path.join(HERE, 'bev_encoder_cfg.json'), 'w') as f:
+        json.dump(dict(encoder=cfg, lifter=dict(bev_h=H, bev_w=W, dim=dim), img_shape=[48, 80]), f, indent=1)
+
+
 if __name__ == '__main__':
     assert os.path.isdir(REF), f"{REF} not found: golden vectors can only be regenerated where the reference is mounted"
     sys.path.insert(0, REF)
@@ -546,8 +641,10 @@ if __name__ == '__main__':
     for p in ('model', 'model.encoder', 'model.encoder.bevformer', 'model.encoder.tpvformer', 'model.head',
               'model.head.nerfacc_head', 'model.head.utils'):
         namespace(p)
-    golden_geometry()
-    golden_losses(LOSS_REG)
-    golden_more(LOSS_REG)
-    golden_encoder(REG)
-    golden_segmentor(REG)
+    only = sys.argv[1:]          # e.g. `python make_golden.py bev_encoder` regenerates one fixture
+    todo = dict(geometry=golden_geometry, losses=lambda: golden_losses(LOSS_REG), more=lambda: golden_more(LOSS_REG),
+                encoder=lambda: golden_encoder(REG), bev_encoder=lambda: golden_bev_encoder(REG),
+                segmentor=lambda: golden_segmentor(REG))
+    for name, fn in todo.items():
+        if not only or name in only:
+            fn()

@@ -119,6 +119,44 @@ def test_tpvformer_encoder_vs_reference_class(hip):
         assert torch.allclose(a, b, rtol=1e-5, atol=1e-5), key
 
 
+def test_bevformer_encoder_vs_reference_class(hip):
+    """The BEV lifter family (config/nuscenes/nuscenes_occ_bev.py): two BEVFormerLayers (mmcv-style deformable
+    self-attention + BEVCrossAttention over 2 cameras x 2 levels + FFN + LN) with the REFERENCE's state dict loaded by
+    name, against the outputs of the reference's own BEVFormerEncoder (tests/golden/bev_encoder.npz)."""
+    from selfocc_amd.registry import MODELS
+    import selfocc_amd.model  # noqa: F401
+    from selfocc_amd.model import bricks
+    enc_np = np.load(os.path.join(G, "bev_encoder.npz"))
+    cfg = json.load(open(os.path.join(G, "bev_encoder_cfg.json")))
+    enc = MODELS.build(dict(type='BEVFormerEncoder', **copy.deepcopy(cfg['encoder'])))
+    lifter = MODELS.build(dict(type='BEVQueryLifter', **cfg['lifter']))
+    enc.load_state_dict({k[4:]: torch.tensor(v) for k, v in enc_np.items() if k.startswith('enc.')}, strict=True)
+    lifter.load_state_dict({k[5:]: torch.tensor(v) for k, v in enc_np.items() if k.startswith('lift.')}, strict=True)
+    assert torch.allclose(enc.ref_3d, torch.tensor(enc_np['ref_3d']), atol=1e-6)
+    assert torch.equal(enc.ref_2d, torch.tensor(enc_np['ref_2d']))
+    enc, lifter = enc.to(D0).eval(), lifter.to(D0).eval()
+    feats = [torch.tensor(enc_np['feat0']).to(D0), torch.tensor(enc_np['feat1']).to(D0)]
+    metas = [dict(lidar2img=enc_np['lidar2img'], img_shape=tuple(cfg['img_shape']))]
+    ref = torch.tensor(enc_np['out'])
+    run = lambda: enc(lifter(feats)['representation'], ms_img_feats=feats, metas=metas)['representation']
+    with torch.no_grad():
+        out = run()                                   # inference: camera-loop kernel, torch projections (few rows)
+    assert out.shape == ref.shape
+    assert torch.allclose(out.cpu(), ref, rtol=1e-4, atol=1e-4), (out.cpu() - ref).abs().max()
+    old_min = bricks.LINEAR_FWD_MIN_ROWS
+    bricks.LINEAR_FWD_MIN_ROWS = 1                    # ... every projection / residual / norm through selfocc_linear_fwd
+    try:
+        with torch.no_grad():
+            out_f = run()
+    finally:
+        bricks.LINEAR_FWD_MIN_ROWS = old_min
+    assert torch.allclose(out_f.cpu(), ref, rtol=1e-4, atol=1e-4), (out_f.cpu() - ref).abs().max()
+    out_ag = run()                                    # the autograd path (what training uses)
+    assert torch.allclose(out_ag.detach().cpu(), ref, rtol=1e-4, atol=1e-4), (out_ag.detach().cpu() - ref).abs().max()
+    out_ag.square().mean().backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in enc.parameters())
+
+
 def test_encoder_backward_runs(hip):
     """autograd through the whole encoder (MSDA backward kernel underneath) gives finite grads"""
     from selfocc_amd.registry import MODELS
