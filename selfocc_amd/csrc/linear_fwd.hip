@@ -28,7 +28,9 @@
 // before the current tile's MFMAs and the W operand double-buffered in registers across MFMA groups (543 -> 483 us =
 // 85 TFLOP/s over the twelve shapes; PMC: the MFMA pipes are busy 64 % of the kernel on the 178 500 x 288 shape).  Tried
 // without gain: W as the MFMA's A operand so that a lane owns four consecutive columns of a row and the epilogue is
-// float4 loads / stores (512 us; the SGPR budget overflows), a contiguous range of row tiles per block (504 us).
+// float4 loads / stores (512 us; the SGPR budget overflows), a contiguous range of row tiles per block (504 us), the
+// epilogue of tile i cut into slices between the MFMA groups of tile i + 1 (507 us: anything between two MFMAs costs
+// more than its issue slot).
 // The HBM side is far from its limit (torch fill_ writes the same 100 MB in 16 us = 6 TB/s).
 #include "so_device.h"
 #include <algorithm>
