@@ -53,95 +53,144 @@ struct FieldArgs {
     int n_tiles;
 };
 
+// Forward kernel, "transposed chain": the hidden layer is computed as Y^T = W1 X^T (W1 = the MFMA's A operand, read
+// from LDS with ds_read_b128 = four k-steps per read; X^T = the B operand, the lane's own 48 Softplus(x) registers), so
+// a lane ends up holding 48 hidden units OF ITS OWN VOXEL (units 32 ct + 8 a + 4 half + b).  Because the k labelling of
+// an MFMA is free as long as A and B agree, exactly those registers are the next layer's A operand (Z[voxel][unit],
+// with W2 read from LDS at the same permuted units): the 32 x 96 hidden tile never goes through LDS, there is no
+// C-layout -> A-layout transpose, no wave barrier, and the block's LDS drops from 151 KB to 52 KB (three 4-wave
+// blocks per CU instead of one 8-wave block).
+constexpr int kFieldFwdWaves = 4;
+
 template <int C, bool BF16>
-__global__ __launch_bounds__(field_waves(C) * 64) void field_volume_kernel(FieldArgs a) {
-    constexpr int kFieldWaves = field_waves(C);
-    constexpr int KS = C / 2;          // MFMA k-steps (2 k per step)
-    constexpr int NT = C / 32;         // 32-column tiles of the hidden layer
-    constexpr int YS = C + 4;          // row stride of the transpose tile (16-byte aligned rows)
+__global__ __launch_bounds__(kFieldFwdWaves * 64) void field_volume_kernel(FieldArgs a) {
+    constexpr int KS = C / 2;          // k-steps of the hidden layer (2 k per MFMA)
+    constexpr int NT = C / 32;         // 32-unit tiles of the hidden layer
+    constexpr int KP = C + 4;          // LDS row stride: conflict-free ds_read_b128 (cf. linear_fwd.hip)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *w1s = smem;                               // [KS][2][C]    hidden weight, B-operand order
-    float *w2s = w1s + (size_t)C * C;                // [KS][2][32]   output weight, zero-padded to 32 columns
-    float *ytiles = w2s + (size_t)C * 32;            // [waves][32][YS]
+    float *w1s = smem;                               // [C units][KP]   hidden weight, row = unit, column = input k
+    float *w2s = w1s + (size_t)C * KP;               // [32 outputs][KP] output weight (zero rows beyond out_dim)
+    float *b1s = w2s + (size_t)32 * KP;              // [C]
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, half = lane >> 5;
 
     // ---- stage the weights (once per block; blocks are persistent) ------------------------------
     if (a.n_hidden == 1) {
-        for (int e = threadIdx.x; e < C * C; e += kFieldWaves * 64) {
-            const int n = e % C, kk = e / C;           // kk = ks * 2 + half
-            const int k = (kk & 1) * KS + (kk >> 1);
-            w1s[e] = a.w_hidden[(size_t)n * C + k];
+        for (int e = threadIdx.x; e < C * (C / 4); e += kFieldFwdWaves * 64) {
+            const int u = e / (C / 4), k4 = e - u * (C / 4);
+            *(float4 *)(w1s + u * KP + 4 * k4) = ((const float4 *)(a.w_hidden + (size_t)u * C))[k4];
         }
+        for (int e = threadIdx.x; e < C; e += kFieldFwdWaves * 64) b1s[e] = a.b_hidden[e];
     }
-    for (int e = threadIdx.x; e < C * 32; e += kFieldWaves * 64) {
-        const int n = e & 31, kk = e >> 5;
-        const int k = (kk & 1) * KS + (kk >> 1);
-        w2s[e] = n < a.out_dim ? a.w_out[(size_t)n * C + k] : 0.0f;
+    for (int e = threadIdx.x; e < 32 * (C / 4); e += kFieldFwdWaves * 64) {
+        const int n = e / (C / 4), k4 = e - n * (C / 4);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < a.out_dim) v = ((const float4 *)(a.w_out + (size_t)n * C))[k4];
+        *(float4 *)(w2s + n * KP + 4 * k4) = v;
     }
     __syncthreads();
-    float *ytile = ytiles + (size_t)wave * 32 * YS;
 
-    for (int tile = blockIdx.x * kFieldWaves + wave; tile < a.n_tiles; tile += gridDim.x * kFieldWaves) {
-        // ---- A operand: Softplus(hw + zh + wz) of row m, columns half * KS .. + KS ---------------
-        const long long m = (long long)tile * 32 + i;
-        const long long mc = m < a.M ? m : a.M - 1;
-        const int d = (int)(mc % a.D);
-        const int hwi = (int)(mc / a.D);               // h * W + w
-        const int w = hwi % a.W, h = hwi / a.W;
+    for (int tile = blockIdx.x * kFieldFwdWaves + wave; tile < a.n_tiles; tile += gridDim.x * kFieldFwdWaves) {
+        // ---- Softplus(hw + zh + wz) of voxel i, inputs half * KS .. + KS -----------------------------
+        // (32-bit index arithmetic: the host guarantees M < 2^31; 64-bit division costs ~100 VALU instructions each)
+        const unsigned m = (unsigned)tile * 32u + (unsigned)i;
+        const unsigned mc = m < (unsigned)a.M ? m : (unsigned)a.M - 1u;
+        const unsigned hwi = mc / (unsigned)a.D;       // h * W + w
+        const unsigned d = mc - hwi * (unsigned)a.D;
+        const unsigned h = hwi / (unsigned)a.W, w = hwi - h * (unsigned)a.W;
         const float4 *p0 = (const float4 *)(a.hw + (size_t)hwi * C + half * KS);
         const float4 *p1 = (const float4 *)(a.zh + ((size_t)d * a.H + h) * C + half * KS);
         const float4 *p2 = (const float4 *)(a.wz + ((size_t)w * a.D + d) * C + half * KS);
-        float av[KS];
+        float xv[KS];
 #pragma unroll
         for (int q = 0; q < KS / 4; ++q) {
             const float4 x0 = p0[q], x1 = p1[q], x2 = p2[q];
-            av[4 * q + 0] = so_softplus((x0.x + x1.x) + x2.x);
-            av[4 * q + 1] = so_softplus((x0.y + x1.y) + x2.y);
-            av[4 * q + 2] = so_softplus((x0.z + x1.z) + x2.z);
-            av[4 * q + 3] = so_softplus((x0.w + x1.w) + x2.w);
+            xv[4 * q + 0] = so_softplus((x0.x + x1.x) + x2.x);
+            xv[4 * q + 1] = so_softplus((x0.y + x1.y) + x2.y);
+            xv[4 * q + 2] = so_softplus((x0.z + x1.z) + x2.z);
+            xv[4 * q + 3] = so_softplus((x0.w + x1.w) + x2.w);
         }
+        f32x16 o;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) o[v] = 0.0f;
+        const float *w2row = w2s + i * KP;               // this lane's output channel as the B operand
         if (a.n_hidden == 1) {   // uniform
+            // hidden layer, transposed: acc[ct][v] = y[voxel i][unit 32 ct + 8 (v >> 2) + 4 half + (v & 3)]
             f32x16 acc[NT];
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[ct][v] = 0.0f;
+            constexpr int QN = KS / 4, NS = NT * QN;
+            const float *abase = w1s + i * KP + half * KS;
+            float4 wa = *(const float4 *)abase;
 #pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-                const float *brow = w1s + (ks * 2 + half) * C + i;
-#pragma unroll
-                for (int ct = 0; ct < NT; ++ct)
-                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks], brow[ct * 32], acc[ct], 0, 0, 0);
+            for (int sidx = 0; sidx < NS; ++sidx) {
+                const int ct = sidx / QN, q = sidx - ct * QN;
+                float4 wn = wa;
+                if (sidx + 1 < NS) {
+                    const int ct2 = (sidx + 1) / QN, q2 = (sidx + 1) - ct2 * QN;
+                    wn = *(const float4 *)(abase + 32 * ct2 * KP + 4 * q2);
+                }
+                __builtin_amdgcn_sched_barrier(0);      // keep the next group's read ahead of this group's MFMAs
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.x, xv[4 * q], acc[ct], 0, 0, 0);
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.y, xv[4 * q + 1], acc[ct], 0, 0, 0);
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.z, xv[4 * q + 2], acc[ct], 0, 0, 0);
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa.w, xv[4 * q + 3], acc[ct], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                wa = wn;
             }
-            // C layout (col = lane & 31, row = (v & 3) + 8 (v >> 2) + 4 (lane >> 5)) -> bias, Softplus -> LDS [row][col]
+            // bias + Softplus in place, then the output layer straight from these registers:
+            // o[voxel][channel] += z[voxel][unit] W2[channel][unit], unit = 32 ct + 8 a + 4 half + b
+            if (a.out_dim == 1) {
+                // SDF only (the depth configs): a 32-column MFMA chain for ONE useful column is a quarter of the tile's
+                // matrix-pipe time; the lane already holds 48 of its voxel's 96 hidden units -> 48 fmas + one exchange
+                float dot = 0.0f;
+#pragma unroll
+                for (int ct = 0; ct < NT; ++ct) {
+#pragma unroll
+                    for (int aa = 0; aa < 4; ++aa) {
+                        const int u0 = 32 * ct + 8 * aa + 4 * half;
+                        const float4 bb = *(const float4 *)(b1s + u0);
+                        const float4 w2 = *(const float4 *)(w2s + u0);       // row 0 of W2: broadcast read
+                        dot = fmaf(so_softplus(acc[ct][4 * aa + 0] + bb.x), w2.x, dot);
+                        dot = fmaf(so_softplus(acc[ct][4 * aa + 1] + bb.y), w2.y, dot);
+                        dot = fmaf(so_softplus(acc[ct][4 * aa + 2] + bb.z), w2.z, dot);
+                        dot = fmaf(so_softplus(acc[ct][4 * aa + 3] + bb.w), w2.w, dot);
+                    }
+                }
+                dot += __shfl_xor(dot, 32, 64);
+                if (half == 0 && m < (unsigned)a.M) a.sdf[m] = dot + a.b_out[0];
+                continue;
+            }
 #pragma unroll
             for (int ct = 0; ct < NT; ++ct) {
-                const float bias = a.b_hidden[ct * 32 + i];
 #pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const int r = (v & 3) + 8 * (v >> 2) + 4 * half;
-                    ytile[r * YS + ct * 32 + i] = so_softplus(acc[ct][v] + bias);
+                for (int aa = 0; aa < 4; ++aa) {
+                    const int u0 = 32 * ct + 8 * aa + 4 * half;
+                    const float4 bb = *(const float4 *)(b1s + u0);        // broadcast read (same address per half wave)
+                    const float4 w2 = *(const float4 *)(w2row + u0);
+                    const float z0 = so_softplus(acc[ct][4 * aa + 0] + bb.x), z1 = so_softplus(acc[ct][4 * aa + 1] + bb.y);
+                    const float z2 = so_softplus(acc[ct][4 * aa + 2] + bb.z), z3 = so_softplus(acc[ct][4 * aa + 3] + bb.w);
+                    o = __builtin_amdgcn_mfma_f32_32x32x2f32(z0, w2.x, o, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_32x32x2f32(z1, w2.y, o, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_32x32x2f32(z2, w2.z, o, 0, 0, 0);
+                    o = __builtin_amdgcn_mfma_f32_32x32x2f32(z3, w2.w, o, 0, 0, 0);
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            const float4 *yr = (const float4 *)(ytile + i * YS + half * KS);
+        } else {
+            // single linear layer: o[voxel][channel] = sum_k x[voxel][k] W2[channel][k], k = half * KS + ks
 #pragma unroll
             for (int q = 0; q < KS / 4; ++q) {
-                const float4 t = yr[q];
-                av[4 * q + 0] = t.x; av[4 * q + 1] = t.y; av[4 * q + 2] = t.z; av[4 * q + 3] = t.w;
+                const float4 w2 = *(const float4 *)(w2row + half * KS + 4 * q);
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[4 * q], w2.x, o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[4 * q + 1], w2.y, o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[4 * q + 2], w2.z, o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[4 * q + 3], w2.w, o, 0, 0, 0);
             }
-            __builtin_amdgcn_wave_barrier();
         }
-        // ---- output layer --------------------------------------------------------------------------
-        f32x16 o;
-#pragma unroll
-        for (int v = 0; v < 16; ++v) o[v] = 0.0f;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-            o = __builtin_amdgcn_mfma_f32_32x32x2f32(av[ks], w2s[(ks * 2 + half) * 32 + i], o, 0, 0, 0);
+        // ---- store: C layout of o: column (channel) = lane & 31, row (voxel) = (v & 3) + 8 (v >> 2) + 4 half ----
         const int n = i;                                   // output channel of this lane
         const float bias = n < a.out_dim ? a.b_out[n] : 0.0f;
 #pragma unroll
@@ -473,12 +522,14 @@ extern "C" int selfocc_field_volume_fwd(const float *hw, const float *zh, const 
                feat_stride, out_dim - 1);
     SO_REQUIRE(feat_dtype == SO_DTYPE_F32 || feat_dtype == SO_DTYPE_BF16, "field_volume: bad feat_dtype");
     const long long M = (long long)H * W * D;
-    SO_REQUIRE(M < (1LL << 31) * 32, "field_volume: volume too large");
+    SO_REQUIRE(M < (1LL << 31) - 64, "field_volume: volume too large");
     FieldArgs a{hw, zh, wz, H, W, D, w_hidden, b_hidden, w_out, b_out, n_hidden, out_dim, sdf, feat, feat_stride, M,
                 (int)((M + 31) / 32)};
-    const int nw = field_waves(C);
-    const size_t shm = ((size_t)C * C + (size_t)C * 32 + (size_t)nw * 32 * (C + 4)) * sizeof(float);
-    const int blocks = std::min((a.n_tiles + nw - 1) / nw, 256);
+    const int nw = kFieldFwdWaves;
+    const size_t shm = ((size_t)(C + 32) * (C + 4) + C) * sizeof(float);
+    // persistent blocks: as many as the LDS of a CU holds (52 KB each at C = 96 -> 3 per CU), at most one tile each
+    const int per_cu = std::max(1, std::min(4, (int)((160 * 1024) / (shm + 1024))));
+    const int blocks = std::min((a.n_tiles + nw - 1) / nw, 256 * per_cu);
     hipStream_t st = (hipStream_t)stream;
 #define SO_LAUNCH(CC, BF)                                                                                    \
     {                                                                                                        \
