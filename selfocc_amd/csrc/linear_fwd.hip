@@ -128,6 +128,23 @@ __global__ __launch_bounds__(WAVES * 64) void linear_fwd16_kernel(LinearFwdArgs 
     const int cb = __builtin_amdgcn_readfirstlane((int)(logical % (unsigned)a.ncb));
     const long long rc = __builtin_amdgcn_readfirstlane((int)(logical / (unsigned)a.ncb));
     const int n0 = a.col0 + cb * 96;
+    const long long nwt = (a.T + 15) / 16, wt_step = (long long)WAVES * a.groups;
+    // the A operand of the NEXT tile is loaded before the MFMAs of the current one (24 - 48 more registers; the kernel
+    // runs 2 waves per SIMD by choice, so they are free): a wave never waits for HBM between its tiles
+    float av[KQ], an[KQ];
+    auto load_a = [&](long long wtile, float (&dst)[KQ]) {
+        const long long r0 = wtile * 16;
+        const int rm = (int)min(16LL, a.T - r0);
+        const float *xb = a.x + r0 * K;
+        const unsigned xoff = (unsigned)(min(n, rm - 1) * K + kq * KQ);
+#pragma unroll
+        for (int q = 0; q < KQ / 4; ++q) {
+            const float4 v = *(const float4 *)(xb + xoff + 4 * q);
+            dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
+        }
+    };
+    long long wt = rc * WAVES + wave;
+    if (wt < nwt) load_a(wt, av);        // the first tile's x is in flight while the block stages its slice of W
     {
         constexpr int NV = NT * 32 * (K / 4), PER = (NV + THREADS - 1) / THREADS;
         float4 wv[PER];
@@ -160,23 +177,6 @@ __global__ __launch_bounds__(WAVES * 64) void linear_fwd16_kernel(LinearFwdArgs 
         bt[t] = (LN && cok[t]) ? a.beta[col] : 0.0f;
     }
 
-    const long long nwt = (a.T + 15) / 16, wt_step = (long long)WAVES * a.groups;
-    // the A operand of the NEXT tile is loaded before the MFMAs of the current one (24 - 48 more registers; the kernel
-    // runs 2 waves per SIMD by choice, so they are free): a wave never waits for HBM between its tiles
-    float av[KQ], an[KQ];
-    auto load_a = [&](long long wtile, float (&dst)[KQ]) {
-        const long long r0 = wtile * 16;
-        const int rm = (int)min(16LL, a.T - r0);
-        const float *xb = a.x + r0 * K;
-        const unsigned xoff = (unsigned)(min(n, rm - 1) * K + kq * KQ);
-#pragma unroll
-        for (int q = 0; q < KQ / 4; ++q) {
-            const float4 v = *(const float4 *)(xb + xoff + 4 * q);
-            dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
-        }
-    };
-    long long wt = rc * WAVES + wave;
-    if (wt < nwt) load_a(wt, av);
     for (; wt < nwt; wt += wt_step) {
         const long long row0 = wt * 16;
         const int rem = (int)min(16LL, a.T - row0);

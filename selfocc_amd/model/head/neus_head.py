@@ -280,7 +280,7 @@ class NeuSHead(BaseModule):
                  embed_dims=128, color_dims=0, density_layers=2, sh_deg=2, sh_act="relu", init_cfg=None,
                  print_freq=50, two_split=True, tpv=False, using_2d_img_feats=False,
                  sample_pos='start', single_jitter=True, feat_dtype=torch.float32, exact_render=False,
-                 ray_shard=False, **kwargs):
+                 ray_shard=False, render_normal=False, **kwargs):
         super().__init__(init_cfg)
         for name, on in dict(num_samples_importance=num_samples_importance > 0, num_up_sample_steps=num_up_sample_steps > 0,
                              use_numerical_gradients=use_numerical_gradients, estimate_flow=estimate_flow,
@@ -311,6 +311,10 @@ class NeuSHead(BaseModule):
         self.single_jitter = single_jitter
         self.exact_render = exact_render
         self.ray_shard = ray_shard          # shard the ray lattice over the ranks (selfocc_amd/dist.py)
+        # render(): fill `vis_normal` (the fork's "normal_vis" = (sum_i w_i grad_i / |grad_i| + 1) / 2, consumed by the
+        # vis_* scripts only) from a chunked per-sample pass; off by default (zeros): eval_depth.py never reads it and
+        # the pass costs ~25 x the depth render
+        self.render_normal = render_normal
         self.last_inv_s = None
 
     # ---- helpers -----------------------------------------------------------------------
@@ -413,14 +417,42 @@ class NeuSHead(BaseModule):
             out = render_rays(vol, rays, cfg, bkgd_rays=bk)
         shp = (1, num_cams, num_rays)
         rgb = out['rgb'].reshape(*shp, 3) if 'rgb' in out else torch.empty(*shp, 0, device=device)
+        if kwargs.get('vis_normal', self.render_normal) and not self._sharding(rays):
+            normal = self._normal_vis(vol, rays, cfg).reshape(*shp, 3)
+        else:
+            normal = torch.zeros(*shp, 3, device=device)
         outputs = {'ms_depths': [out['depth'].reshape(shp)], 'ms_colors': [rgb],
-                   'vis_normal': [torch.zeros(*shp, 3, device=device)], 'ms_accs': [out['acc'].reshape(shp)],
+                   'vis_normal': [normal], 'ms_accs': [out['acc'].reshape(shp)],
                    'ms_rays': pix}
         if self.return_max_depth:
             outputs['ms_max_depths'] = [out['max_depth'].reshape(shp)]
         if self.return_sem and 'sem' in out:
             outputs['sem'] = [out['sem'].reshape(*shp, -1)]
         return outputs
+
+    def _normal_vis(self, vol, rays, cfg, chunk_rays=90000):
+        """sdfstudio's `normal_vis` of the reference's render dicts (neus_head.py:379, 414, 463): the weighted sum of
+        the unit SDF gradients along each ray, mapped to [0, 1].  Per-sample weights / gradients come from the
+        sample-parallel kernel in row-block chunks of ~``chunk_rays`` rays (the reference's README-sized batches), so
+        no (R, S, 3) tensor of the whole frame ever exists."""
+        from ... import dist as sdist
+        n_chunks = max(1, -(-rays.n_rays // chunk_rays))
+        if rays.pixel_grid:
+            n_chunks = min(n_chunks, rays.ny)
+        parts = []
+        for k in range(n_chunks):
+            sub = sdist.shard_rays(rays, k, n_chunks)
+            o = render_rays(vol, sub, cfg, per_sample=True, want_grad_samples=True)
+            g = o['grad']
+            nrm = g / g.norm(dim=-1, keepdim=True).clamp_min(1e-12)          # F.normalize(p=2, eps=1e-12)
+            parts.append((o['weights'].unsqueeze(-1) * nrm).sum(1))
+        if rays.pixel_grid and n_chunks > 1:      # chunks are row blocks of every camera: back to (cam, row, col) order
+            n_cams = rays.img2lidar.shape[0]
+            rows = [sdist.row_block(rays.ny, k, n_chunks) for k in range(n_chunks)]
+            normal = torch.cat([p.reshape(n_cams, b - a, rays.nx, 3) for p, (a, b) in zip(parts, rows)], 1).reshape(-1, 3)
+        else:
+            normal = torch.cat(parts, 0)
+        return (normal + 1.0) / 2.0
 
     def forward(self, representation, metas=None, **kwargs):
         field = self.model.field

@@ -113,6 +113,25 @@ def test_head_eval_render_vs_oracle(hip):
         assert close(out['sem'][0].reshape(-1, 5).cpu(), ref['sem'], 1e-4, 1e-4).float().mean() >= 0.98
         assert (out['ms_accs'][0].flatten().cpu() - ref['acc']).abs().max() < 5e-3
         assert out['ms_max_depths'][0].shape == (1, 2, 60)
+        # vis_normal (the fork's normal_vis; reference neus_head.py:379, 414, 463): zeros unless asked for, then the
+        # weighted sum of the unit SDF gradients from the chunked per-sample pass == the oracle's per-sample outputs
+        assert torch.count_nonzero(out['vis_normal'][0]) == 0
+        with torch.no_grad():
+            outn = head.render(metas, vis_normal=True)
+        refs = oracle.render_fwd(SDFVolume(vol.mapping, vol.sdf.detach().cpu(), vol.feat.detach().cpu(), vol.n_rgb, vol.n_sem),
+                                 rays, cfg, per_sample=True, want_grad_samples=True)
+        g = refs['grad']
+        want = ((refs['weights'].unsqueeze(-1) * (g / g.norm(dim=-1, keepdim=True).clamp_min(1e-12))).sum(1) + 1.0) / 2.0
+        got = outn['vis_normal'][0].reshape(-1, 3).cpu()
+        assert got.shape == want.shape and (got - want).abs().max() < 1e-4
+        # ... and chunking into row blocks leaves the frame order intact
+        with torch.no_grad():
+            ncfg = head._render_cfg(False)
+            ncfg.inv_s_dev = head.model.field.inv_s_device()
+            sm = head._normal_vis(SDFVolume(vol.mapping, vol.sdf.detach(), vol.feat.detach(), vol.n_rgb, vol.n_sem),
+                                  RaySet(img2lidar=cams.to(vol.sdf.device), nx=10, ny=6, sx=6.4, sy=64 / 6), ncfg,
+                                  chunk_rays=25)
+        assert (sm.cpu() - got).abs().max() < 1e-6
     finally:
         os.environ['eval'] = 'false'
 
