@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SELFOCC_ABI_VERSION 22
+#define SELFOCC_ABI_VERSION 23
 
 int selfocc_abi_version(void);
 const char *selfocc_last_error(void);
@@ -441,6 +441,14 @@ int selfocc_linear_fwd_supported(int64_t T, int32_t N, int32_t K);
 int selfocc_linear_fwd(const float *x, const float *w, const float *bias, const float *residual, int32_t ldr,
                        const float *ln_gamma, const float *ln_beta, float ln_eps, float *y, int32_t ldy, float *y_pre,
                        float *mean, float *rstd, int64_t T, int32_t N, int32_t K, uint32_t flags, void *stream);
+/* The `value_proj` of the deformable attentions (image_cross_attention.py:262-266, mmcv MultiScaleDeformableAttention)
+ * with the output written HEAD-MAJOR, the layout the MSDA kernels gather fastest from (SO_VALUE_HEAD_MAJOR), by the
+ * projection itself:  x (T, K) = T / nv batch items (cameras) of nv pixels;  N = G * 96 output columns = G groups (one
+ * attention module each: e.g. the three TPV planes' value_proj stacked) of 6 heads x 16 channels;
+ *     y (G, T / nv, 6, nv, 16):   y[g][b][h][pix][c] = relu?(x[b * nv + pix] . w[96 g + 16 h + c] + bias[...])
+ * nv >= 16, T a multiple of nv, T * N < 2^31.  flags: SO_LINEAR_RELU. */
+int selfocc_linear_fwd_heads(const float *x, const float *w, const float *bias, float *y, int64_t T, int32_t N, int32_t K,
+                             int32_t nv, uint32_t flags, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Fused temporal reprojection photometric term.  Replaces the per-sample part of

@@ -44,6 +44,8 @@ struct LinearFwdArgs {
     long long T;
     int N, K, ldy, ldr;
     int relu, ncb, groups, col0;
+    int hm_nv;               // > 0: head-major output (selfocc_linear_fwd_heads): rows per batch item
+    unsigned hm_sg;          // floats per 96-column group of the head-major output: (T / nv) * 6 * nv * 16
     float eps;
 };
 
@@ -114,6 +116,31 @@ SO_DEVFN void so_linear_epilogue16(f32x4 (&acc)[NT16], const float (&bv)[NT16], 
 #pragma unroll
             for (int t = 0; t < NT16; ++t)
                 if (FULL || (rok && cok[t])) yb[yo + 16 * t] = o[t];
+        }
+    }
+}
+
+// Head-major epilogue (selfocc_linear_fwd_heads): the 96 columns of a block are 6 heads x 16 channels of one deformable
+// attention's `value`, and a 16-column accumulator tile IS one head — the tile's 64-byte row segments go to
+// y[group][b][head][pix][0..16) instead of y[row][16 head ..]: the (bs, heads, nv, d) layout the MSDA kernels gather
+// fastest from (a cache line then holds x-neighbours of one head), written by the projection itself — no transposing
+// copy.  Rows of a tile are consecutive, so (b, pix) advance without a division per lane (nv >= 16).
+template <int NT16>
+SO_DEVFN void so_linear_epilogue16_hm(f32x4 (&acc)[NT16], const float (&bv)[NT16], float relu_lo, float *yg, long long row0,
+                                      int rem, int nv, int n, int kq) {
+    const long long b0 = row0 / nv;
+    const int pix0 = (int)(row0 - b0 * nv);
+    const unsigned hs = (unsigned)nv * 16u;                       // floats per (b, head)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int rl = 4 * kq + j;
+        int pix = pix0 + rl;
+        unsigned bo = (unsigned)b0 * 6u * hs;
+        if (pix >= nv) { pix -= nv; bo += 6u * hs; }
+        const unsigned o0 = bo + (unsigned)pix * 16u + (unsigned)n;
+        if (rl < rem) {
+#pragma unroll
+            for (int t = 0; t < NT16; ++t) yg[o0 + (unsigned)t * hs] = fmaxf(acc[t][j] + bv[t], relu_lo);
         }
     }
 }
@@ -219,7 +246,10 @@ __global__ __launch_bounds__(WAVES * 64) void linear_fwd16_kernel(LinearFwdArgs 
         float *mb = (LN && a.mean) ? a.mean + row0 : nullptr, *sb = (LN && a.mean) ? a.rstd + row0 : nullptr;
         int no = n;
         asm volatile("" : "+v"(no));      // keeps the loop-invariant row offsets of the epilogue inside the loop
-        if (rem == 16 && full_cols)
+        if (!LN && NT == 3 && a.hm_nv > 0) {
+            if constexpr (!LN && NT == 3)
+                so_linear_epilogue16_hm<NT16>(acc, bv, relu_lo, a.y + (size_t)cb * a.hm_sg, row0, rem, a.hm_nv, no, kq);
+        } else if (rem == 16 && full_cols)
             so_linear_epilogue16<LN, true, NT16>(acc, bv, gv, bt, cok, relu_lo, rb, a.ldr, yb, a.ldy, pb, mb, sb, a.N, a.eps,
                                                  rem, no, kq);
         else
@@ -241,10 +271,10 @@ bool so_linear_fwd_ok(long long T, int N, int K) {
 
 extern "C" int selfocc_linear_fwd_supported(int64_t T, int32_t N, int32_t K) { return so_linear_fwd_ok(T, N, K) ? 1 : 0; }
 
-extern "C" int selfocc_linear_fwd(const float *x, const float *w, const float *bias, const float *residual, int32_t ldr,
-                                  const float *ln_gamma, const float *ln_beta, float ln_eps, float *y, int32_t ldy,
-                                  float *y_pre, float *mean, float *rstd, int64_t T, int32_t N, int32_t K,
-                                  uint32_t flags, void *stream) {
+static int so_linear_fwd_launch(const float *x, const float *w, const float *bias, const float *residual, int32_t ldr,
+                                const float *ln_gamma, const float *ln_beta, float ln_eps, float *y, int32_t ldy,
+                                float *y_pre, float *mean, float *rstd, int64_t T, int32_t N, int32_t K,
+                                uint32_t flags, int32_t hm_nv, void *stream) {
     SO_REQUIRE(so_linear_fwd_ok(T, N, K), "linear_fwd: unsupported shape (T = %lld rows, N = %d, K = %d; K must be 32, 64, 96, "
                "128 or 192)", (long long)T, N, K);
     SO_REQUIRE(x && w && y, "linear_fwd: NULL pointer");
@@ -259,6 +289,8 @@ extern "C" int selfocc_linear_fwd(const float *x, const float *w, const float *b
     a.T = T; a.N = N; a.K = K; a.ldy = ldy; a.ldr = ldr;
     a.relu = (flags & SO_LINEAR_RELU) ? 1 : 0;
     a.eps = ln_eps;
+    a.hm_nv = hm_nv;
+    a.hm_sg = hm_nv > 0 ? (unsigned)(T * 96) : 0u;
     hipStream_t st = (hipStream_t)stream;
     // main launch: the full 96-column blocks (three accumulator tiles per wave); tail launch: the last 1 - 64 columns with
     // one or two tiles (compile-time, so that no accumulator tile sits behind a branch)
@@ -314,4 +346,22 @@ extern "C" int selfocc_linear_fwd(const float *x, const float *w, const float *b
 #undef SO_L16_1
     }
     return so_launch_status();
+}
+
+extern "C" int selfocc_linear_fwd(const float *x, const float *w, const float *bias, const float *residual, int32_t ldr,
+                                  const float *ln_gamma, const float *ln_beta, float ln_eps, float *y, int32_t ldy,
+                                  float *y_pre, float *mean, float *rstd, int64_t T, int32_t N, int32_t K,
+                                  uint32_t flags, void *stream) {
+    return so_linear_fwd_launch(x, w, bias, residual, ldr, ln_gamma, ln_beta, ln_eps, y, ldy, y_pre, mean, rstd, T, N, K, flags, 0,
+                                stream);
+}
+
+extern "C" int selfocc_linear_fwd_heads(const float *x, const float *w, const float *bias, float *y, int64_t T, int32_t N,
+                                        int32_t K, int32_t nv, uint32_t flags, void *stream) {
+    SO_REQUIRE(N >= 96 && N % 96 == 0, "linear_fwd_heads: N = %d must be a multiple of 96 (6 heads x 16 channels per group)", N);
+    SO_REQUIRE(nv >= 16 && T % nv == 0, "linear_fwd_heads: T = %lld rows must be a whole number of batch items of nv = %d >= 16 rows",
+               (long long)T, nv);
+    SO_REQUIRE((long long)T * N < (1LL << 31), "linear_fwd_heads: output too large for 32-bit offsets");
+    return so_linear_fwd_launch(x, w, bias, nullptr, 0, nullptr, nullptr, 0.0f, y, N, nullptr, nullptr, nullptr, T, N, K, flags, nv,
+                                stream);
 }

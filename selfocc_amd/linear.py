@@ -70,3 +70,27 @@ def linear_fwd(x, weight, bias=None, relu=False, residual=None, ln=None, out=Non
                                    ptr(out), int(ldy), ptr(y_pre), ptr(mean), ptr(rstd), T, N, K,
                                    LINEAR_RELU if relu else 0, current_stream(x.device)), "selfocc_linear_fwd")
     return (out, y_pre, mean, rstd) if want_stats else out
+
+
+def linear_fwd_heads_supported(rows, n_out, n_in, nv):
+    return (n_out >= 96 and n_out % 96 == 0 and nv >= 16 and rows % nv == 0 and rows * n_out < 2 ** 31
+            and linear_fwd_supported(rows, n_out, n_in))
+
+
+def linear_fwd_heads(x, weight, bias, nv, relu=False):
+    """value_proj with a head-major result (csrc/linear_fwd.hip, selfocc_linear_fwd_heads): x (B * nv, K), weight
+    (G * 96, K) -> (G, B, 6, nv, 16) float32 — per group the (bs, heads, nv, d) tensor the fused / camera-loop MSDA ops
+    take with ``head_major=True``."""
+    from .abi import LINEAR_RELU
+    if not x.is_cuda:
+        raise RuntimeError("linear_fwd_heads needs CUDA(HIP) tensors: selfocc_amd has no CPU fallback")
+    T, K = x.shape
+    N = weight.shape[0]
+    assert weight.shape[1] == K and x.dtype == torch.float32 and weight.dtype == torch.float32
+    x, weight = x.contiguous(), weight.contiguous()
+    if bias is not None:
+        bias = bias.contiguous()
+    y = torch.empty(N // 96 if N % 96 == 0 else 0, T // nv if nv else 0, 6, nv, 16, device=x.device, dtype=torch.float32)
+    check(lib().selfocc_linear_fwd_heads(ptr(x), ptr(weight), ptr(bias), ptr(y), T, N, K, int(nv),
+                                         LINEAR_RELU if relu else 0, current_stream(x.device)), "selfocc_linear_fwd_heads")
+    return y

@@ -9,7 +9,8 @@ import torch
 import torch.nn as nn
 
 from ..registry import MODELS
-from ..linear import linear_wgrad, wgrad_supported, linear_fwd, linear_fwd_supported
+from ..linear import (linear_wgrad, wgrad_supported, linear_fwd, linear_fwd_supported, linear_fwd_heads,
+                      linear_fwd_heads_supported)
 from ..msda import (MultiScaleDeformableAttnFunction, msda_fused_inference, MSDAFusedFunction, to_head_major,
                     msda_fused_supported)
 
@@ -116,6 +117,23 @@ FUSED_WGRAD = True
 import os as _os0
 FUSED_LINEAR_FWD = _os0.environ.get('SELFOCC_FUSED_LINEAR', '1') == '1'
 LINEAR_FWD_MIN_ROWS = 1024
+
+
+# inference: value_proj writes the head-major layout the MSDA kernels gather fastest from (selfocc_linear_fwd_heads: no
+# transposing copy, unlike HEAD_MAJOR_VALUE below) when the attention has 6 heads x 16 channels (every shipped config)
+HEAD_MAJOR_PROJ = _os0.environ.get('SELFOCC_HEAD_MAJOR_PROJ', '1') == '1'
+
+
+def value_proj_head_major(lin_weight, lin_bias, value2d, nv, num_heads):
+    """(G, B, 6, nv, 16) head-major projection of (B * nv, K) rows through the stacked weight (G * 96, K), or None when
+    the shape / mode does not qualify (the caller then projects pixel-major as the reference does)."""
+    if not (HEAD_MAJOR_PROJ and FUSED_LINEAR_FWD and not torch.is_grad_enabled() and not torch.is_autocast_enabled()
+            and value2d.is_cuda and value2d.dtype == torch.float32 and lin_weight.dtype == torch.float32 and num_heads == 6):
+        return None
+    rows, n_out = value2d.shape[0], lin_weight.shape[0]
+    if rows < LINEAR_FWD_MIN_ROWS or not linear_fwd_heads_supported(rows, n_out, value2d.shape[1], nv):
+        return None
+    return linear_fwd_heads(value2d, lin_weight, lin_bias, nv)
 
 
 def _linear_fwd_ok(x2d, weight):
@@ -302,10 +320,18 @@ def deformable_sampling(module, query, value, reference_points, spatial_shapes, 
         assert sum(host_shapes[0::2][i] * host_shapes[1::2][i] for i in range(len(host_shapes) // 2)) == num_value
     else:
         assert int((spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum()) == num_value
-    value = module.value_proj(value)
-    if key_padding_mask is not None:
-        value = value.masked_fill(key_padding_mask[..., None], 0.0)
-    value = value.view(bs, num_value, module.num_heads, -1)
+    LP0 = module.num_levels * module.num_points
+    v_hm = None
+    if (key_padding_mask is None and not torch.is_grad_enabled() and LP0 <= 256 and not HEAD_MAJOR_VALUE
+            and module.value_proj.weight.shape[0] == 96):
+        # inference: the projection itself writes (bs, heads, nv, d)
+        v_hm = value_proj_head_major(module.value_proj.weight, module.value_proj.bias, value.reshape(bs * num_value, -1),
+                                     num_value, module.num_heads)
+    if v_hm is None:
+        value = module.value_proj(value)
+        if key_padding_mask is not None:
+            value = value.masked_fill(key_padding_mask[..., None], 0.0)
+        value = value.view(bs, num_value, module.num_heads, -1)
     off = module.sampling_offsets(query).view(bs, num_query, module.num_heads, module.num_levels,
                                               module.num_points, 2)
     if reference_points.shape[-1] != 2:
@@ -316,12 +342,14 @@ def deformable_sampling(module, query, value, reference_points, spatial_shapes, 
         # inference: softmax + sampling-location prologue fused into the HIP kernel (no loc / weight tensors)
         logits = module.attention_weights(query).view(bs, num_query, module.num_heads, LP)
         kind = {'level': 0, 'point': 1, 'level_point': 2}[per_level_reference]
-        if HEAD_MAJOR_VALUE:
+        hm = HEAD_MAJOR_VALUE
+        if v_hm is not None:
+            value, hm = v_hm[0], True
+        elif HEAD_MAJOR_VALUE:
             value = to_head_major(value)
         if VALUE_BF16:
             value = value.to(torch.bfloat16)
-        return msda_fused_inference(value, spatial_shapes, level_start_index, reference_points, kind, off, logits,
-                                    HEAD_MAJOR_VALUE)
+        return msda_fused_inference(value, spatial_shapes, level_start_index, reference_points, kind, off, logits, hm)
     if FUSED_TRAINING and value.is_cuda and LP <= 256:
         # training: the same fusion in both directions (no loc / weight tensors, no softmax / normalise kernels)
         host = getattr(spatial_shapes, '_so_host', None)

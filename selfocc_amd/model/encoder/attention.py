@@ -167,14 +167,21 @@ class BEVCrossAttention(BaseModule):
         _, l, _, _ = value.shape                                            # (cams, nv, bs, C)
         hm = bricks.HEAD_MAJOR_VALUE
         if value_pre is not None and value_pre.dim() == 4:
-            v = value_pre              # TPVCrossAttention already laid this plane's values out head-major
+            v, hm = value_pre, True    # TPVCrossAttention already laid this plane's values out head-major
         elif value_pre is not None:    # this plane's column block of the merged value projection (TPVCrossAttention)
             v, hm = value_pre.view(num_cams, l, heads, -1), False
         else:
-            v = da.value_proj(value.permute(2, 0, 1, 3).reshape(num_cams, l, self.embed_dims))
-            v = v.view(num_cams, l, heads, -1)
-            if hm:
-                v = to_head_major(v)
+            vin = value.permute(2, 0, 1, 3).reshape(num_cams * l, self.embed_dims)
+            v_hm = None
+            if host_shapes is None and not hm and da.value_proj.weight.shape[0] == 96:
+                # inference: the projection itself writes (cams, heads, l, d) (selfocc_linear_fwd_heads)
+                v_hm = bricks.value_proj_head_major(da.value_proj.weight, da.value_proj.bias, vin, l, heads)
+            if v_hm is not None:
+                v, hm = v_hm[0], True
+            else:
+                v = da.value_proj(vin.view(num_cams, l, self.embed_dims)).view(num_cams, l, heads, -1)
+                if hm:
+                    v = to_head_major(v)
         off = da.sampling_offsets(query[0]).view(-1, heads, L, P, 2)
         logits = da.attention_weights(query[0]).view(-1, heads, L * P)
         vis_all = getattr(bev_masks, '_so_visible', None)                   # left by the HIP point_sampling
@@ -236,6 +243,18 @@ class TPVCrossAttention(BaseModule):
                 w, b = self._merged_value_proj()
                 cams, l = value.shape[0], value.shape[1]
                 vin = value.permute(2, 0, 1, 3).reshape(cams * l, C)
+                heads0 = self.attns[0].deformable_attention.num_heads
+                v_hm = bricks.value_proj_head_major(w, b, vin, l, heads0) if C == 96 else None
+                if v_hm is not None:
+                    # (3, cams, heads, l, d): each plane's head-major value, written by the projection kernel itself
+                    if bricks.VALUE_BF16:
+                        v_hm = v_hm.to(torch.bfloat16)
+                    vpre = list(v_hm)
+                    return [self.attns[i](query[i], key, value, residual[i] if residual is not None else None,
+                                          spatial_shapes=spatial_shapes, level_start_index=level_start_index,
+                                          reference_points_cams=reference_points_cams[i], bev_masks=tpv_masks[i],
+                                          rebatch_plan=plans[i], out=outs[i], value_pre=vpre[i],
+                                          post_norm=kwargs.get('post_norm')) for i in range(3)]
                 if bricks.FUSED_LINEAR_FWD and bricks._linear_fwd_ok(vin, w):
                     v_all = bricks.linear_fwd(vin, w, b).view(cams, l, 3 * C)
                 else:

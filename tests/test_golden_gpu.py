@@ -157,6 +157,53 @@ def test_bevformer_encoder_vs_reference_class(hip):
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in enc.parameters())
 
 
+@pytest.mark.parametrize("family", ["tpv", "bev"])
+def test_head_major_value_projection_changes_nothing(hip, family):
+    """At the shipped width (96 = 6 heads x 16) the inference value_proj writes head-major through
+    selfocc_linear_fwd_heads and the MSDA kernels gather from that layout: same encoder output as the pixel-major path."""
+    from selfocc_amd.registry import MODELS
+    import selfocc_amd.model  # noqa: F401
+    from selfocc_amd.model import bricks
+    from selfocc_amd import linear as lin_mod
+    name = "encoder" if family == "tpv" else "bev_encoder"
+    enc_np = np.load(os.path.join(G, name + ".npz"))
+    cfg = json.load(open(os.path.join(G, name + "_cfg.json")))
+    ecfg = json.loads(json.dumps(cfg['encoder']).replace('"embed_dims": 32', '"embed_dims": 96').replace('"num_heads": 2', '"num_heads": 6')
+                      .replace('"feedforward_channels": 64', '"feedforward_channels": 192'))
+    torch.manual_seed(5)
+    enc = MODELS.build(dict(type='TPVFormerEncoder' if family == "tpv" else 'BEVFormerEncoder', **ecfg)).to(D0)
+    enc.init_weights()
+    for n, p in enc.named_parameters():
+        if 'sampling_offsets.weight' in n or 'attention_weights' in n:
+            p.data = 0.2 * torch.randn_like(p)
+    enc.eval()
+    lcfg = dict(cfg['lifter']); lcfg['dim'] = 96
+    lifter = MODELS.build(dict(type='TPVQueryLifter' if family == "tpv" else 'BEVQueryLifter', **lcfg)).to(D0).eval()
+    feats = [torch.randn(1, 2, 96, 6, 10, device=D0), torch.randn(1, 2, 96, 3, 5, device=D0)]
+    metas = [dict(lidar2img=enc_np['lidar2img'], img_shape=tuple(cfg['img_shape']))]
+    run = lambda: enc(lifter(feats)['representation'], ms_img_feats=feats, metas=metas)['representation']
+    calls = {'n': 0}
+    real = bricks.linear_fwd_heads
+
+    def counting(*a, **k):
+        calls['n'] += 1
+        return real(*a, **k)
+    old = (bricks.LINEAR_FWD_MIN_ROWS, bricks.HEAD_MAJOR_PROJ, bricks.linear_fwd_heads)
+    try:
+        bricks.LINEAR_FWD_MIN_ROWS, bricks.linear_fwd_heads = 1, counting
+        with torch.no_grad():
+            bricks.HEAD_MAJOR_PROJ = True
+            a = run()
+            n_hm = calls['n']
+            bricks.HEAD_MAJOR_PROJ = False
+            b = run()
+    finally:
+        bricks.LINEAR_FWD_MIN_ROWS, bricks.HEAD_MAJOR_PROJ, bricks.linear_fwd_heads = old
+    assert n_hm >= 2 * len(enc.layers) and calls['n'] == n_hm       # self- and cross-attention value_proj of every layer
+    for x, y in zip(a if isinstance(a, (list, tuple)) else [a], b if isinstance(b, (list, tuple)) else [b]):
+        assert torch.isfinite(x).all() and torch.allclose(x, y, rtol=1e-6, atol=1e-6), (x - y).abs().max()
+
+
 def test_encoder_backward_runs(hip):
     """autograd through the whole encoder (MSDA backward kernel underneath) gives finite grads"""
     from selfocc_amd.registry import MODELS

@@ -120,3 +120,23 @@ def test_linear_fwd_unsupported_shape_is_loud(hip):
         linear_fwd(torch.randn(1000, 100).cuda(), torch.randn(96, 100).cuda())
     with pytest.raises(RuntimeError):       # LayerNorm epilogue needs the whole row in one column block
         linear_fwd(torch.randn(1000, 96).cuda(), torch.randn(192, 96).cuda(), ln=(torch.ones(192).cuda(), torch.zeros(192).cuda(), 1e-5))
+
+
+@pytest.mark.parametrize("B,nv,G,K", [(6, 25500, 3, 96), (1, 78899, 1, 96), (2, 4100, 2, 96), (3, 17, 1, 96), (2, 1000, 1, 192)])
+def test_linear_fwd_heads_is_the_head_major_projection(hip, B, nv, G, K):
+    """selfocc_linear_fwd_heads == selfocc_linear_fwd followed by the (b, pix, g, h, c) -> (g, b, h, pix, c) transposition,
+    bit for bit (the same MFMA chain; only the store addresses differ)."""
+    from selfocc_amd.linear import linear_fwd, linear_fwd_heads, linear_fwd_heads_supported
+    T, N = B * nv, 96 * G
+    assert linear_fwd_heads_supported(T, N, K, nv)
+    g = torch.Generator().manual_seed(B * nv + G)
+    x = torch.randn(T, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    y = linear_fwd(x, w, b)
+    want = y.view(B, nv, G, 6, 16).permute(2, 0, 3, 1, 4).contiguous()
+    got = linear_fwd_heads(x, w, b, nv)
+    assert got.shape == (G, B, 6, nv, 16) and torch.equal(got, want)
+    assert torch.equal(linear_fwd_heads(x, w, b, nv, relu=True), want.clamp_min(0))
+    with pytest.raises(RuntimeError):
+        linear_fwd_heads(x, w[:95], b[:95], nv)            # N must be whole 96-column groups
