@@ -14,8 +14,9 @@
 //   * a persistent block owns a 96-column slice of W in LDS (row stride K + 4 floats: conflict-free ds_read_b128,
 //     staged with all loads in flight) and its waves walk over 16-row tiles of x;
 //   * the A operand (16 rows x K) is loaded ONCE per tile straight into MFMA layout: the reduction index is
-//     permuted so that lane (row m, quarter kq) holds x[row][kq K/4 .. (kq+1) K/4) — K/16 float4 loads per lane — and
-//     the B operand read from LDS uses the same permutation (W[n][kq K/4 + j]);
+//     permuted so that lane (row m, quarter kq) holds x[row][16 q + 4 kq + j] (q < K/16, j < 4) — K/16 float4 loads per
+//     lane, the four kq lanes of a row reading 64 contiguous bytes — and the B operand read from LDS uses the same
+//     permutation (W[n][16 q + 4 kq + j]);
 //   * the epilogue works on the accumulator layout (a lane holds one column of 4 rows; 16 lanes hold 16 consecutive
 //     columns of a row): bias / ReLU / residual per element, LayerNorm by two 4-step shuffle reductions per row.
 // f32 MFMA on gfx950 is an exact fmaf chain: float32 arithmetic, only the summation order differs from a BLAS.
@@ -30,7 +31,8 @@
 // without gain: W as the MFMA's A operand so that a lane owns four consecutive columns of a row and the epilogue is
 // float4 loads / stores (512 us; the SGPR budget overflows), a contiguous range of row tiles per block (504 us), the
 // epilogue of tile i cut into slices between the MFMA groups of tile i + 1 (507 us: anything between two MFMAs costs
-// more than its issue slot).
+// more than its issue slot); the first x tile loaded before the W staging, and the k permutation that makes the x
+// loads touch 16 half lines per instruction instead of 48 lines (both kept, neither measurable: 491 / 492 us).
 // The HBM side is far from its limit (torch fill_ writes the same 100 MB in 16 us = 6 TB/s).
 #include "so_device.h"
 #include <algorithm>
@@ -58,8 +60,8 @@ SO_DEVFN unsigned so_lin_xcd_block() {   // workgroup b runs on XCD b % 8: give 
 
 // 16-row wave tiles on v_mfma_f32_16x16x4_f32 (same f32 rate as 32x32x2, half the registers per wave: A operand K / 4,
 // six 4-register accumulators for 96 columns; twice as many work units to balance over the 1 024 SIMDs).
-//   A[m][k]: lane (m = l % 16, kq = l / 16) holds x[row m][kq K/4 .. (kq+1) K/4)     (K / 16 float4 loads per lane)
-//   B[k][n]: lane (n = l % 16, kq) reads W[n0 + 16 t + n][kq K/4 + j] from LDS (row stride K + 4: conflict-free b128)
+//   A[m][k]: lane (m = l % 16, kq = l / 16) holds x[row m][16 q + 4 kq + j], q < K / 16, j < 4   (K / 16 float4 loads per lane)
+//   B[k][n]: lane (n = l % 16, kq) reads W[n0 + 16 t + n][16 q + 4 kq + j] from LDS (row stride K + 4: conflict-free b128)
 //   D[m][n]: lane holds column n = l % 16 of rows 4 kq + j, j = 0..3
 // Two column tiles are interleaved so that no MFMA waits for its own accumulator (40 cycles dependent latency vs 32 issue).
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -163,10 +165,13 @@ __global__ __launch_bounds__(WAVES * 64) void linear_fwd16_kernel(LinearFwdArgs 
         const long long r0 = wtile * 16;
         const int rm = (int)min(16LL, a.T - r0);
         const float *xb = a.x + r0 * K;
-        const unsigned xoff = (unsigned)(min(n, rm - 1) * K + kq * KQ);
+        // k permutation: load q of lane (row n, kq) covers k = 16 q + 4 kq .. + 3, so the four kq lanes of a row read 64
+        // CONTIGUOUS bytes per instruction (a load instruction touches 16 half lines; with k = kq K/4 + 4 q + j it
+        // touched 64 sixteen-byte pieces in 48 lines — three times the line accesses of the whole tile per pass)
+        const unsigned xoff = (unsigned)(min(n, rm - 1) * K + 4 * kq);
 #pragma unroll
         for (int q = 0; q < KQ / 4; ++q) {
-            const float4 v = *(const float4 *)(xb + xoff + 4 * q);
+            const float4 v = *(const float4 *)(xb + xoff + 16 * q);
             dst[4 * q] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
         }
     };
@@ -217,7 +222,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_fwd16_kernel(LinearFwdArgs 
         // B operand double-buffered in registers: the ds_read_b128 pair of group s + 1 is issued before the eight MFMAs
         // of group s (with one or two waves per SIMD nothing else hides the LDS latency)
         constexpr int QN = KQ / 4, NS = NT * QN;
-        const float *bbase = wl + n * KP + kq * KQ;
+        const float *bbase = wl + n * KP + 4 * kq;      // the same k permutation as the x operand: k = 16 q + 4 kq + j
         float4 b0 = *(const float4 *)(bbase), b1 = *(const float4 *)(bbase + 16 * KP);
 #pragma unroll
         for (int sidx = 0; sidx < NS; ++sidx) {
@@ -225,8 +230,8 @@ __global__ __launch_bounds__(WAVES * 64) void linear_fwd16_kernel(LinearFwdArgs 
             float4 nb0 = b0, nb1 = b1;
             if (sidx + 1 < NS) {
                 const int tp2 = (sidx + 1) / QN, q2 = (sidx + 1) - tp2 * QN;
-                nb0 = *(const float4 *)(bbase + 32 * tp2 * KP + 4 * q2);
-                nb1 = *(const float4 *)(bbase + (32 * tp2 + 16) * KP + 4 * q2);
+                nb0 = *(const float4 *)(bbase + 32 * tp2 * KP + 16 * q2);
+                nb1 = *(const float4 *)(bbase + (32 * tp2 + 16) * KP + 16 * q2);
             }
             __builtin_amdgcn_sched_barrier(0);      // (the scheduler otherwise sinks the reads next to their first use)
             acc[2 * tp] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q], b0.x, acc[2 * tp], 0, 0, 0);
