@@ -213,6 +213,41 @@ def test_cfg2_feature_volumes_staged_kernels_vs_oracle(hip, n_rgb, n_sem, feat_d
     parity_report(got, ref, label=f"cfg2 307k rays C={1 + n_rgb + n_sem} {feat_dtype}", min_frac=0.999)
 
 
+def _novel_view(M, yaw_deg=3.0, shift=(0.4, -0.2, 0.05)):
+    """img2lidar of a camera moved to a novel pose (kitti_novel_depth renders from `render_img2lidar`,
+    utils/config_tools.py:90-92): rotate the rig about z and translate it."""
+    import math
+    c, s_ = math.cos(math.radians(yaw_deg)), math.sin(math.radians(yaw_deg))
+    T = torch.tensor([[c, -s_, 0, shift[0]], [s_, c, 0, shift[1]], [0, 0, 1, shift[2]], [0, 0, 0, 1]], dtype=torch.float64)
+    return (T @ M.double()).float()
+
+
+@pytest.mark.parametrize("name,n_rgb,n_sem,novel", [("cfg4", 3, 0, False), ("cfg4", 3, 0, True), ("cfg4", 0, 0, True),
+                                                   ("cfg5", 3, 21, False), ("cfg5", 0, 0, False)])
+def test_baseline_configs_4_and_5_vs_oracle(hip, name, n_rgb, n_sem, novel):
+    """BASELINE configs[3] (SemanticKITTI mono 370x1220, 257x257x33 volume, 176x608 eval lattice, 256 samples, sdf + rgb,
+    original and NOVEL-view camera) and configs[4]'s shapes (nuscenes_occ: 257x257x25, 6 cams, 25-channel volume, 256
+    samples) as parity cases: every ray of the frame against the C oracle, default fast path."""
+    d = torch.device("cuda:0")
+    vol = sy.make_volume(name, n_rgb=n_rgb, n_sem=n_sem, seed=1)
+    rays = sy.make_rays(name, seed=1)
+    if novel:
+        rays = RaySet(img2lidar=torch.stack([_novel_view(m) for m in rays.img2lidar]), nx=rays.nx, ny=rays.ny, sx=rays.sx,
+                      sy=rays.sy)
+    cfg = sy.make_render_config(name, inv_s=20.0)
+    ref = oracle.render_fwd(vol, rays, cfg)
+    got = render_rays(vol.to(d), _dev_rays(rays, d), cfg)
+    torch.cuda.synchronize()
+    rep = parity_report(got, ref, label=f"{name} C={1 + n_rgb + n_sem}{' novel view' if novel else ''}", min_frac=0.999)
+    assert rep['n_rays'] == rays.n_rays and rep['frac_acc_gt_0.05'] > 0.2
+    # and the canonical (EXACT) path on the same frame: bit-exact SDF-side quantities are covered at cfg1; here depth
+    cfg_e = sy.make_render_config(name, inv_s=20.0, exact=True)
+    got_e = render_rays(vol.to(d), _dev_rays(rays, d), cfg_e)
+    ok = ref['acc'] > 0.05
+    rel = (got_e['depth'].cpu() - ref['depth']).abs() / ref['depth'].abs().clamp_min(1e-6)
+    assert (rel[ok] < 1e-4).float().mean() >= 0.9999 and rel[ok].max() < 1e-3
+
+
 def test_fast_path_switches_agree(hip):
     """The free-space skip is exact by construction (both sigmoids are exactly 1.0f in the skipped cells), so
     skip on / off must agree to accumulation-order noise; canonical cell selection near faces (face_safe) may
