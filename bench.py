@@ -317,6 +317,7 @@ def main():
         hot_path = {}
         here = os.path.dirname(os.path.abspath(__file__))
         for key, script in (("eval_frame_nuscenes_depth_ms", "bench_hotpath_eval.py"),
+                            ("occ_eval_frame_nuscenes_occ_ms", "bench_hotpath_occ.py"),
                             ("train_iteration_nuscenes_occ_ms", "bench_hotpath_train.py")):
             try:
                 r = subprocess.run([sys.executable, os.path.join(here, "scripts", script)], capture_output=True,

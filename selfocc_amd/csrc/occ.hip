@@ -10,8 +10,8 @@
 //
 // Everything here is the CANONICAL arithmetic (so_device.h): the trilinear value is
 // bit-identical to torch's CPU grid_sampler_3d, hence the integer occupancy is bit-exact.
-// The work is tiny (640 k lattice points) and pure gather: one lane per output point,
-// D-axis neighbours fetched as one 8-byte load.
+// The work is small (640 k lattice points) and pure gather: a team of 8 lanes per output point (one channel
+// group each), D-axis neighbours of the SDF fetched as one 8-byte load.
 #include "so_device.h"
 
 namespace {
@@ -31,39 +31,99 @@ SO_DEVFN float so_trilerp_chan(const float *__restrict__ vol, int H, int W, int 
     return out;
 }
 
+// ---- channel teams ------------------------------------------------------------------------------------------------
+// A query point is served by a TEAM of 8 adjacent lanes: lane j owns channels j, j + 8, j + 16, ... of the channels-last
+// record, so one load instruction of the team reads 32 contiguous bytes of a corner (a lane-per-point loop over the 21
+// semantic channels issued 168 scattered dword loads per lane and left the chip with 10 k waves for the whole 640 k-point
+// lattice: 1.5 ms; the teams make it 80 k short waves).  Per channel the arithmetic is unchanged — out = sum over the
+// corners k = 0..7 in order, out-of-range corners skipped (torch's grid_sampler_3d, padding_mode = 'zeros') — so values
+// and the integer occupancy / arg-max stay bit-identical.  Lane 0 of the team also does the SDF channel.
+constexpr int kTeam = 8, kTeamRounds = 4;          // up to 32 channels
+
+struct TeamCorner {
+    size_t vox[8];     // voxel index of corner k
+    float w[8];        // its trilinear weight ((fd * fw) * fh, torch's order)
+    bool in[8];
+};
+
+SO_DEVFN TeamCorner so_team_corners(const so_cell &c, int H, int W, int D) {
+    TeamCorner t;
+    const float fd[2] = {c.fd0, c.fd1}, fw[2] = {c.fw0, c.fw1}, fh[2] = {c.fh0, c.fh1};
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int h = c.h0 + (k >> 2), w = c.w0 + ((k >> 1) & 1), d = c.d0 + (k & 1);
+        t.in[k] = (h >= 0) && (h < H) && (w >= 0) && (w < W) && (d >= 0) && (d < D);
+        t.w[k] = (fd[k & 1] * fw[(k >> 1) & 1]) * fh[k >> 2];
+        t.vox[k] = t.in[k] ? ((size_t)h * W + w) * D + d : 0;
+    }
+    return t;
+}
+
+// this lane's channels (j, j + 8, ...) of the trilinear lookup; the team's first maximum over all n_ch channels
+template <bool BF16>
+SO_DEVFN void so_team_lookup(const void *__restrict__ vol, int stride, int ch0, int n_ch, const TeamCorner &t, int j,
+                             float (&out)[kTeamRounds], float &best, int &arg) {
+    best = -INFINITY;
+    arg = 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < kTeamRounds; ++r) {
+        const int ch = j + kTeam * r;
+        out[r] = 0.0f;
+        if (ch < n_ch) {     // (n_ch <= 32: host)
+            float v = 0.0f;
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (t.in[k]) {
+                    const size_t e = t.vox[k] * (size_t)stride + ch0 + ch;
+                    const float x = BF16 ? so_bf16_to_f32(((const uint16_t *)vol)[e]) : ((const float *)vol)[e];
+                    v = v + x * t.w[k];
+                }
+            }
+            out[r] = v;
+            if (v > best) { best = v; arg = ch; }      // ascending channels: the lane's first maximum
+        }
+    }
+    if (arg == 0x7fffffff) arg = 0;                      // nothing beat -inf (or the lane has no channel): like the serial loop
+    const bool has = j < n_ch;
+    float b = has ? best : -INFINITY;
+    int a_ = has ? arg : 0x7ffffffe;
+#pragma unroll
+    for (int m = 1; m < kTeam; m <<= 1) {                // first maximum across the team: larger value, then smaller channel
+        const float ob = __shfl_xor(b, m, 64);
+        const int oa = __shfl_xor(a_, m, 64);
+        if (ob > b || (ob == b && oa < a_)) { b = ob; a_ = oa; }
+    }
+    best = b;
+    arg = (a_ >= 0x7ffffffe) ? 0 : a_;
+    // the serial loop keeps arg = 0 unless some value is > -inf
+    if (!(b > -INFINITY)) arg = 0;
+}
+
 __global__ __launch_bounds__(256) void field_query_kernel(so_query_args a) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= a.n) return;
+    const long long gt = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long pt = gt / kTeam;
+    const int j = (int)(gt - pt * kTeam);
+    const bool live = pt < a.n;
+    const int i = live ? (int)pt : a.n - 1;      // dead teams shadow the last point (the shuffles need every lane)
     const int H = a.map.h.tot_len, W = a.map.w.tot_len, D = a.map.d.tot_len;
     const so_cell c = so_locate(a.map, a.xyz[3 * (size_t)i], a.xyz[3 * (size_t)i + 1], a.xyz[3 * (size_t)i + 2]);
-    if (a.sdf) {
+    if (a.sdf && j == 0 && live) {
         float v[8], wk[8];
         so_gather_sdf(a.sdf_vol, H, W, D, c, v);
         a.sdf[i] = so_trilerp_sdf(c, v, wk);
     }
     if (a.n_sem > 0 && (a.sem_logits || a.sem_argmax)) {
-        float best = -INFINITY;
-        int arg = 0;
-        for (int k = 0; k < a.n_sem; ++k) {
-            float v;
-            if (a.feat_dtype == SO_DTYPE_F32) {
-                v = so_trilerp_chan((const float *)a.feat_vol, H, W, D, a.feat_stride, a.n_rgb + k, c);
-            } else {
-                // bf16 storage: same canonical order on the up-converted corners
-                const float fd[2] = {c.fd0, c.fd1}, fw[2] = {c.fw0, c.fw1}, fh[2] = {c.fh0, c.fh1};
-                v = 0.0f;
-                for (int kk = 0; kk < 8; ++kk) {
-                    const int h = c.h0 + (kk >> 2), w = c.w0 + ((kk >> 1) & 1), d = c.d0 + (kk & 1);
-                    const bool in = (h >= 0) && (h < H) && (w >= 0) && (w < W) && (d >= 0) && (d < D);
-                    const float wk = (fd[kk & 1] * fw[(kk >> 1) & 1]) * fh[kk >> 2];
-                    if (in)
-                        v = v + so_bf16_to_f32(((const uint16_t *)a.feat_vol)[(((size_t)h * W + w) * D + d) * a.feat_stride + a.n_rgb + k]) * wk;
-                }
-            }
-            if (a.sem_logits) a.sem_logits[(size_t)i * a.n_sem + k] = v;
-            if (v > best) { best = v; arg = k; }  // first maximum, like torch.argmax
+        const TeamCorner t = so_team_corners(c, H, W, D);
+        float out[kTeamRounds], best;
+        int arg;
+        if (a.feat_dtype == SO_DTYPE_F32) so_team_lookup<false>(a.feat_vol, a.feat_stride, a.n_rgb, a.n_sem, t, j, out, best, arg);
+        else so_team_lookup<true>(a.feat_vol, a.feat_stride, a.n_rgb, a.n_sem, t, j, out, best, arg);
+        if (live && a.sem_logits) {
+#pragma unroll
+            for (int r = 0; r < kTeamRounds; ++r)
+                if (j + kTeam * r < a.n_sem) a.sem_logits[(size_t)i * a.n_sem + j + kTeam * r] = out[r];
         }
-        if (a.sem_argmax) a.sem_argmax[i] = arg;
+        if (live && a.sem_argmax && j == 0) a.sem_argmax[i] = arg;
     }
 }
 
@@ -94,8 +154,11 @@ __global__ __launch_bounds__(256) void field_query_bwd_kernel(so_query_args a, c
 
 __global__ __launch_bounds__(256) void occ_resample_kernel(so_occ_args a) {
     const int n = a.n0 * a.n1 * a.n2;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const long long gt = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long pt = gt / kTeam;
+    const int j = (int)(gt - pt * kTeam);
+    const bool live = pt < n;
+    const int i = live ? (int)pt : n - 1;
     // F.grid_sample(align_corners=True) of coords * 2 - 1  (eval_iou.py:217-221)
     so_cell c;
     const float gh = ((((a.coords[3 * (size_t)i] * 2.0f) - 1.0f) + 1.0f) / 2.0f) * (float)(a.H - 1);
@@ -107,24 +170,26 @@ __global__ __launch_bounds__(256) void occ_resample_kernel(so_occ_args a) {
     c.fw1 = gw - fw; c.fw0 = (fw + 1.0f) - gw;
     c.fd1 = gd - fd; c.fd0 = (fd + 1.0f) - gd;
     float v[8], wk[8];
-    so_gather_sdf(a.grid, a.H, a.W, a.D, c, v);
+    so_gather_sdf(a.grid, a.H, a.W, a.D, c, v);       // (8 lanes read the same 8 values: one broadcast line each)
     const float s = so_trilerp_sdf(c, v, wk);
-    if (a.sampled) a.sampled[i] = s;
     int occ = a.density ? (s >= a.thresh) : (s <= a.thresh);
     const int i2 = i % a.n2, i1 = (i / a.n2) % a.n1, i0 = i / (a.n2 * a.n1);
     if (i0 < a.crop[0] || i0 >= a.n0 - a.crop[1] || i1 < a.crop[2] || i1 >= a.n1 - a.crop[3] ||
         i2 < a.crop[4] || i2 >= a.n2 - a.crop[5])
         occ = 0;
-    if (a.occ) a.occ[i] = occ;
+    if (live && j == 0) {
+        if (a.sampled) a.sampled[i] = s;
+        if (a.occ) a.occ[i] = occ;
+    }
     if (a.sem && a.logits) {
-        float best = -INFINITY;
-        int arg = 0;
-        for (int k = 0; k < a.C; ++k) {
-            const float l = so_trilerp_chan(a.logits, a.H, a.W, a.D, a.C, k, c);
-            if (l > best) { best = l; arg = k; }
+        const TeamCorner t = so_team_corners(c, a.H, a.W, a.D);
+        float out[kTeamRounds], best;
+        int arg;
+        so_team_lookup<false>(a.logits, a.C, 0, a.C, t, j, out, best, arg);
+        if (live && j == 0) {
+            const int cls = a.lut ? a.lut[arg] : arg;
+            a.sem[i] = occ * cls;
         }
-        const int cls = a.lut ? a.lut[arg] : arg;
-        a.sem[i] = occ * cls;
     }
 }
 
@@ -174,7 +239,11 @@ extern "C" int selfocc_field_query(const so_query_args *args, void *stream) {
         SO_REQUIRE(a.feat_stride >= a.n_rgb + a.n_sem, "feat_stride < n_rgb + n_sem");
         SO_REQUIRE(a.feat_dtype == SO_DTYPE_F32 || a.feat_dtype == SO_DTYPE_BF16, "bad feat_dtype");
     }
-    hipLaunchKernelGGL(field_query_kernel, dim3((a.n + 255) / 256), dim3(256), 0, (hipStream_t)stream, a);
+    SO_REQUIRE(!(a.sem_logits || a.sem_argmax) || a.n_sem <= kTeam * kTeamRounds, "field_query: n_sem = %d > %d", a.n_sem,
+               kTeam * kTeamRounds);
+    const long long nthreads = (long long)a.n * kTeam;
+    SO_REQUIRE(nthreads < (1LL << 31) * 256, "field_query: too many points");
+    hipLaunchKernelGGL(field_query_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, (hipStream_t)stream, a);
     return so_launch_status();
 }
 
@@ -207,7 +276,8 @@ extern "C" int selfocc_occ_resample(const so_occ_args *args, void *stream) {
     SO_REQUIRE(a.grid && a.coords, "grid / coords is NULL");
     SO_REQUIRE(a.H >= 2 && a.W >= 2 && a.D >= 2, "grid dims must be >= 2");
     SO_REQUIRE(a.sem == nullptr || (a.logits != nullptr && a.C >= 1), "sem requested but logits NULL / C < 1");
-    hipLaunchKernelGGL(occ_resample_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+    SO_REQUIRE(a.sem == nullptr || a.C <= kTeam * kTeamRounds, "occ_resample: C = %d > %d classes", a.C, kTeam * kTeamRounds);
+    hipLaunchKernelGGL(occ_resample_kernel, dim3((unsigned)((n * kTeam + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, a);
     return so_launch_status();
 }
