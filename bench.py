@@ -290,7 +290,12 @@ def main():
         from oracle import torch_port as tp
         ex = sy.explicit_rays(rays_cpu)
         dc = vol_cpu.to_reference_layout()
-        cores = torch.get_num_threads()
+        # thread count: the best of a sweep on the GPU box's host (scripts/micro/cpu_port_threads.py, 256 hardware
+        # threads): 8 / 16 / 32 / 64 / 128 / 256 torch threads = 53 / 55 / 53 / 41 / 17 / 5 k rays/s — torch's default (128)
+        # oversubscribes these memory-bound ops
+        default_threads = torch.get_num_threads()
+        cores = min(16, default_threads)
+        torch.set_num_threads(cores)
         tp.render_port(vol_cpu.mapping, dc, n_rgb, n_sem, ex.origins[:2000], ex.dirs[:2000], ex.dir_norm[:2000], cfg)
         chunk, done, spent = 90_000, 0, 0.0
         while done < n_rays and spent < 12.0:
@@ -299,9 +304,11 @@ def main():
             tp.render_port(vol_cpu.mapping, dc, n_rgb, n_sem, ex.origins[sl], ex.dirs[sl], ex.dir_norm[sl], cfg, chunk=chunk)
             spent += time.perf_counter() - c0
             done = sl.stop
+        torch.set_num_threads(default_threads)
         cpu_baseline = {"value": round(done / spent, 1), "unit": "rays/s", "cores": cores, "kind": "port",
                         "sample": f"first {done} rays of the same cfg2 frame (chunks of 90000), C={args.channels}, "
-                                  f"torch CPU F.grid_sample + NeuS compositing, {spent:.1f} s"}
+                                  f"torch CPU F.grid_sample + NeuS compositing, {spent:.1f} s; {cores} torch threads = "
+                                  f"the fastest of a 8..256 sweep on this host ({os.cpu_count()} hardware threads)"}
         # the plain-C restatement (OpenMP, all hardware threads) on the whole frame, for scale
         if parity:
             cpu_baseline["c_oracle_rays_per_s"] = round(rays_cpu.n_rays / parity["oracle_seconds"], 1)
