@@ -124,15 +124,23 @@ LINEAR_FWD_MIN_ROWS = 1024
 HEAD_MAJOR_PROJ = _os0.environ.get('SELFOCC_HEAD_MAJOR_PROJ', '1') == '1'
 
 
+HEAD_MAJOR_PROJ_TRAIN = _os0.environ.get('SELFOCC_HEAD_MAJOR_PROJ_TRAIN', '1') == '1'
+
+
 def value_proj_head_major(lin_weight, lin_bias, value2d, nv, num_heads):
     """(G, B, 6, nv, 16) head-major projection of (B * nv, K) rows through the stacked weight (G * 96, K), or None when
-    the shape / mode does not qualify (the caller then projects pixel-major as the reference does)."""
-    if not (HEAD_MAJOR_PROJ and FUSED_LINEAR_FWD and not torch.is_grad_enabled() and not torch.is_autocast_enabled()
+    the shape / mode does not qualify (the caller then projects pixel-major as the reference does).  Under autograd
+    the result carries the projection's backward (_TallLinearHeads)."""
+    if not (HEAD_MAJOR_PROJ and FUSED_LINEAR_FWD and not torch.is_autocast_enabled()
             and value2d.is_cuda and value2d.dtype == torch.float32 and lin_weight.dtype == torch.float32 and num_heads == 6):
         return None
     rows, n_out = value2d.shape[0], lin_weight.shape[0]
     if rows < LINEAR_FWD_MIN_ROWS or not linear_fwd_heads_supported(rows, n_out, value2d.shape[1], nv):
         return None
+    if torch.is_grad_enabled() and (value2d.requires_grad or lin_weight.requires_grad):
+        if not HEAD_MAJOR_PROJ_TRAIN:
+            return None
+        return _TallLinearHeads.apply(value2d, lin_weight, lin_bias, nv)
     return linear_fwd_heads(value2d, lin_weight, lin_bias, nv)
 
 
@@ -201,12 +209,17 @@ class _TallLinear(torch.autograd.Function):
     @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
+        return _tall_linear_backward(x, weight, dy, ctx.has_bias)
+
+
+def _tall_linear_backward(x, weight, dy, has_bias):
+        """(dx, dW, db) of y = x W^T + b for a row-major dy (shared by _TallLinear and _TallLinearHeads)."""
         dy = dy.contiguous().to(x.dtype)
         T = x.shape[0]
         if (FUSED_WGRAD and dy.is_cuda and dy.dtype == torch.float32 and T > 0
                 and wgrad_supported(T, dy.shape[1], x.shape[1])):
             # one MFMA pass over dy and x for dW and db (csrc/linear.hip) instead of batched GEMMs + two reductions
-            dw, db = linear_wgrad(dy, x, ctx.has_bias)
+            dw, db = linear_wgrad(dy, x, has_bias)
             return dy @ weight, dw, db
         G = max(1, min(256, T // 2048))  # ~2 k+ rows per batched GEMM: enough workgroups, small partial-sum tensor
         R = T // G                       # rows per batched GEMM
@@ -227,7 +240,28 @@ class _TallLinear(torch.autograd.Function):
             db = db + dy[Tp:].sum(0)
         if Tp < T:
             dw = dw + dy[Tp:].t() @ x[Tp:]
-        return dy @ weight, dw, (db if ctx.has_bias else None)
+        return dy @ weight, dw, (db if has_bias else None)
+
+
+class _TallLinearHeads(torch.autograd.Function):
+    """value_proj with a HEAD-MAJOR result under autograd: forward = selfocc_linear_fwd_heads (the projection writes the
+    (G, B, 6, nv, 16) layout the MSDA kernels gather fastest from, forward and backward point kernels alike); backward
+    brings the head-major gradient back to rows with one transposing copy and continues as _TallLinear."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, x, weight, bias, nv):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return linear_fwd_heads(x, weight, bias, nv)
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, dy_hm):
+        x, weight = ctx.saved_tensors
+        G, B, H, nv, d = dy_hm.shape
+        dy = dy_hm.permute(1, 3, 0, 2, 4).reshape(B * nv, G * H * d)        # (b, pix, g, h, c): one transposing copy
+        return (*_tall_linear_backward(x, weight, dy, ctx.has_bias), None)
 
 
 class TallLinear(nn.Linear):
@@ -322,9 +356,9 @@ def deformable_sampling(module, query, value, reference_points, spatial_shapes, 
         assert int((spatial_shapes[:, 0] * spatial_shapes[:, 1]).sum()) == num_value
     LP0 = module.num_levels * module.num_points
     v_hm = None
-    if (key_padding_mask is None and not torch.is_grad_enabled() and LP0 <= 256 and not HEAD_MAJOR_VALUE
-            and module.value_proj.weight.shape[0] == 96):
-        # inference: the projection itself writes (bs, heads, nv, d)
+    if (key_padding_mask is None and LP0 <= 256 and not HEAD_MAJOR_VALUE and module.value_proj.weight.shape[0] == 96
+            and (not torch.is_grad_enabled() or FUSED_TRAINING)):
+        # the projection itself writes (bs, heads, nv, d)
         v_hm = value_proj_head_major(module.value_proj.weight, module.value_proj.bias, value.reshape(bs * num_value, -1),
                                      num_value, module.num_heads)
     if v_hm is None:
@@ -355,14 +389,19 @@ def deformable_sampling(module, query, value, reference_points, spatial_shapes, 
         host = getattr(spatial_shapes, '_so_host', None)
         if host is None:
             host = [int(v) for v in spatial_shapes.reshape(-1).tolist()]
-        if msda_fused_supported(host, bs, num_query, module.num_heads, value.shape[-1], module.num_levels,
-                                module.num_points):
+        d_head = module.value_proj.weight.shape[0] // module.num_heads if v_hm is not None else value.shape[-1]
+        if msda_fused_supported(host, bs, num_query, module.num_heads, d_head, module.num_levels, module.num_points):
             logits = module.attention_weights(query).view(bs, num_query, module.num_heads, LP)
             kind = {'level': 0, 'point': 1, 'level_point': 2}[per_level_reference]
-            if HEAD_MAJOR_VALUE:
+            hm = HEAD_MAJOR_VALUE
+            if v_hm is not None:
+                value, hm = v_hm[0], True
+            elif HEAD_MAJOR_VALUE:
                 value = to_head_major(value)
             return MSDAFusedFunction.apply(value, spatial_shapes, level_start_index, reference_points, kind, off,
-                                           logits, host, HEAD_MAJOR_VALUE, VALUE_BF16)
+                                           logits, host, hm, VALUE_BF16)
+    if v_hm is not None:      # (the unfused fallback below wants the mmcv layout)
+        value = v_hm[0].permute(0, 2, 1, 3).contiguous()
     aw = module.attention_weights(query).view(bs, num_query, module.num_heads,
                                               module.num_levels * module.num_points).softmax(-1)
     aw = aw.view(bs, num_query, module.num_heads, module.num_levels, module.num_points)

@@ -173,8 +173,8 @@ class BEVCrossAttention(BaseModule):
         else:
             vin = value.permute(2, 0, 1, 3).reshape(num_cams * l, self.embed_dims)
             v_hm = None
-            if host_shapes is None and not hm and da.value_proj.weight.shape[0] == 96:
-                # inference: the projection itself writes (cams, heads, l, d) (selfocc_linear_fwd_heads)
+            if not hm and da.value_proj.weight.shape[0] == 96:
+                # the projection itself writes (cams, heads, l, d) (selfocc_linear_fwd_heads; under autograd _TallLinearHeads)
                 v_hm = bricks.value_proj_head_major(da.value_proj.weight, da.value_proj.bias, vin, l, heads)
             if v_hm is not None:
                 v, hm = v_hm[0], True

@@ -202,6 +202,32 @@ def test_head_major_value_projection_changes_nothing(hip, family):
     assert n_hm >= 2 * len(enc.layers) and calls['n'] == n_hm       # self- and cross-attention value_proj of every layer
     for x, y in zip(a if isinstance(a, (list, tuple)) else [a], b if isinstance(b, (list, tuple)) else [b]):
         assert torch.isfinite(x).all() and torch.allclose(x, y, rtol=1e-6, atol=1e-6), (x - y).abs().max()
+    # the same under autograd (_TallLinearHeads: head-major forward, the gradient transposed back for wgrad / dgrad):
+    # outputs and every parameter / input gradient agree with the pixel-major training path
+    feats[0].requires_grad_(True)
+
+    def train_pass(flag):
+        bricks.HEAD_MAJOR_PROJ_TRAIN = flag
+        enc.zero_grad(); feats[0].grad = None
+        out = run()
+        outs = list(out) if isinstance(out, (list, tuple)) else [out]
+        sum((o * torch.linspace(-1, 1, o.shape[-1], device=D0)).sum() for o in outs).backward()
+        return [o.detach() for o in outs], {n: p.grad.clone() for n, p in enc.named_parameters()}, feats[0].grad.clone()
+    old2 = (bricks.LINEAR_FWD_MIN_ROWS, bricks.HEAD_MAJOR_PROJ_TRAIN, bricks.linear_fwd_heads)
+    try:
+        bricks.LINEAR_FWD_MIN_ROWS, bricks.linear_fwd_heads = 1, counting
+        n0 = calls['n']
+        o1, g1, f1 = train_pass(True)
+        assert calls['n'] - n0 >= 2 * len(enc.layers)
+        o0, g0, f0 = train_pass(False)
+    finally:
+        bricks.LINEAR_FWD_MIN_ROWS, bricks.HEAD_MAJOR_PROJ_TRAIN, bricks.linear_fwd_heads = old2
+    for x, y in zip(o1, o0):
+        assert torch.allclose(x, y, rtol=1e-5, atol=1e-5), (x - y).abs().max()
+    assert torch.allclose(f1, f0, rtol=1e-4, atol=1e-5 * f0.abs().max().item() + 1e-8), (f1 - f0).abs().max()
+    for n in g0:
+        scale = max(g0[n].abs().max().item(), 1e-12)
+        assert torch.allclose(g1[n], g0[n], rtol=1e-3, atol=1e-4 * scale), (n, (g1[n] - g0[n]).abs().max().item(), scale)
 
 
 def test_encoder_backward_runs(hip):
