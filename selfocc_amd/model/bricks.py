@@ -3,6 +3,7 @@ ModuleList, init helpers, FFN, norm builder and the mmcv MultiScaleDeformableAtt
 class whose parameters / state-dict keys CrossViewHybridAttention inherits
 (model/encoder/tpvformer/attention/cross_view_hybrid_attention.py:12)."""
 import math
+import os
 import warnings
 
 import torch
@@ -114,17 +115,16 @@ def build_activation_layer(cfg):
 FUSED_WGRAD = True
 # forward of the tall projections (and, in inference, the residual add / LayerNorm that follow them) through
 # selfocc_linear_fwd (csrc/linear_fwd.hip); False: torch.addmm + separate elementwise kernels (A/B)
-import os as _os0
-FUSED_LINEAR_FWD = _os0.environ.get('SELFOCC_FUSED_LINEAR', '1') == '1'
+FUSED_LINEAR_FWD = os.environ.get('SELFOCC_FUSED_LINEAR', '1') == '1'
 LINEAR_FWD_MIN_ROWS = 1024
 
 
 # inference: value_proj writes the head-major layout the MSDA kernels gather fastest from (selfocc_linear_fwd_heads: no
 # transposing copy, unlike HEAD_MAJOR_VALUE below) when the attention has 6 heads x 16 channels (every shipped config)
-HEAD_MAJOR_PROJ = _os0.environ.get('SELFOCC_HEAD_MAJOR_PROJ', '1') == '1'
+HEAD_MAJOR_PROJ = os.environ.get('SELFOCC_HEAD_MAJOR_PROJ', '1') == '1'
 
 
-HEAD_MAJOR_PROJ_TRAIN = _os0.environ.get('SELFOCC_HEAD_MAJOR_PROJ_TRAIN', '1') == '1'
+HEAD_MAJOR_PROJ_TRAIN = os.environ.get('SELFOCC_HEAD_MAJOR_PROJ_TRAIN', '1') == '1'
 
 
 def value_proj_head_major(lin_weight, lin_bias, value2d, nv, num_heads):
@@ -336,8 +336,7 @@ HEAD_MAJOR_VALUE = False
 # point kernels); arithmetic and gradients stay float32.  Halves the corner segments the L1-bound gathers move
 # (BASELINE configs[1]: "bf16"); deviates from the reference's float32 MSDA by the bf16 rounding of value (~2^-9
 # relative), so it is opt-in: the default reproduces the reference to 1e-4.  env SELFOCC_VALUE_BF16=1 sets it.
-import os as _os
-VALUE_BF16 = _os.environ.get('SELFOCC_VALUE_BF16', '0') == '1'
+VALUE_BF16 = os.environ.get('SELFOCC_VALUE_BF16', '0') == '1'
 
 
 def deformable_sampling(module, query, value, reference_points, spatial_shapes, level_start_index,
