@@ -21,8 +21,11 @@
 // are 31 us): at 2 waves per SIMD (144 accumulator + 48 prefetch registers) the two overlap only partly.  Tried without
 // gain: branch-free clamped loads + ping-pong register buffers + sched_barrier so that the compiler emits counted
 // vmcnt waits (74 us: 64-bit address math per load, spills), an XCD-aware block order that lets the n-groups of a row
-// chunk share x in one L2 (70 -> 70 us; 96 -> 138 us for N = 432).  Next step would be LDS-staged tiles shared by
-// the block's waves.
+// chunk share x in one L2 (70 -> 70 us; 96 -> 138 us for N = 432); and (end of round 2) the LDS-staged form — a block
+// stages 32 rows of dY / X with coalesced float4 loads (next stage in registers, one barrier per stage) and its four
+// waves split the 96 x K output 2 x 2 on v_mfma_f32_16x16x4_f32 (36 accumulator registers, ds_read_b32 operands): correct,
+// but 83 / 113 / 202 us where this kernel takes 70 / 95 / 153 us (a barrier per 72 MFMAs per wave and one LDS read per
+// operand cost more than the overlap buys) — dropped.
 #include "so_device.h"
 #include <algorithm>
 
