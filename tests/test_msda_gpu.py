@@ -126,22 +126,24 @@ def test_msda_fused_prologue_matches_unfused(hip, kind, P, L):
     assert torch.allclose(got.cpu(), want, rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("P,L,D", [(8, 4, 16), (48, 4, 16), (5, 2, 8), (70, 3, 16), (3, 1, 32)])
-def test_msda_cross_camera_loop_matches_per_camera_ops(hip, P, L, D):
+@pytest.mark.parametrize("P,L,D,cams", [(8, 4, 16, 5), (48, 4, 16, 5), (5, 2, 8, 5), (70, 3, 16, 5), (3, 1, 32, 5),
+                                        (8, 4, 16, 1), (48, 4, 16, 1)])
+def test_msda_cross_camera_loop_matches_per_camera_ops(hip, P, L, D, cams):
     """selfocc_msda_cross_fwd == sum over the visible cameras of the plain op (oracle-checked above)
-    / max(#visible, 1): queries seen by no camera, one camera and all cameras."""
+    / max(#visible, 1): queries seen by no camera, one camera and all cameras; cams = 1 is the mono SemanticKITTI /
+    KITTI-raw configs (BASELINE configs[3])."""
     from selfocc_amd.msda import msda_cross_inference
     g = torch.Generator().manual_seed(P * 10 + L)
     shapes = torch.tensor([[24, 50], [12, 25], [6, 13], [3, 7]][:L])
     starts = torch.cat([torch.zeros(1, dtype=torch.int64), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
     nv = int((shapes[:, 0] * shapes[:, 1]).sum())
-    cams, nq, H = 5, 203, 3
+    nq, H = 203, 3
     value = torch.randn(cams, nv, H, D, generator=g)
     off = torch.randn(nq, H, L, P, 2, generator=g) * 3
     logits = torch.randn(nq, H, L * P, generator=g) * 2
     ref = torch.rand(cams, nq, P, 2, generator=g) * 1.4 - 0.2
     vis = torch.rand(cams, nq, generator=g) < 0.4
-    vis[:, 0] = False; vis[:, 1] = True; vis[:, 2] = False; vis[3, 2] = True
+    vis[:, 0] = False; vis[:, 1] = True; vis[:, 2] = False; vis[min(3, cams - 1), 2] = True
     d = torch.device("cuda:0")
     got = msda_cross_inference(value.to(d), shapes.to(d), starts.to(d), ref.to(d), vis.to(d), off.to(d), logits.to(d)).cpu()
     aw = logits.softmax(-1).view(nq, H, L, P)
@@ -196,8 +198,8 @@ def test_msda_fused_training_matches_unfused_autograd(hip, kind, P, L, D):
     assert torch.allclose(a[3], b[3], rtol=1e-3, atol=1e-4 * b[3].abs().max().item())   # grad logits
 
 
-@pytest.mark.parametrize("P,L,D", [(8, 4, 16), (48, 4, 16), (5, 2, 8), (3, 1, 32)])
-def test_msda_cross_training_matches_per_camera_autograd(hip, P, L, D):
+@pytest.mark.parametrize("P,L,D,cams", [(8, 4, 16, 4), (48, 4, 16, 4), (5, 2, 8, 4), (3, 1, 32, 4), (8, 4, 16, 1), (48, 4, 16, 1)])
+def test_msda_cross_training_matches_per_camera_autograd(hip, P, L, D, cams):
     """MSDACrossFunction (camera loop, fused prologue, both directions) == mean over the visible cameras of
     the plain op under torch autograd: output and gradients w.r.t. value, raw offsets, raw logits."""
     from selfocc_amd.msda import MSDACrossFunction, msda_fused_supported
@@ -205,7 +207,7 @@ def test_msda_cross_training_matches_per_camera_autograd(hip, P, L, D):
     shapes = torch.tensor([[24, 50], [12, 25], [6, 13], [3, 7]][:L])
     starts = torch.cat([torch.zeros(1, dtype=torch.int64), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
     nv = int((shapes[:, 0] * shapes[:, 1]).sum())
-    cams, nq, H = 4, 260, 3
+    nq, H = 260, 3             # cams = 1: the mono KITTI configs
     host = [int(v) for v in shapes.reshape(-1)]
     assert msda_fused_supported(host, cams, nq, H, D, L, P)
     d = torch.device("cuda:0")
