@@ -129,7 +129,7 @@ def _render_chunk(mapping, vol, n_rgb, n_sem, o, d, dn, cfg, t_rand, bkgd_rays, 
         sm = torch.softmax(h[:, 1 + n_rgb:], dim=-1).reshape(-1, S, n_sem)
         out['sem'] = (weights[..., None] * sm).sum(-2)
     if return_samples:
-        out.update(weights=weights, ts=ts, deltas=dz, sdf=sdf, grad=grad)
+        out.update(weights=weights, ts=ts, deltas=dz, sdf=sdf, grad=grad, starts=starts, ends=ends)
     return out
 
 

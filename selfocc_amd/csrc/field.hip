@@ -533,12 +533,9 @@ extern "C" int selfocc_field_volume_fwd(const float *hw, const float *zh, const 
     hipStream_t st = (hipStream_t)stream;
 #define SO_LAUNCH(CC, BF)                                                                                    \
     {                                                                                                        \
-        static bool attr_set = false;                                                                        \
-        if (!attr_set) {                                                                                     \
-            (void)hipFuncSetAttribute((const void *)field_volume_kernel<CC, BF>,                             \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);         \
-            attr_set = true;                                                                                 \
-        }                                                                                                    \
+        /* per launch: the attribute is per device (a process may drive several GPUs) */                     \
+        (void)hipFuncSetAttribute((const void *)field_volume_kernel<CC, BF>,                                 \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);             \
         hipLaunchKernelGGL((field_volume_kernel<CC, BF>), dim3(blocks), dim3(nw * 64), shm, st, a);             \
     }
     const bool bf = feat_dtype == SO_DTYPE_BF16;
@@ -569,12 +566,9 @@ extern "C" int selfocc_field_volume_bwd(const float *hw, const float *zh, const 
     FieldBwdArgs a{hw, zh, wz, H, W, D, w_hidden, b_hidden, w_out, out_dim, g_sdf, g_feat, feat_stride,
                    g_hw, g_zh, g_wz, g_w_hidden, g_b_hidden, g_w_out, g_b_out, M, (int)((M + 31) / 32)};
     const size_t shm = ((size_t)kFB_C * kFB_LD + 32 * kFB_LD + (size_t)kFB_WAVES * 2 * 32 * kFB_TS) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute((const void *)field_volume_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  160 * 1024 - 256);
-        attr_set = true;
-    }
+    // per launch: the attribute is per device (a process may drive several GPUs)
+    (void)hipFuncSetAttribute((const void *)field_volume_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024 - 256);
     const int blocks = std::min((a.n_tiles + kFB_WAVES - 1) / kFB_WAVES, 256);
     hipLaunchKernelGGL(field_volume_bwd_kernel, dim3(blocks), dim3(kFB_WAVES * 64), shm, (hipStream_t)stream, a);
     return so_launch_status();

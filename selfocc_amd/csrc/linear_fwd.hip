@@ -320,12 +320,11 @@ static int so_linear_fwd_launch(const float *x, const float *w, const float *bia
         const long long nblk = groups * a.ncb;
 #define SO_L16_1(KQ_, LN_, NT_)                                                                                       \
     do {                                                                                                             \
-        static bool attr_set = false;                                                                                \
-        if (!attr_set && lds_blk > 48 * 1024) {                                                                      \
+        /* per launch, not once per process: the attribute is per device, and a second GPU in the same process */    \
+        /* would otherwise launch without it (cheap: no driver round trip after the first call on a device)      */    \
+        if (lds_blk > 48 * 1024)                                                                                     \
             (void)hipFuncSetAttribute((const void *)linear_fwd16_kernel<KQ_, LN_, NT_, 4>,                           \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_blk);                     \
-            attr_set = true;                                                                                         \
-        }                                                                                                            \
         hipLaunchKernelGGL((linear_fwd16_kernel<KQ_, LN_, NT_, 4>), dim3((unsigned)nblk), dim3(256), lds_blk, st, a); \
     } while (0)
 #define SO_L16_2(KQ_, LN_)                                                                                            \

@@ -1773,12 +1773,9 @@ int so_band_scatter(const int32_t *shapes, const int32_t *starts, const float *g
     // the grid is an upper bound (every point in two bands): blocks past item0[nb] return at once
 #define SO_LAUNCH_T(DD, TT)                                                                                      \
     {                                                                                                            \
-        static bool attr_set = false;                                                                            \
-        if (!attr_set) {                                                                                         \
-            (void)hipFuncSetAttribute((const void *)msda_bwd_band_list_kernel<DD, TT>,                           \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, band_tile_bytes(TT));          \
-            attr_set = true;                                                                                     \
-        }                                                                                                        \
+        /* per launch: the attribute is per device (a process may drive several GPUs) */                         \
+        (void)hipFuncSetAttribute((const void *)msda_bwd_band_list_kernel<DD, TT>,                               \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, band_tile_bytes(TT));              \
         hipLaunchKernelGGL((msda_bwd_band_list_kernel<DD, TT>), dim3((unsigned)max_items), dim3(TT), shm, st,    \
                            shapes, starts, g_out, g_value, w.recs, cnt, off, item0, w.list, nb, dm, bp);         \
     }

@@ -53,6 +53,7 @@ def _point_sampling_hip(reference_points, lidar2img, img_metas):
     return cam, mask
 
 
+@torch.autocast("cuda", enabled=False)
 def point_sampling(reference_points, img_metas):
     """Project 3-D reference points (B, D, Q, 3) into every camera.
     Returns reference_points_cam (N, B, Q, D, 2) in [0,1] image coordinates and the

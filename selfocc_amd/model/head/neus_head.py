@@ -435,7 +435,9 @@ class NeuSHead(BaseModule):
         the unit SDF gradients along each ray, mapped to [0, 1].  Per-sample weights / gradients come from the
         sample-parallel kernel in row-block chunks of ~``chunk_rays`` rays (the reference's README-sized batches), so
         no (R, S, 3) tensor of the whole frame ever exists."""
+        import dataclasses
         from ... import dist as sdist
+        cfg = dataclasses.replace(cfg, bkgd_mode=abi.BKGD_NONE)       # weights / gradients only: no per-ray background needed
         n_chunks = max(1, -(-rays.n_rays // chunk_rays))
         if rays.pixel_grid:
             n_chunks = min(n_chunks, rays.ny)

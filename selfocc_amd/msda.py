@@ -99,9 +99,15 @@ def _i32(t, device):
     constants go through 16 MSDA calls per frame and each conversion is a kernel launch."""
     if t.dtype == torch.int32 and t.device == device and t.is_contiguous():
         return t
+    if t.is_inference():
+        # inference tensors carry no version counter (reading ``_version`` raises): they cannot be written in place
+        # outside inference mode either, so the object identity is the cache key
+        ver = -1
+    else:
+        ver = t._version
     c = getattr(t, '_so_i32', None)
-    if c is None or c[0] != t._version or c[1].device != device:
-        c = (t._version, t.to(device=device, dtype=torch.int32).contiguous())
+    if c is None or c[0] != ver or c[1].device != device:
+        c = (ver, t.to(device=device, dtype=torch.int32).contiguous())
         try:
             t._so_i32 = c
         except AttributeError:

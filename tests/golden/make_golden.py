@@ -634,6 +634,280 @@ def golden_bev_encoder(REG):
         json.dump(dict(encoder=cfg, lifter=dict(bev_h=H, bev_w=W, dim=dim), img_shape=[48, 80]), f, indent=1)
 
 
+def install_nerfstudio_stubs():
+    """Stand-ins for the absent sdfstudio fork (`nerfstudio.*`, docs/installation.md:28-39) so that the REAL
+    model/head/neus_head/neus_head.py can be imported and run.  ``NeuSCustomModel.__call__`` /
+    ``pre_compute_density_color`` / ``forward_geonetwork`` / ``forward_sdfnetwork`` are served by the declared
+    restatement in oracle/torch_port.py (render_port, field_lookup) over the authors' own in-repo field BEVNeRF
+    (model/head/nerfacc_head/bev_nerf.py); what the fixture pins is therefore everything neus_head.py itself does —
+    ray construction, ts / deltas / max-depth post-math, get_uniform_sdf, forward_occ, two-split, dict assembly —
+    NOT the fork's internals (still "parity unpinned", oracle/oracle_render.c)."""
+    from oracle import torch_port as tp
+    bn = ref_import('model.head.nerfacc_head.bev_nerf')
+    DRAWS = {}          # random draws of the last call, replayed by the GPU test
+
+    class FieldHeadNames:
+        SDF = 'sdf'
+
+    class SceneBox:
+        def __init__(self, aabb, near=None, far=None, collider_type=None, **kw):
+            self.aabb, self.near, self.far, self.collider_type = aabb, near, far, collider_type
+
+    class RayBundle:
+        def __init__(self, origins, directions, directions_norm=None, pixel_area=None, **kw):
+            self.origins, self.directions, self.directions_norm, self.pixel_area = origins, directions, directions_norm, pixel_area
+
+    class Frustums:
+        def __init__(self, origins, directions, starts, ends):
+            self.origins, self.directions, self.starts, self.ends = origins, directions, starts, ends
+
+        def get_positions(self):
+            return self.origins[:, None] + self.directions[:, None] * (self.starts + self.ends) / 2
+
+    class RaySamples:
+        def __init__(self, frustums):
+            self.frustums = frustums
+
+    class SDFCustomFieldConfig:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+    class Field(nn.Module):
+        def __init__(self, c):
+            super().__init__()
+            # colour + semantic logits share `color_dims` in NeuSHead configs (neus_head.py:284-288: h[..., 1:4] rgb, 4: sem)
+            self.net = bn.BEVNeRF(c.mapping_args, embed_dims=c.embed_dims, color_dims=c.color_dims, sem_dims=0,
+                                  density_layers=c.density_layers, sh_deg=c.sh_deg, sh_act=c.sh_act, tpv=c.tpv)
+            self.mapping = self.net.mapping
+            self.variance = nn.Parameter(c.beta_init * torch.ones(1), requires_grad=c.beta_learnable)
+            self.color_dims, self.return_sem = c.color_dims, c.return_sem
+            self.n_rgb = 3 if c.color_dims >= 3 else 0
+            self.n_sem = c.color_dims - 3 if c.color_dims > 3 else 0
+
+        def set_numerical_gradients_delta(self, delta):
+            self.delta = delta
+
+        def pre_compute_density_color(self, representation, **kw):
+            self.net.pre_compute_density_color(representation)
+
+        def forward_geonetwork(self, xyz):
+            return tp.field_lookup(self.mapping, self.net.density_color, xyz.reshape(-1, 3))
+
+        def forward_sdfnetwork(self, xyz):
+            return self.forward_geonetwork(xyz)[:, 0]
+
+        def inv_s(self):
+            return torch.exp(self.variance * 10.0).clip(1e-6, 1e6)
+
+    class Model(nn.Module):
+        def __init__(self, cfg, scene_box):
+            super().__init__()
+            self.cfg, self.scene_box = cfg, scene_box
+            self.field = Field(cfg.sdf_field)
+
+        def forward(self, ray_bundle, iter=None):
+            c, f = self.cfg, self.field
+            o, d, dn = ray_bundle.origins, ray_bundle.directions, ray_bundle.directions_norm[:, 0]
+            N = o.shape[0]
+            bk = {'white': (1, (1., 1., 1.)), 'black': (1, (0., 0., 0.)), 'random': (2, (0., 0., 0.))}[c.background_color]
+            rc = types.SimpleNamespace(aabb=self.scene_box.aabb.flatten().tolist(), n_samples=c.num_samples, near_plane=c.near_plane,
+                                       sample_pos=0, inv_s=float(f.inv_s()), depth_div_norm=True, bkgd_mode=bk[0], bkgd=bk[1],
+                                       clamp_rgb=not self.training)
+            t_rand = torch.rand(N) if (self.training and c.perturb) else None
+            bkr = torch.rand(N, 3) if bk[0] == 2 else None
+            if t_rand is not None:
+                DRAWS['t_rand'] = t_rand
+            if bkr is not None:
+                DRAWS.setdefault('bkgd', []).append(bkr)
+            with torch.no_grad():
+                r = tp.render_port(f.mapping, f.net.density_color.detach(), f.n_rgb, f.n_sem if c.return_sem else 0, o, d, dn, rc,
+                                   t_rand=t_rand, bkgd_rays=bkr, return_samples=True)
+            g = r['grad']
+            normal = (r['weights'][..., None] * (g / g.norm(dim=-1, keepdim=True).clamp_min(1e-12))).sum(1)
+            out = {'rgb': r['rgb'] if 'rgb' in r else o.new_zeros(N, 0), 'accumulation': r['acc'][:, None],
+                   'depth': r['depth'][:, None], 'fars': r['fars'][:, None], 'weights': r['weights'][..., None],
+                   'normal_vis': (normal + 1.0) / 2.0, 'inv_s': rc.inv_s,
+                   'ray_samples': RaySamples(Frustums(o, d, r['starts'][..., None], r['ends'][..., None])),
+                   'field_outputs': {FieldHeadNames.SDF: r['sdf'][..., None]},
+                   'eik_grad': g.reshape(-1, 3)}
+            if 'sem' in r:
+                out['sem'] = r['sem']
+            if c.sdf_field.second_derivative:
+                s = f.net.density_color[0, 0]
+                out['field_outputs']['second_grad'] = torch.cat([
+                    (s[2:] - 2 * s[1:-1] + s[:-2]).flatten(), (s[:, 2:] - 2 * s[:, 1:-1] + s[:, :-2]).flatten(),
+                    (s[:, :, 2:] - 2 * s[:, :, 1:-1] + s[:, :, :-2]).flatten()])
+            return out
+
+    class NeuSCustomModelConfig:
+        def __init__(self, **kw):
+            self.__dict__.update(kw)
+
+        def setup(self, scene_box=None, num_train_data=0, **kw):
+            return Model(self, scene_box)
+
+    _mod('nerfstudio'); _mod('nerfstudio.models'); _mod('nerfstudio.fields'); _mod('nerfstudio.data')
+    _mod('nerfstudio.cameras'); _mod('nerfstudio.field_components')
+    _mod('nerfstudio.models.neus_custom', NeuSCustomModelConfig=NeuSCustomModelConfig)
+    _mod('nerfstudio.fields.sdf_custom_field', SDFCustomFieldConfig=SDFCustomFieldConfig)
+    _mod('nerfstudio.data.scene_box', SceneBox=SceneBox)
+    _mod('nerfstudio.cameras.rays', RayBundle=RayBundle)
+    _mod('nerfstudio.field_components.field_heads', FieldHeadNames=FieldHeadNames)
+    return DRAWS
+
+
+def _flatten_out(prefix, d, arrs):
+    """Every entry of a NeuSHead output dict -> npz arrays (lists get an index suffix; None is recorded as absent)."""
+    for k, v in d.items():
+        if v is None:
+            arrs[f'{prefix}.{k}.none'] = np.zeros(0)
+        elif isinstance(v, (list, tuple)):
+            arrs[f'{prefix}.{k}.len'] = np.array(len(v))
+            for i, t in enumerate(v):
+                arrs[f'{prefix}.{k}.{i}'] = t.detach().cpu().numpy()
+        else:
+            arrs[f'{prefix}.{k}'] = v.detach().cpu().numpy()
+
+
+def golden_head(REG):
+    """The REAL NeuSHead (model/head/neus_head/neus_head.py) over the nerfstudio stand-ins: forward (train: cellular
+    rays, two-split; eval: fixed rays), prepare + render (chunked and unchunked), forward_occ, for a TPV and a BEV
+    configuration.  Every key of every returned dict is saved together with the inputs, the state and the random draws."""
+    import json
+    if 'dataset' not in sys.modules:
+        ds = types.ModuleType('dataset'); ds.__path__ = [os.path.join(REF, 'dataset')]; sys.modules['dataset'] = ds
+    namespace('model.head.neus_head')
+    DRAWS = install_nerfstudio_stubs()
+    ref_import('model.head.base_head')
+    nh = ref_import('model.head.neus_head.neus_head')
+
+    def cams(n, seed, img=(64, 64), f=60.0):
+        rng = np.random.RandomState(seed)
+        Kinv = np.linalg.inv(np.array([[f, 0, img[1] / 2, 0], [0, f, img[0] / 2, 0], [0, 0, 1, 0], [0, 0, 0, 1]]))
+        out = []
+        for i in range(n):
+            yaw = 0.4 + 2 * np.pi * i / n + 0.1 * rng.randn()
+            c2w = np.eye(4)
+            c2w[:3, :3] = np.array([[np.sin(yaw), 0, np.cos(yaw)], [-np.cos(yaw), 0, np.sin(yaw)], [0, -1, 0]])
+            c2w[:3, 3] = [0.6 * rng.randn(), 0.6 * rng.randn(), 0.4 + 0.2 * rng.randn()]
+            out.append(c2w @ Kinv)
+        return np.stack(out)
+
+    cfgs = {
+        # TPV, colour + semantics, cellular training lattice, two-split (first half: depth cams, second half: temporal)
+        'tpv': dict(roi_aabb=[-12.8, -12.8, -1.0, 12.8, 12.8, 3.0], resolution=0.8, near_plane=0.0, far_plane=1e10,
+                    num_samples=32, num_samples_importance=0, num_up_sample_steps=0, base_variance=4, beta_init=0.25,
+                    beta_hand_tune=False, use_numerical_gradients=False, sample_gradient=True, return_uniform_sdf=True,
+                    return_second_grad=True, use_compact_2nd_grad=True, return_sem=True, return_max_depth=True,
+                    return_sample_sdf=True, ray_sample_mode='cellular', ray_number=[6, 10], ray_img_size=[64, 64],
+                    ray_upper_crop=4, trans_kw=['img2lidar', 'temImg2lidar'], render_bkgd='random',
+                    mapping_args=dict(nonlinear_mode='linear', h_size=[8, 0], h_range=[12.8, 0], h_half=False,
+                                      w_size=[8, 0], w_range=[12.8, 0], w_half=False, d_size=[11, 0], d_range=[-1.0, 3.0, 3.0]),
+                    embed_dims=96, color_dims=8, density_layers=2, sh_deg=0, sh_act='relu', two_split=True, tpv=True,
+                    print_freq=50),
+        # BEV, SDF only (the nuscenes_depth / kitti form), fixed lattice, single key with an eval key and a novel view
+        'bev': dict(roi_aabb=[-8.0, 0.0, -1.0, 8.0, 16.0, 3.0], resolution=0.5, near_plane=0.0, far_plane=1e10,
+                    num_samples=24, num_samples_importance=0, num_up_sample_steps=0, base_variance=4, beta_init=0.3,
+                    beta_hand_tune=False, use_numerical_gradients=False, sample_gradient=True, return_uniform_sdf=False,
+                    return_second_grad=False, return_sem=False, return_max_depth=True,
+                    ray_sample_mode='fixed', ray_number=[5, 8], ray_img_size=[48, 80],
+                    trans_kw='temImg2lidar', trans_kw_eval=['img2lidar'], novel_view=[0.3, -0.2, 0.1, 8.0], render_bkgd='white',
+                    mapping_args=dict(nonlinear_mode='linear', h_size=[32, 0], h_range=[16.0, 0], h_half=True,
+                                      w_size=[8, 0], w_range=[8.0, 0], w_half=False, d_size=[4, 0], d_range=[-1.0, 3.0, 3.0]),
+                    embed_dims=32, color_dims=0, density_layers=2, sh_deg=0, sh_act='relu', two_split=False, tpv=False),
+    }
+    arrs, meta_json = {}, {}
+    for tag, cfg in cfgs.items():
+        torch.manual_seed(21 if tag == 'tpv' else 22)
+        import copy
+        head = nh.NeuSHead(**copy.deepcopy(cfg))
+        f = head.model.field
+        with torch.no_grad():
+            f.net.density_net[-1].bias[0] = 0.4          # surfaces inside the box
+        H, W, D, C = f.mapping.size_h, f.mapping.size_w, f.mapping.size_d, cfg['embed_dims']
+        g = torch.Generator().manual_seed(5)
+        if cfg['tpv']:
+            rep = [torch.randn(1, H * W, C, generator=g), torch.randn(1, D * H, C, generator=g), torch.randn(1, W * D, C, generator=g)]
+        else:
+            rep = torch.randn(1, H * W, C, generator=g)
+        n_cams = 2
+        img = tuple(cfg['ray_img_size'])
+        c0, c1 = cams(n_cams, 1, img), cams(n_cams, 2, img)
+        if tag == 'bev':
+            c0[:, 1, 3] += 6.0; c1[:, 1, 3] += 6.0        # the KITTI-like box lies in front of the rig
+        metas = [dict(img2lidar=list(c0), temImg2lidar=list(c1))]
+        for k, v in to_np(head.state_dict()).items():
+            arrs[f'{tag}.sd.{k}'] = v
+        for i, r in enumerate(rep if cfg['tpv'] else [rep]):
+            arrs[f'{tag}.rep{i}'] = r.numpy()
+        arrs[f'{tag}.img2lidar'], arrs[f'{tag}.temImg2lidar'] = c0, c1
+        meta_json[tag] = cfg
+
+        # ---- train.py: head.forward in training mode (perturbed samples, cellular lattice drawn from numpy) ----
+        os.environ['eval'] = 'false'
+        head.train()
+        DRAWS.clear()
+        np.random.seed(77)
+        torch.manual_seed(100)
+        out = head(rep, metas, global_iter=7)
+        _flatten_out(f'{tag}.train', out, arrs)
+        arrs[f'{tag}.train.draw.t_rand'] = DRAWS['t_rand'].numpy()
+        if 'bkgd' in DRAWS:
+            arrs[f'{tag}.train.draw.bkgd'] = DRAWS['bkgd'][0].numpy()
+        if cfg['return_uniform_sdf']:
+            # the shift of get_uniform_sdf(shift=True) (neus_head.py:283-285) is the LAST torch.rand_like of the call:
+            # re-draw it from the recorded generator state by re-running the same sequence
+            torch.manual_seed(100)
+            N = out['origin'].shape[0]
+            torch.rand(N)
+            if 'bkgd' in DRAWS:
+                torch.rand(N, 3)
+            n = int(np.prod(out['uniform_sdf'].shape))
+            arrs[f'{tag}.train.draw.shift'] = torch.rand_like(torch.empty(n, 3)).numpy()
+
+        # ---- head.forward in eval mode (no perturbation; eval key / eval lattice) ----
+        os.environ['eval'] = 'true'
+        head.eval()
+        DRAWS.clear()
+        torch.manual_seed(101)
+        with torch.no_grad():
+            out = head(rep, metas)
+        _flatten_out(f'{tag}.evalfwd', out, arrs)
+        if 'bkgd' in DRAWS:
+            arrs[f'{tag}.evalfwd.draw.bkgd'] = DRAWS['bkgd'][0].numpy()
+        if cfg['return_uniform_sdf']:
+            torch.manual_seed(101)
+            N = out['origin'].shape[0]
+            if 'bkgd' in DRAWS:
+                torch.rand(N, 3)
+            n = int(np.prod(out['uniform_sdf'].shape))
+            arrs[f'{tag}.evalfwd.draw.shift'] = torch.rand_like(torch.empty(n, 3)).numpy()
+
+        # ---- eval_depth.py:165-166: prepare + render, unchunked and in chunks of 50 rays ----
+        for name, batch in (('render0', 0), ('render50', 50)):
+            DRAWS.clear()
+            torch.manual_seed(102)
+            with torch.no_grad():
+                head.prepare(rep, metas)
+                out = head.render(metas, batch=batch)
+            _flatten_out(f'{tag}.{name}', out, arrs)
+            if 'bkgd' in DRAWS:
+                arrs[f'{tag}.{name}.draw.bkgd'] = torch.cat(DRAWS['bkgd']).numpy()
+
+        # ---- eval_iou.py: forward_occ with its own aabb / resolution, and with the head's defaults ----
+        with torch.no_grad():
+            out = head.forward_occ(rep, metas, aabb=[-6.0, -5.0, -0.5, 6.0, 7.0, 2.5], resolution=0.5)
+            out.pop('rep')
+            _flatten_out(f'{tag}.occ', out, arrs)
+            out = head.forward_occ(rep, metas)
+            out.pop('rep')
+            _flatten_out(f'{tag}.occdef', out, arrs)
+        os.environ['eval'] = 'false'
+    save('head.npz', **arrs)
+    with open(os.path.join(HERE, 'head_cfg.json'), 'w') as fjs:
+        json.dump(meta_json, fjs, indent=1)
+
+
 if __name__ == '__main__':
     assert os.path.isdir(REF), f"{REF} not found: golden vectors can only be regenerated where the reference is mounted"
     sys.path.insert(0, REF)
@@ -644,7 +918,7 @@ if __name__ == '__main__':
     only = sys.argv[1:]          # e.g. `python make_golden.py bev_encoder` regenerates one fixture
     todo = dict(geometry=golden_geometry, losses=lambda: golden_losses(LOSS_REG), more=lambda: golden_more(LOSS_REG),
                 encoder=lambda: golden_encoder(REG), bev_encoder=lambda: golden_bev_encoder(REG),
-                segmentor=lambda: golden_segmentor(REG))
+                segmentor=lambda: golden_segmentor(REG), head=lambda: golden_head(REG))
     for name, fn in todo.items():
         if not only or name in only:
             fn()

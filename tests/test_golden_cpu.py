@@ -273,3 +273,42 @@ def test_our_stages_bind_the_reference_segmentor_keywords():
                 assert c is not None
                 sig = inspect.signature(getattr(c, call['method']))
                 sig.bind(None, **{k: None for k in call['kwargs']})     # raises TypeError if a keyword does not bind
+
+
+@pytest.mark.parametrize("tag,mode", [('tpv', 'train'), ('bev', 'train'), ('tpv', 'evalfwd'), ('bev', 'evalfwd')])
+def test_head_ray_construction_vs_reference_head(tag, mode):
+    """Host half of NeuSHead (no kernel involved): pixel lattice, origin / direction / direction_norm and the
+    get_uniform_sdf lattice exactly as the REAL neus_head.py built them (tests/golden/head.npz; :265-281, :508-527)."""
+    import copy
+    import json
+    from selfocc_amd.registry import MODELS
+    from selfocc_amd.occ import uniform_lattice
+    import selfocc_amd.model  # noqa: F401
+    z = np.load(os.path.join(G, "head.npz"))
+    cfg = json.load(open(os.path.join(G, "head_cfg.json")))[tag]
+    head = MODELS.build(dict(type='NeuSHead', **copy.deepcopy(cfg)))
+    metas = [dict(img2lidar=list(z[f'{tag}.img2lidar']), temImg2lidar=list(z[f'{tag}.temImg2lidar']))]
+    os.environ['eval'] = 'true' if mode == 'evalfwd' else 'false'
+    try:
+        np.random.seed(77)
+        rays, pix, num_cams, num_rays = head._rays(metas, torch.device('cpu'))
+        origin, direction = head.img2lidar(metas, pix)
+    finally:
+        os.environ['eval'] = 'false'
+    direction = direction.flatten(0, 2)
+    dn = torch.norm(direction, dim=-1, keepdim=True)
+    t = lambda k: torch.tensor(z[f'{tag}.{mode}.{k}'])
+    assert torch.allclose(pix, t('ms_rays'), rtol=1e-6, atol=1e-5)
+    assert torch.allclose(origin.unsqueeze(2).repeat(1, 1, num_rays, 1).flatten(0, 2), t('origin'), rtol=1e-6, atol=1e-6)
+    assert torch.allclose(direction / dn, t('direction'), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(dn, t('direction_norm'), rtol=1e-5, atol=1e-6)
+    assert num_cams * num_rays == t('origin').shape[0]
+    # the in-kernel lattice descriptor generates the same pixels
+    if rays.pixel_grid:
+        xs = torch.arange(rays.nx, dtype=torch.float32) * np.float32(rays.sx) + np.float32(rays.ox)
+        ys = torch.arange(rays.ny, dtype=torch.float32) * np.float32(rays.sy) + np.float32(rays.oy)
+        lat = torch.stack([xs[None].expand(rays.ny, -1), ys[:, None].expand(-1, rays.nx)], -1).flatten(0, 1)
+        assert torch.allclose(lat, t('ms_rays'), rtol=1e-6, atol=1e-4)
+    xyz = uniform_lattice([-6.0, -5.0, -0.5, 6.0, 7.0, 2.5], 0.5, 'cpu')
+    assert torch.equal(xyz, torch.tensor(z[f'{tag}.occ.xyz']))
+    assert torch.equal(uniform_lattice(cfg['roi_aabb'], cfg['resolution'], 'cpu'), torch.tensor(z[f'{tag}.occdef.xyz']))
