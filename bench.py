@@ -254,6 +254,15 @@ def main():
                   "depth_max_abs_all_rays_m": float(f"{(got['depth'] - ref['depth']).abs().max().item():.3e}"),
                   "acc_max_abs_all_rays": float(f"{(got['acc'] - ref['acc']).abs().max().item():.3e}"),
                   "excluded_rays": 0, "oracle_seconds": round(oracle_s, 2)}
+        low = ~ok
+        parity["low_acc_weighted_depth_err_over_far"] = float(
+            f"{((got['depth'] - ref['depth']).abs() * ref['acc'] / ref['fars'].clamp_min(1e-6))[low].max().item():.3e}") if low.any() else 0.0
+        parity["rule"] = ("acc > 0.05: |d - d_ref| < 1e-4 d_ref on every ray (parity_frac_1e-4 == 1); acc <= 0.05: "
+                          "|d - d_ref| acc_ref <= 1e-4 far; every ray: |acc - acc_ref| <= 1e-4 "
+                          "(tests/test_render_gpu.py::parity_report(strict=True) asserts the same rule)")
+        parity["rule_holds"] = bool(parity["parity_frac_1e-4"] == 1.0 and parity["depth_max_rel_acc_gt_0.05"] < 1e-4
+                                    and parity["low_acc_weighted_depth_err_over_far"] <= 1e-4
+                                    and parity["acc_max_abs_all_rays"] <= 1e-4)
         for k in ('rgb', 'sem'):
             if k in ref:
                 parity[k + "_max_abs_all_rays"] = float(f"{(got[k] - ref[k]).abs().max().item():.3e}")

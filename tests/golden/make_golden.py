@@ -95,10 +95,31 @@ def _mod(name, **attrs):
 
 def install_stubs():
     from oracle.torch_port import msda_port
-    from selfocc_amd.model import bricks          # vendor-equivalent FFN / LN (mmcv bricks are absent)
     REG = _Registry('reference_models')
     LOSS_REG = _Registry('reference_losses')
-    REG.register_module(module=bricks.FFN)
+
+    class FFN(_BaseModule):
+        """mmcv==2.0.1 mmcv/cnn/bricks/transformer.py FFN, restated from the published source (mmcv is absent; nothing
+        of selfocc_amd is imported here): [Linear, act, Dropout] x (num_fcs - 1), Linear, Dropout; identity + out."""
+        def __init__(self, embed_dims=256, feedforward_channels=1024, num_fcs=2, act_cfg=dict(type='ReLU', inplace=True),
+                     ffn_drop=0., dropout_layer=None, add_identity=True, init_cfg=None, **kwargs):
+            super().__init__(init_cfg)
+            assert num_fcs >= 2 and act_cfg['type'] == 'ReLU' and dropout_layer is None
+            layers, in_ch = [], embed_dims
+            for _ in range(num_fcs - 1):
+                layers.append(nn.Sequential(nn.Linear(in_ch, feedforward_channels), nn.ReLU(inplace=True), nn.Dropout(ffn_drop)))
+                in_ch = feedforward_channels
+            layers += [nn.Linear(feedforward_channels, embed_dims), nn.Dropout(ffn_drop)]
+            self.layers = nn.Sequential(*layers)
+            self.dropout_layer = nn.Identity()
+            self.add_identity = add_identity
+
+        def forward(self, x, identity=None):
+            out = self.layers(x)
+            if not self.add_identity:
+                return self.dropout_layer(out)
+            return (x if identity is None else identity) + self.dropout_layer(out)
+    REG.register_module(module=FFN)
 
     class MSDABase(_BaseModule):
         """parameter layout of mmcv MultiScaleDeformableAttention (forward is overridden by the
@@ -908,6 +929,121 @@ def golden_head(REG):
         json.dump(meta_json, fjs, indent=1)
 
 
+FULL_ENCODER = dict(dim=96, heads=6, cams=6, tpv=(25, 25, 7), fpn=((12, 25), (6, 13), (3, 7), (2, 4)), img_shape=(96, 200),
+                    seed_params=31, seed_lifter=32, seed_feats=33, seed_loss=34)
+
+
+def full_encoder_inputs(spec=FULL_ENCODER):
+    """Seeded inputs of the shipped-structure encoder fixture (shared with tests/test_golden_encoder_full_gpu.py, which
+    regenerates them instead of loading megabytes): FPN maps, camera matrices, loss direction per plane."""
+    g = torch.Generator().manual_seed(spec['seed_feats'])
+    feats = [torch.randn(1, spec['cams'], spec['dim'], h, w, generator=g) for h, w in spec['fpn']]
+    Hi, Wi = spec['img_shape']
+    f = Wi / 2 / np.tan(np.deg2rad(35.0))
+    l2i = []
+    for i in range(spec['cams']):
+        yaw = 0.3 + 2 * np.pi * i / spec['cams']
+        R = np.array([[np.sin(yaw), -np.cos(yaw), 0, 0.2 * np.cos(3 * i)], [0, 0, -1, 1.5], [np.cos(yaw), np.sin(yaw), 0, 0.3 * np.sin(2 * i)],
+                      [0, 0, 0, 1]])
+        K = np.array([[f, 0, Wi / 2, 0], [0, f, Hi / 2, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+        l2i.append(K @ R)
+    H, W, Z = spec['tpv']
+    g = torch.Generator().manual_seed(spec['seed_loss'])
+    loss_dirs = [torch.randn(1, n, spec['dim'], generator=g) for n in (H * W, Z * H, W * Z)]
+    return feats, np.stack(l2i), loss_dirs
+
+
+def full_encoder_cfg(spec=FULL_ENCODER):
+    """config/nuscenes/nuscenes_occ.py:190-301 with a reduced grid: 96 dims, 6 heads x 16, 6 cameras, 4 FPN levels,
+    num_points_cross = [48, 48, 8], num_points_self = 12, two of the four identical layers."""
+    dim, heads = spec['dim'], spec['heads']
+    H, W, Z = spec['tpv']
+    mapping_args = dict(nonlinear_mode='linear', h_size=[(H - 1) // 2, 0], h_range=[40.0, 0], h_half=False,
+                        w_size=[(W - 1) // 2, 0], w_range=[40.0, 0], w_half=False, d_size=[Z - 1, 0], d_range=[-1.0, 5.4, 5.4])
+    layer = dict(type='TPVFormerLayer',
+                 attn_cfgs=[dict(type='CrossViewHybridAttention', embed_dims=dim, num_heads=heads, num_levels=3,
+                                 num_points=12, dropout=0.1, batch_first=True),
+                            dict(type='TPVCrossAttention', embed_dims=dim, num_cams=spec['cams'], dropout=0.1, batch_first=True,
+                                 num_heads=heads, num_levels=4, num_points=[48, 48, 8])],
+                 feedforward_channels=2 * dim, ffn_dropout=0.1,
+                 operation_order=('self_attn', 'norm', 'cross_attn', 'norm', 'ffn', 'norm'))
+    return dict(mapping_args=mapping_args, embed_dims=dim, num_cams=spec['cams'], num_feature_levels=4,
+                positional_encoding=dict(type='TPVPositionalEncoding', num_freqs=[12] * 3, embed_dims=dim,
+                                         tot_range=[-40.0, -40.0, -1.0, 40.0, 40.0, 5.4]),
+                num_points_cross=[48, 48, 8], num_points_self=[12] * 3, transformerlayers=[layer, layer], num_layers=2)
+
+
+def golden_encoder_full(REG):
+    """The REAL TPVFormerEncoder at the SHIPPED structure (the kernel instantiations nuscenes_occ runs: <16,5|6> camera
+    loop, <16,3> self-attention, 6 x 16 head-major projections, pillar points that leave the image), forward planes AND
+    the reference's autograd gradients of a seeded scalar w.r.t. every parameter, the query planes and the four FPN maps.
+    Parameters / inputs are regenerated from seeds on the test side (tests/util.seeded_fill); stored: outputs, loss,
+    gradients (large ones as every 8th row + all row norms), checksums of the regenerated tensors."""
+    import copy
+    import json
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from util import seeded_fill, grad_digest
+    for p in ('model', 'model.encoder', 'model.encoder.bevformer', 'model.encoder.bevformer.attention',
+              'model.encoder.tpvformer', 'model.encoder.tpvformer.attention', 'model.encoder.tpvformer.modules',
+              'model.lifter'):
+        if p not in sys.modules:
+            namespace(p)
+    ica = ref_import('model.encoder.bevformer.attention.image_cross_attention')
+    sys.modules['model.encoder.bevformer.attention'].BEVCrossAttention = ica.BEVCrossAttention
+    sys.modules['model.encoder.bevformer.attention'].BEVDeformableAttention = ica.BEVDeformableAttention
+    cv = ref_import('model.encoder.tpvformer.attention.cross_view_hybrid_attention')
+    tca = ref_import('model.encoder.tpvformer.attention.image_cross_attention')
+    sys.modules['model.encoder.tpvformer.attention'].TPVCrossAttention = tca.TPVCrossAttention
+    sys.modules['model.encoder.tpvformer.attention'].CrossViewHybridAttention = cv.CrossViewHybridAttention
+    sys.modules['model.encoder.tpvformer.modules'].CameraAwareSE = object
+    ref_import('model.encoder.tpvformer.tpvformer_pos_embed')
+    ref_import('model.encoder.tpvformer.tpvformer_encoder_layer')
+    enc_mod = ref_import('model.encoder.tpvformer.tpvformer_encoder')
+    lift = ref_import('model.lifter.tpv_query_lifter')
+
+    spec = FULL_ENCODER
+    cfg = full_encoder_cfg(spec)
+    torch.manual_seed(0)
+    enc = enc_mod.TPVFormerEncoder(**copy.deepcopy(cfg))
+    enc.init_weights()
+    lifter = lift.TPVQueryLifter(*spec['tpv'], spec['dim'])
+    seeded_fill(enc, spec['seed_params'])
+    seeded_fill(lifter, spec['seed_lifter'])
+    enc.eval()                                            # dropout off, autograd on
+    feats, l2i, loss_dirs = full_encoder_inputs(spec)
+    feats = [f.requires_grad_(True) for f in feats]
+    metas = [dict(lidar2img=l2i, img_shape=spec['img_shape'])]
+    out = enc(lifter(feats)['representation'], ms_img_feats=feats, metas=metas)['representation']
+    loss = sum((o * d).sum() for o, d in zip(out, loss_dirs)) / sum(o.numel() for o in out)
+    names = [n for n, _ in enc.named_parameters()]
+    lnames = [n for n, _ in lifter.named_parameters()]
+    grads = torch.autograd.grad(loss, list(enc.parameters()) + list(lifter.parameters()) + feats)
+    arrs = dict(loss=loss.detach().numpy(), out_hw=out[0].detach().numpy(), out_zh=out[1].detach().numpy(),
+                out_wz=out[2].detach().numpy())
+    k = 0
+    for pref, ns in (('enc', names), ('lift', lnames), ('feat', [str(i) for i in range(len(feats))])):
+        for n in ns:
+            for kind, t in grad_digest(grads[k]).items():
+                arrs[f'grad.{pref}.{n}.{kind}'] = t.numpy()
+            k += 1
+    # checksums of what the test regenerates from the seeds
+    arrs['check.enc'] = np.array([sum(float(p.double().sum()) for p in enc.parameters()),
+                                  sum(float(p.double().abs().sum()) for p in enc.parameters())])
+    arrs['check.lift'] = np.array([sum(float(p.double().sum()) for p in lifter.parameters())])
+    arrs['check.feats'] = np.array([float(f.double().sum()) for f in feats])
+    arrs['lidar2img'] = l2i
+    # how many pillar points fall outside every image (the inside-point compaction / zero-padding paths are exercised)
+    bu = ref_import('model.encoder.bevformer.utils')
+    for nm in ('hw', 'zh', 'wz'):
+        _, mask = bu.point_sampling(getattr(enc, f'ref_3d_{nm}').unsqueeze(0).clone(), metas)
+        arrs[f'visible_frac.{nm}'] = np.array(float(mask.float().mean()))
+    save('encoder_full.npz', **arrs)
+    with open(os.path.join(HERE, 'encoder_full_cfg.json'), 'w') as fjs:
+        json.dump(dict(spec=spec, encoder=cfg, lifter=dict(tpv_h=spec['tpv'][0], tpv_w=spec['tpv'][1], tpv_z=spec['tpv'][2],
+                                                             dim=spec['dim'])), fjs, indent=1)
+    print('encoder_full: loss', float(loss), 'visible', {n: float(arrs[f'visible_frac.{n}']) for n in ('hw', 'zh', 'wz')})
+
+
 if __name__ == '__main__':
     assert os.path.isdir(REF), f"{REF} not found: golden vectors can only be regenerated where the reference is mounted"
     sys.path.insert(0, REF)
@@ -918,7 +1054,8 @@ if __name__ == '__main__':
     only = sys.argv[1:]          # e.g. `python make_golden.py bev_encoder` regenerates one fixture
     todo = dict(geometry=golden_geometry, losses=lambda: golden_losses(LOSS_REG), more=lambda: golden_more(LOSS_REG),
                 encoder=lambda: golden_encoder(REG), bev_encoder=lambda: golden_bev_encoder(REG),
-                segmentor=lambda: golden_segmentor(REG), head=lambda: golden_head(REG))
+                segmentor=lambda: golden_segmentor(REG), head=lambda: golden_head(REG),
+                encoder_full=lambda: golden_encoder_full(REG))
     for name, fn in todo.items():
         if not only or name in only:
             fn()

@@ -230,8 +230,9 @@ def test_head_major_value_projection_changes_nothing(hip, family):
         assert torch.allclose(g1[n], g0[n], rtol=1e-3, atol=1e-4 * scale), (n, (g1[n] - g0[n]).abs().max().item(), scale)
 
 
-def test_encoder_backward_runs(hip):
-    """autograd through the whole encoder (MSDA backward kernel underneath) gives finite grads"""
+def test_encoder_backward_camera_loop_vs_rebatch(hip):
+    """autograd through the whole encoder: finite gradients everywhere, and the camera-loop training path (default) gives
+    the gradients of the reference's re-batch route to 1e-4 of each tensor's scale"""
     from selfocc_amd.registry import MODELS
     import selfocc_amd.model  # noqa: F401
     enc_np = np.load(os.path.join(G, "encoder.npz"))
@@ -242,8 +243,14 @@ def test_encoder_backward_runs(hip):
     lifter = MODELS.build(dict(type='TPVQueryLifter', **cfg['lifter'])).to(D0)
     feats = [torch.tensor(enc_np['feat0']).to(D0).requires_grad_(True), torch.tensor(enc_np['feat1']).to(D0)]
     metas = [dict(lidar2img=enc_np['lidar2img'], img_shape=tuple(cfg['img_shape']))]
+    # a seeded linear functional of the planes: `o.square().mean()` after the closing LayerNorm is constant up to rounding,
+    # so its gradients are cancellation noise (the 5 - 8 % tolerance this test used to need)
+    gl = torch.Generator().manual_seed(12)
+    dirs = [torch.randn(o_shape, generator=gl).to(D0) for o_shape in ((1, 63, 32), (1, 27, 32), (1, 21, 32))]
+    scalar = lambda planes: sum((o * d).sum() for o, d in zip(planes, dirs))
     out = enc(lifter(feats)['representation'], ms_img_feats=feats, metas=metas)['representation']
-    sum(o.square().mean() for o in out).backward()
+    assert [tuple(o.shape) for o in out] == [tuple(d.shape) for d in dirs]
+    scalar(out).backward()
     assert torch.isfinite(feats[0].grad).all() and feats[0].grad.abs().sum() > 0
     for n, p in enc.named_parameters():
         assert p.grad is not None and torch.isfinite(p.grad).all(), n
@@ -257,14 +264,14 @@ def test_encoder_backward_runs(hip):
             m.camera_loop = False
     enc.zero_grad(); feats[0].grad = None
     out = enc(lifter(feats)['representation'], ms_img_feats=feats, metas=metas)['representation']
-    sum(o.square().mean() for o in out).backward()
-    # gradients here are ~1e-8 on activations of order 1 (LayerNorm / softmax cancellations): the two float32
-    # evaluation orders agree to a few per cent of each tensor's scale (measured 0.9 % / 2 %); the kernels
-    # themselves are checked at 1e-3 / 1e-4 in tests/test_msda_gpu.py
-    assert torch.allclose(feats[0].grad, g_feat, rtol=0, atol=5e-2 * g_feat.abs().max().item())
+    scalar(out).backward()
+    # two float32 evaluation orders of the same gradients: 1e-4 of each tensor's scale (both routes are pinned to the
+    # reference's own autograd at 2e-5 in tests/test_golden_encoder_full_gpu.py)
+    assert torch.allclose(feats[0].grad, g_feat, rtol=0, atol=1e-4 * g_feat.abs().max().item()), \
+        (feats[0].grad - g_feat).abs().max().item() / g_feat.abs().max().item()
     for n, p in enc.named_parameters():
         scale = max(g_loop[n].abs().max().item(), 1e-12)
-        assert torch.allclose(p.grad, g_loop[n], rtol=0, atol=8e-2 * scale), n
+        assert torch.allclose(p.grad, g_loop[n], rtol=0, atol=1e-4 * scale), (n, (p.grad - g_loop[n]).abs().max().item() / scale)
 
 
 # ---- tests/golden/more.npz + segmentor_protocol.json --------------------------------------------------------

@@ -122,3 +122,60 @@ def test_differentiable_port_matches_grid_sample_port():
                                       ex.dirs.double(), ex.dir_norm.double(), cfg, torch.tensor(15.0, dtype=torch.float64))
     for k in ('sdf', 'grad', 'weights', 'acc', 'rgb', 'sem'):
         assert torch.allclose(a[k].double(), b[k], rtol=2e-3, atol=2e-5), k
+
+
+def test_oracle_with_hand_filled_args_equals_marshalled_args():
+    """oracle.render_fwd fills `so_render_args` through the product's marshal_render_args, so a marshalling bug would be
+    invisible to a HIP-vs-oracle comparison (both sides read the same struct).  Here the struct is
+    filled field by field from raw tensors and plain numbers, following include/selfocc_hip.h only — the C oracle must
+    return the same bits either way; the torch port (explicit rays built here from the matrices, not by the product's
+    helpers) pins the meaning of the lattice fields."""
+    import ctypes as C
+    n_rgb, n_sem = 3, 5
+    vol = sy.make_volume("cfg1", n_rgb=n_rgb, n_sem=n_sem, seed=4)
+    rays = sy.make_rays("cfg1", seed=4)
+    cfg = sy.make_render_config("cfg1", inv_s=25.0, sample_pos=1, bkgd_mode=abi.BKGD_CONST, bkgd=(0.25, 0.5, 1.0),
+                                clamp_rgb=True, exact=True)
+    ref = oracle.render_fwd(vol, rays, cfg, per_sample=True, want_grad_samples=True)
+
+    a = abi.SoRenderArgs()
+    a.map = vol.mapping.to_abi()
+    sdf, feat, cams = vol.sdf.contiguous(), vol.feat.contiguous(), rays.img2lidar.contiguous().float()
+    a.sdf_vol, a.feat_vol = sdf.data_ptr(), feat.data_ptr()
+    a.feat_dtype, a.feat_stride, a.n_rgb, a.n_sem = 0, feat.shape[3], n_rgb, n_sem          # SO_DTYPE_F32 = 0
+    n_cams, ny, nx = cams.shape[0], rays.ny, rays.nx
+    N, S = n_cams * ny * nx, 32
+    a.ray_mode, a.n_rays = 1, N                                                              # SO_RAYS_PIXEL_GRID = 1
+    a.img2lidar, a.n_cams, a.nx, a.ny = cams.data_ptr(), n_cams, nx, ny
+    a.sx, a.sy, a.ox, a.oy = rays.sx, rays.sy, rays.ox, rays.oy
+    for i, v in enumerate(sy.CONFIGS["cfg1"]["aabb"]):
+        a.aabb[i] = v
+    a.near_plane, a.n_samples, a.sample_pos, a.jitter_mode = 0.0, S, 1, 0                    # SO_SAMPLE_AT_MID, no jitter
+    a.inv_s, a.bkgd_mode = 25.0, 1                                                           # SO_BKGD_CONST = 1
+    a.bkgd[0], a.bkgd[1], a.bkgd[2] = 0.25, 0.5, 1.0
+    a.flags = 1 | 2 | 4                                                                      # DEPTH_DIV_NORM | CLAMP_RGB | EXACT
+    shapes = dict(depth=(N,), acc=(N,), max_depth=(N,), nears=(N,), fars=(N,), rgb=(N, 3), sem=(N, n_sem),
+                  weights=(N, S), ts=(N, S), deltas=(N, S), sdf=(N, S), grad=(N, S, 3))
+    out = {k: torch.empty(*s) for k, s in shapes.items()}
+    for k, t in out.items():
+        setattr(a, k, t.data_ptr())
+    # the constants above are the header's (a drift between abi.py and these literals fails here, not silently)
+    assert (abi.DTYPE_F32, abi.RAYS_PIXEL_GRID, abi.SAMPLE_AT_MID, abi.JITTER_NONE, abi.BKGD_CONST) == (0, 1, 1, 0, 1)
+    assert (abi.FLAG_DEPTH_DIV_NORM, abi.FLAG_CLAMP_RGB, abi.FLAG_EXACT) == (1, 2, 4)
+    fn = oracle.lib().oracle_render_fwd
+    fn.restype, fn.argtypes = C.c_int, [C.POINTER(abi.SoRenderArgs)]
+    assert fn(a) == 0
+    for k in ref:
+        assert torch.equal(out[k], ref[k]), k
+    # meaning of the lattice fields: pixel (ix * sx + ox, iy * sy + oy) of camera c, row-major, cameras outermost
+    xs = torch.arange(nx, dtype=torch.float32) * rays.sx + rays.ox
+    ys = torch.arange(ny, dtype=torch.float32) * rays.sy + rays.oy
+    pix = torch.stack([xs[None].expand(ny, -1), ys[:, None].expand(-1, nx), torch.ones(ny, nx)], -1).reshape(-1, 3)
+    d = torch.einsum('cij,pj->cpi', cams[:, :3, :3], pix).reshape(-1, 3)
+    o = cams[:, None, :3, 3].expand(-1, ny * nx, -1).reshape(-1, 3)
+    dn = d.norm(dim=-1)
+    port = tp.render_port(vol.mapping, vol.to_reference_layout(), n_rgb, n_sem, o, d / dn[:, None], dn, cfg)
+    ok = port['acc'] > 0.05
+    assert torch.allclose(out['fars'], port['fars'], rtol=1e-5, atol=1e-5)
+    assert torch.allclose(out['depth'][ok], port['depth'][ok], rtol=1e-4, atol=1e-5)
+    assert torch.allclose(out['rgb'], port['rgb'], rtol=1e-4, atol=2e-5)

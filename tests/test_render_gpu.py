@@ -20,7 +20,7 @@ def _cmp(got, ref, keys=None, rtol=1e-4, atol=1e-6):
     return worst
 
 
-def parity_report(got, ref, label="", f64=None, min_frac=0.995, max_rel=2e-2, acc_abs=2e-3, depth_abs_over_far=5e-3):
+def parity_report(got, ref, label="", f64=None, min_frac=0.995, max_rel=2e-2, acc_abs=2e-3, depth_abs_over_far=5e-3, strict=True):
     """FAST mode (per-ray affine grid coordinates with canonical cell selection near voxel faces, hardware
     exp2 / rcp, cancellation-free alpha, free-space skipping) vs the float32 C oracle.  EVERY ray is compared —
     no class of rays is excluded.
@@ -35,7 +35,15 @@ def parity_report(got, ref, label="", f64=None, min_frac=0.995, max_rel=2e-2, ac
     Why a fraction and not 100 %: NeuS's alpha = (sig(a) - sig(b) + 1e-5) / (sig(a) + 1e-5) subtracts two
     sigmoids that agree to ~1e-5 in free space, so the float32 ORACLE carries ~6e-8 rounding noise on a 1e-5
     quantity per sample; `f64` (the same formulas in double) shows how far the oracle itself is from the exact
-    value — the report prints both distances.  Returns the measured fractions."""
+    value — the report prints both distances.  Returns the measured fractions.
+
+    ``strict`` (the default: every case at the benchmarked inv_s = 20 with the default face-safe fast path; the rule
+    bench.py prints as `parity.rule`; measured worst case over all of them — cfg1 / cfg2 full frame / cfg4 / cfg5:
+    depth_max_rel 4.3e-5, acc 5.3e-5, rgb 3.8e-5, sem 1.7e-5, weighted low-acc depth error 6.7e-7 far):
+      * acc > 0.05:  |depth - depth_ref| < 1e-4 * depth_ref on EVERY ray (fraction == 1.0);
+      * acc <= 0.05: |depth - depth_ref| * acc_ref <= 1e-4 * far (the depth of a ray that accumulates ~nothing is a
+        ratio of two rounding-noise sums; weighted by what the ray contributes to any loss or metric it is bounded);
+      * every ray:   |acc - acc_ref| <= 1e-4, rgb / sem within 1e-4 absolute."""
     g = {k: v.detach().cpu() for k, v in got.items()}
     ok = ref['acc'] > 0.05
     rel = (g['depth'] - ref['depth']).abs() / ref['depth'].abs().clamp_min(1e-6)
@@ -58,7 +66,17 @@ def parity_report(got, ref, label="", f64=None, min_frac=0.995, max_rel=2e-2, ac
         rep['oracle_f32_vs_f64_depth_max_rel'] = rel64[ok].max().item()
         relg = (g['depth'].double() - f64['depth']).abs() / f64['depth'].abs().clamp_min(1e-6)
         rep['hip_vs_f64_depth_frac_1e-4'] = (relg[ok] < 1e-4).float().mean().item()
+    low = ~ok
+    rep['low_acc_weighted_depth_err_over_far'] = (((g['depth'] - ref['depth']).abs() * ref['acc'] / ref['fars'].clamp_min(1e-6))[low].max().item()
+                                                  if low.any() else 0.0)
     print(f"\n[parity {label}] " + ", ".join(f"{k}={v:.6g}" for k, v in rep.items()))
+    if strict:
+        assert rep['depth_frac_1e-4'] == 1.0 and rep['depth_max_rel'] < 1e-4, rep
+        assert rep['low_acc_weighted_depth_err_over_far'] <= 1e-4, rep
+        assert rep['acc_max_abs'] <= 1e-4, rep
+        for k in ('rgb', 'sem'):
+            if k in ref:
+                assert rep[k + '_max_abs'] <= 1e-4, rep
     assert torch.allclose(g['nears'], ref['nears'], rtol=1e-6, atol=1e-5)
     assert torch.allclose(g['fars'], ref['fars'], rtol=1e-6, atol=1e-5)
     assert rep['depth_frac_1e-4'] >= min_frac, rep
@@ -77,7 +95,7 @@ def _cmp_fast(got, ref, vol=None, rays=None, cfg=None, entering=False, same_cell
     EVERY sample; with face_safe=False a sample within an ulp of a voxel face may use the neighbouring cell, which
     moves that ray — only the fractions are asserted then."""
     loose = {} if same_cells else dict(max_rel=1.0, acc_abs=1.0, depth_abs_over_far=1.0)
-    rep = parity_report(got, ref, label="cfg1" + ("-entering" if entering else "") + ("" if same_cells else "-no_face_safe"), **loose)
+    rep = parity_report(got, ref, label="cfg1" + ("-entering" if entering else "") + ("" if same_cells else "-no_face_safe"), strict=same_cells, **loose)
     g = {k: v.detach().cpu() for k, v in got.items()}
     if 'weights' in ref:
         d = (g['weights'] - ref['weights']).abs()
@@ -129,7 +147,7 @@ def test_cfg1_pixel_grid_vs_oracle(hip, n_rgb, n_sem, feat_dtype, sample_pos, ex
         _cmp(got_e, ref, keys=[k for k in per_ray if k in got_e])
     else:
         loose = {} if exact is False else dict(max_rel=1.0, acc_abs=1.0, depth_abs_over_far=1.0)
-        parity_report(got_e, ref, label=f"cfg1 eval launch {exact}", **loose)
+        parity_report(got_e, ref, label=f"cfg1 eval launch {exact}", strict=(exact is False), **loose)
         # A/B switch: per-sample outputs through the ray-per-lane kernels of this mode
         from dataclasses import replace
         got_l = render_rays(vol.to(d), rg, replace(cfg, ray_per_lane=True), per_sample=True, want_grad_samples=True)
@@ -190,7 +208,7 @@ def test_bench_config_full_frame_vs_oracle(hip, inv_s):
     # exponent, for the oracle as for the kernel (see the oracle-vs-float64 columns) — the absolute bounds on the
     # ill-conditioned rays scale with that, the 1e-4 fraction does not
     loose = dict(acc_abs=1e-2, depth_abs_over_far=5e-2) if inv_s > 500 else {}
-    rep = parity_report(got, ref, label=f"cfg2 full frame C=1 inv_s={inv_s:g}", f64=f64, min_frac=0.999, **loose)
+    rep = parity_report(got, ref, label=f"cfg2 full frame C=1 inv_s={inv_s:g}", f64=f64, min_frac=0.999, strict=(inv_s == 20.0), **loose)
     assert rep['n_rays'] == 6 * 450 * 800
     same = (got['max_depth'].cpu() - ref['max_depth']).abs() <= 1e-4 * ref['max_depth'].abs() + 1e-5
     assert same[ref['acc'] > 0.05].float().mean() > 0.99
