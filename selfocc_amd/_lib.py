@@ -57,3 +57,19 @@ def ptr(t):
 def current_stream(device):
     import torch
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def upload(arr, device, dtype=None):
+    """Host array (numpy / nested list: the per-frame camera matrices of the metas) -> device tensor WITHOUT a stream
+    synchronisation: staged through torch's caching pinned-memory allocator and copied with non_blocking=True (a plain
+    ``tensor.to(device)`` from pageable memory blocks the host until the stream has drained — SURVEY section 8 f-4).
+    CPU targets get an ordinary tensor."""
+    import numpy as np
+    import torch
+    t = torch.as_tensor(np.asarray(arr))
+    if dtype is not None:
+        t = t.to(dtype)
+    dev = torch.device(device)
+    if dev.type != 'cuda':
+        return t.to(dev)
+    return t.pin_memory().to(dev, non_blocking=True)

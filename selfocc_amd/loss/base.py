@@ -19,11 +19,15 @@ class BaseLoss(nn.Module):
 
 @OPENOCC_LOSS.register_module()
 class MultiLoss(nn.Module):
-    """Sum of the configured losses -> (total, {class name: float}) (loss/multi_loss.py:10-43).
-    ``sync_items=False`` keeps the per-loss values on the device (the reference
-    pays one ``.item()`` host sync per loss per iteration, multi_loss.py:33-41)."""
+    """Sum of the configured losses -> (total, {class name: value}) (loss/multi_loss.py:10-43).
 
-    def __init__(self, loss_cfgs, sync_items=True):
+    The reference pays one ``.item()`` host sync per loss per iteration (multi_loss.py:33-41) although train.py reads
+    the dict only on print iterations (``f'{loss_value:.5f}'``, train.py:255-263, every ``print_freq``).  Here the
+    values stay on the device by default — 0-dim tensors, which format, compare and convert like floats
+    (``format(t, '.5f')`` reads the value back at that moment, i.e. only when something is printed): SURVEY §8 f-4.
+    ``sync_items=True`` restores python floats."""
+
+    def __init__(self, loss_cfgs, sync_items=False):
         super().__init__()
         assert isinstance(loss_cfgs, list)
         self.num_losses = len(loss_cfgs)

@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .._lib import upload
 from ..registry import OPENOCC_LOSS
 from ..reproj import ReprojSampleFunction
 from .base import BaseLoss
@@ -85,7 +86,7 @@ class _ReprojBase(BaseLoss):
     def _transforms(self, metas, key, like, num_cams):
         vals = [m[key] for m in metas]
         if isinstance(vals[0], (np.ndarray, list)):
-            t = like.new_tensor(np.asarray(vals))
+            t = upload(np.asarray(vals), like.device, like.dtype)
         else:
             t = torch.stack(vals, dim=0).to(like)
         return t.reshape(-1, num_cams, 4, 4).float()

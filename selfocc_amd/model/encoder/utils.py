@@ -6,6 +6,8 @@ get_cross_view_ref_points <- model/encoder/tpvformer/utils.py:5-71
 import numpy as np
 import torch
 
+from ..._lib import upload
+
 
 _META_CACHE = {}
 
@@ -21,7 +23,7 @@ def _stack_meta(img_metas, key, like):
         hit = _META_CACHE.get(ck)
         if hit is not None:
             return hit
-        t = like.new_tensor(arr)
+        t = upload(arr, like.device, like.dtype)
         _META_CACHE.clear()                    # one frame at a time
         _META_CACHE[ck] = t
         return t
@@ -43,8 +45,8 @@ def _point_sampling_hip(reference_points, lidar2img, img_metas):
     visible = torch.empty(N, B, Q, device=dev, dtype=torch.bool)
     fx = fy = None
     if 'focal_ratios_x' in img_metas[0]:
-        fx = torch.as_tensor(np.asarray(img_metas[0]['focal_ratios_x']), dtype=torch.float32).to(dev).contiguous()
-        fy = torch.as_tensor(np.asarray(img_metas[0]['focal_ratios_y']), dtype=torch.float32).to(dev).contiguous()
+        fx = upload(img_metas[0]['focal_ratios_x'], dev, torch.float32).contiguous()
+        fy = upload(img_metas[0]['focal_ratios_y'], dev, torch.float32).contiguous()
         assert fx.numel() == N and fy.numel() == N
     h, w = img_metas[0]['img_shape'][0], img_metas[0]['img_shape'][1]
     check(lib().selfocc_point_sampling(ptr(ref), ptr(l2i), ptr(fx), ptr(fy), ptr(cam), ptr(mask), ptr(visible), B, D, Q, N,

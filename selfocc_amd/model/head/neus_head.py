@@ -23,6 +23,7 @@ import torch.distributed as dist
 import torch.nn as nn
 
 from ... import abi
+from ..._lib import upload
 from ...mapping import GridMeterMapping
 from ...occ import field_query, field_query_autograd, uniform_lattice
 from ...field import field_volume, field_volume_supported, field_volume_train_supported, FieldVolumeFunction
@@ -113,18 +114,18 @@ class Img2LiDAR(nn.Module):
             for key in keys:
                 temp.extend(meta[key])
             if isinstance(temp[0], (np.ndarray, list)):
-                mats.append(torch.as_tensor(np.asarray(temp), dtype=torch.float32))
+                mats.append(np.asarray(temp, dtype=np.float32))
             else:
-                mats.append(torch.stack(temp, dim=0).float().cpu())
-        M = torch.stack(mats, 0).to(device)                       # B, N, 4, 4
-        if self.novel_view is not None:
-            rot = M.new_tensor(get_rm(self.novel_view[3], 'z', True))
+                mats.append(torch.stack(temp, dim=0).float().cpu().numpy())
+        M = torch.from_numpy(np.stack(mats, 0))                   # B, N, 4, 4 (host)
+        if self.novel_view is not None:                          # the same float32 torch ops as img2lidar.py:50-57, on the
+            rot = M.new_tensor(get_rm(self.novel_view[3], 'z', True))      # 96 host floats instead of on the device
             M = M.clone()
             M[..., :3, :3] = rot[None, None] @ M[..., :3, :3]
             M[..., 0, 3] += self.novel_view[0]
             M[..., 1, 3] += self.novel_view[1]
             M[..., 2, 3] += self.novel_view[2]
-        return M
+        return upload(M, device, torch.float32)                  # pinned staging + non_blocking copy: no stream sync
 
     def forward(self, metas, rays):
         M = self.matrices(metas, rays.device)
