@@ -134,6 +134,25 @@ SO_DEVFN so_u2v so_bload2u(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned sof
     return __builtin_bit_cast(so_u2v, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
 }
 
+// so_gather_sdf (zero padding outside the volume) on buffer loads: one 32-bit lane offset per (h, w) column instead of a
+// 64-bit address pair — the rare paths of the SDF-only marcher use it, where the four address pairs were what set the
+// kernel's register peak (75 -> 70 VGPRs: 7 waves / SIMD instead of 6)
+SO_DEVFN void so_gather_sdf_buf(__amdgpu_buffer_rsrc_t rs, int H, int W, int D, int h0, int w0, int d0, float v[8]) {
+    const int d0c = min(max(d0, 0), D - 2);
+    const bool dlo_in = (unsigned)d0 < (unsigned)D, dhi_in = (unsigned)(d0 + 1) < (unsigned)D;
+    const bool lo_first = (d0 == d0c), hi_first = (d0 + 1 == d0c);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int h = h0 + (q >> 1), w = w0 + (q & 1);
+        const bool in = ((unsigned)h < (unsigned)H) && ((unsigned)w < (unsigned)W);
+        const int hc = min(max(h, 0), H - 1), wc = min(max(w, 0), W - 1);
+        const so_f2v pr = so_bload2(rs, (unsigned)((hc * W + wc) * D + d0c) * 4u, 0u);
+        const float lo = lo_first ? pr.x : pr.y, hi = hi_first ? pr.x : pr.y;
+        v[2 * q] = (in && dlo_in) ? lo : 0.0f;
+        v[2 * q + 1] = (in && dhi_in) ? hi : 0.0f;
+    }
+}
+
 // all 8 corners in range (wave-uniform precondition): 8 uniform corner bases + one lane offset
 template <int NF, bool BF16>
 SO_DEVFN void so_gather_feat_interior(__amdgpu_buffer_rsrc_t rf, int W, int D, unsigned cell,
@@ -840,7 +859,8 @@ struct AheadStep {
 };
 
 template <bool FACE_SAFE, class GeomFn>
-SO_DEVFN void so_march_fast_ahead(const so_render_args &a, int ray, GeomFn geom) {
+SO_DEVFN void so_march_fast_ahead(const so_render_args &a, int ray, GeomFn geom, float *lds = nullptr, int lane = 0,
+                                   bool store = true) {
     const int H = a.map.h.tot_len, W = a.map.w.tot_len, D = a.map.d.tot_len;
     const int S = a.n_samples;
     const RayGeom g = geom(a);
@@ -859,6 +879,11 @@ SO_DEVFN void so_march_fast_ahead(const so_render_args &a, int ray, GeomFn geom)
     const float *__restrict__ vol = a.sdf_vol;
     const unsigned n_cells = (unsigned)(H * W * D);
     const __amdgpu_buffer_rsrc_t rb = so_make_rsrc(a.sdf_brick, (size_t)n_cells * 33);
+    const __amdgpu_buffer_rsrc_t rs = so_make_rsrc(vol, (size_t)n_cells * 4);
+#ifdef SO_AHEAD_LDS
+    // A/B: the wave's 4x4x4 corner block through LDS instead of two 16-B record gathers per lane
+    const unsigned lane_vox = (unsigned)(((lane >> 4) * W + ((lane >> 2) & 3)) * D + (lane & 3));
+#endif
     const int rcode = max((int)ceilf(dt / so_skip_unit(a.aabb, S)), 1);
     const int maxdim = max(H, max(W, D));
     const float face_m = 3.0f * 1.1920929e-7f * (float)(1u << (32 - __builtin_clz((unsigned)maxdim)));
@@ -908,19 +933,35 @@ SO_DEVFN void so_march_fast_ahead(const so_render_args &a, int ray, GeomFn geom)
             float v[8];
             float fh = cur.fh, fw = cur.fw, fd = cur.fd;
             if (cur.all_interior) {
+#ifdef SO_AHEAD_LDS
+                int hmin, wmin, dmin;
+                const bool boxed = lds != nullptr && so_stage_box(cur.h0, cur.w0, cur.d0, H, W, D, hmin, wmin, dmin) &&
+                                   hmin + 3 < H && wmin + 3 < W && dmin + 3 < D;
+                if (boxed) {      // lane <-> corner (lane >> 4, (lane >> 2) & 3, lane & 3) of the block: ONE dword load per lane
+                    const unsigned vo = ((unsigned)((hmin * W + wmin) * D + dmin) + lane_vox) * 4u;
+                    lds[lane] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, 0u, 0));
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const float *p0 = lds + (((cur.h0 - hmin) * 4 + (cur.w0 - wmin)) * 4 + (cur.d0 - dmin));
+                    v[0] = p0[0]; v[1] = p0[1]; v[2] = p0[4]; v[3] = p0[5]; v[4] = p0[16]; v[5] = p0[17]; v[6] = p0[20]; v[7] = p0[21];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                } else
+#endif
+                {
                 const so_f4v lo = so_bload4(rb, cur.cell * 32u, 0u), hi = so_bload4(rb, cur.cell * 32u + 16u, 0u);
                 v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+                }
             } else {
-                so_cell c;
-                c.h0 = cur.h0; c.w0 = cur.w0; c.d0 = cur.d0;
-                so_gather_sdf(vol, H, W, D, c, v);
+                so_gather_sdf_buf(rs, H, W, D, cur.h0, cur.w0, cur.d0, v);
             }
             if constexpr (FACE_SAFE) {
                 if (__any(near_face(fh, fw, fd))) {
                     if (near_face(fh, fw, fd)) {
                         const so_cell c = canon_cell(i);
                         if (c.h0 != cur.h0 || c.w0 != cur.w0 || c.d0 != cur.d0) {   // the canonical order lands next door
-                            so_gather_sdf(vol, H, W, D, c, v);
+                            so_gather_sdf_buf(rs, H, W, D, c.h0, c.w0, c.d0, v);
                             fh = c.fh1; fw = c.fw1; fd = c.fd1;
                         }
                     }
@@ -964,6 +1005,7 @@ SO_DEVFN void so_march_fast_ahead(const so_render_args &a, int ray, GeomFn geom)
     if (dt * inv_dn < eps32) best_t = tnear + hdt;
     float depth = dsum * so_fast_rcp(acc + 1e-10f);
     if (a.flags & SO_FLAG_DEPTH_DIV_NORM) depth = depth * inv_dn;
+    if (!store) return;
     if (a.depth) a.depth[ray] = depth;
     if (a.acc) a.acc[ray] = acc;
     if (a.max_depth) a.max_depth[ray] = best_t * inv_dn;
@@ -974,10 +1016,10 @@ SO_DEVFN void so_march_fast_ahead(const so_render_args &a, int ray, GeomFn geom)
 // MODE: 0 = canonical (EXACT), 1 = fast, 2 = fast with canonical cell selection near voxel faces,
 //       3 / 4 = the code-ahead skip marcher (SDF-only per-ray launches with brick + skip) without / with it
 template <int NF, bool BF16, bool PER_SAMPLE, int MODE, class GeomFn>
-SO_DEVFN void so_march(const so_render_args &a, int ray, GeomFn geom) {
+SO_DEVFN void so_march(const so_render_args &a, int ray, GeomFn geom, float *lds = nullptr, int lane = 0, bool store = true) {
     if constexpr (MODE >= 3) {
         static_assert(NF == 0 && !PER_SAMPLE, "skip marcher: SDF-only per-ray launches");
-        so_march_fast_ahead<MODE == 4>(a, ray, geom);
+        so_march_fast_ahead<MODE == 4>(a, ray, geom, lds, lane, store);
     } else if constexpr (MODE != 0) {
         so_march_fast<NF, BF16, PER_SAMPLE, false, MODE == 2>(a, ray, geom);
     } else {
@@ -1066,6 +1108,18 @@ __global__ __launch_bounds__(256, (NF >= 8 ? SO_WAVES_FEAT : 1)) void render_fwd
         auto geom = [&](const so_render_args &a) __attribute__((always_inline)) { return so_pixel_ray(a, cam, ix, iy); };
         so_march_fast<NF, BF16, PER_SAMPLE, true, MODE == 2>(a, ray, geom, real, s_stage + wave * StageGeom<NF>::kWaveDwords, lane);
     } else {
+#ifdef SO_AHEAD_LDS
+        if constexpr (MODE >= 3) {
+            // whole-wave LDS staging: lanes beyond the lattice edge shadow the nearest real pixel and skip the stores
+            __shared__ float s_box[4 * 64];
+            const bool real = (ix < a.nx) && (iy < a.ny);
+            ix = min(ix, a.nx - 1); iy = min(iy, a.ny - 1);
+            int ray = (cam * a.ny + iy) * a.nx + ix;
+            auto geom = [&](const so_render_args &a) __attribute__((always_inline)) { return so_pixel_ray(a, cam, ix, iy); };
+            so_march<NF, BF16, PER_SAMPLE, MODE>(a, ray, geom, s_box + wave * 64, lane, real);
+            return;
+        }
+#endif
         if (ix >= a.nx || iy >= a.ny) return;
         int ray = (cam * a.ny + iy) * a.nx + ix;
         auto geom = [&](const so_render_args &a) __attribute__((always_inline)) { return so_pixel_ray(a, cam, ix, iy); };

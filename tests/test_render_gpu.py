@@ -423,3 +423,4 @@ def test_device_inv_s_overrides_the_host_value(hip):
     b = render_rays(vol, small, stale, per_sample=True, want_grad_samples=True)
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
