@@ -10,7 +10,7 @@ mkdir -p _obj
 pids=()
 for s in $SRCS; do
   o=_obj/${s%.hip}.o
-  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ so_device.h -nt "$o" ] || [ ../../include/selfocc_hip.h -nt "$o" ]; then
+  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ -n "$(find . -maxdepth 1 -name "*.h" -newer "$o")" ] || [ ../../include/selfocc_hip.h -nt "$o" ]; then
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off \
       -fno-fast-math -Wall -Wno-unused-function -c "$s" -o "$o" &
     pids+=($!)

@@ -16,7 +16,8 @@ import torch.nn as nn
 from ...registry import MODELS, build_attention
 from ..bricks import (BaseModule, MultiScaleDeformableAttention, TallLinear, constant_init, xavier_init,
                       deformable_sampling, fused_linear)
-from ...msda import msda_cross_inference, MSDACrossFunction, msda_fused_supported, to_head_major
+from ...msda import (msda_cross_inference, MSDACrossFunction, msda_fused_supported, to_head_major, msda_pro_supported,
+                     msda_pro_inference)
 from .. import bricks
 
 
@@ -182,18 +183,25 @@ class BEVCrossAttention(BaseModule):
                 v = da.value_proj(vin.view(num_cams, l, self.embed_dims)).view(num_cams, l, heads, -1)
                 if hm:
                     v = to_head_major(v)
-        off = da.sampling_offsets(query[0]).view(-1, heads, L, P, 2)
-        logits = da.attention_weights(query[0]).view(-1, heads, L * P)
         vis_all = getattr(bev_masks, '_so_visible', None)                   # left by the HIP point_sampling
         visible = vis_all[:, 0] if vis_all is not None else bev_masks[:, 0].any(-1)   # (cams, Q), batch element 0 as the reference
-        if host_shapes is None:
-            if bricks.VALUE_BF16 and v.dtype != torch.bfloat16:
-                v = v.to(torch.bfloat16)
-            slots = msda_cross_inference(v, spatial_shapes, level_start_index, reference_points_cams[:, 0], visible,
-                                         off, logits, hm)[None]
+        if bricks.VALUE_BF16 and host_shapes is None and v.dtype != torch.bfloat16:
+            v = v.to(torch.bfloat16)
+        if (host_shapes is None and bricks.PROLOGUE_FUSED and query.dtype == torch.float32 and not torch.is_autocast_enabled()
+                and query.shape[1] >= bricks.PROLOGUE_MIN_ROWS and da.sampling_offsets.bias is not None
+                and da.attention_weights.bias is not None and msda_pro_supported(heads, v.shape[-1], L, P, query.shape[-1])):
+            # hw plane: the offset / weight linears run in the camera-loop kernel's prologue (csrc/msda_pro.hip)
+            slots = msda_pro_inference(v, spatial_shapes, level_start_index, reference_points_cams[:, 0], 1, query[0],
+                                       da.sampling_offsets, da.attention_weights, L, P, hm, visible=visible)[None]
         else:
-            slots = MSDACrossFunction.apply(v, spatial_shapes, level_start_index, reference_points_cams[:, 0], visible,
-                                            off, logits, host_shapes, hm, bricks.VALUE_BF16)[None]
+            off = da.sampling_offsets(query[0]).view(-1, heads, L, P, 2)
+            logits = da.attention_weights(query[0]).view(-1, heads, L * P)
+            if host_shapes is None:
+                slots = msda_cross_inference(v, spatial_shapes, level_start_index, reference_points_cams[:, 0], visible,
+                                             off, logits, hm)[None]
+            else:
+                slots = MSDACrossFunction.apply(v, spatial_shapes, level_start_index, reference_points_cams[:, 0], visible,
+                                                off, logits, host_shapes, hm, bricks.VALUE_BF16)[None]
         if not self.training and not torch.is_grad_enabled():
             # eval: dropout is the identity; output_proj + residual (+ the layer's next norm) in one launch, written
             # straight into the caller's slice of the concatenated plane buffer (`out`)

@@ -382,3 +382,57 @@ def test_msda_bf16_value_storage(hip, P, L, D):
         return v.grad, o.grad, lg.grad
     for x, y in zip(run_cross(True), run_cross(False)):
         assert torch.allclose(x, y, rtol=1e-5, atol=1e-5 * y.abs().max().item())
+
+
+@pytest.mark.parametrize("value_mode", ["pixel_major", "head_major", "bf16"])
+@pytest.mark.parametrize("form", ["cross_hw", "self"])
+def test_msda_prologue_fused_vs_separate_linears(hip, form, value_mode):
+    """selfocc_msda_pro_fwd (csrc/msda_pro.hip): the sampling_offsets / attention_weights Linears as an f32-MFMA prologue of
+    the sampling kernel == torch Linear (float64-checked) followed by the existing fused / camera-loop kernels, at the two
+    shipped shapes it serves (hw-plane camera loop: 6 cams, L = 4, P = 8; cross-view self-attention: L = 3, P = 12), with a
+    ragged last 16-query tile, invisible queries, points outside the maps."""
+    from selfocc_amd.msda import (msda_pro_inference, msda_pro_supported, msda_fused_inference, msda_cross_inference,
+                                  to_head_major)
+    d0 = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    heads, d, K = 6, 16, 96
+    if form == "cross_hw":
+        L, P, cams, nq = 4, 8, 6, 2093
+        shapes = torch.tensor([[24, 50], [12, 25], [6, 13], [3, 7]])
+    else:
+        L, P, cams, nq = 3, 12, 1, 1517
+        shapes = torch.tensor([[40, 40], [9, 40], [40, 9]])
+    assert msda_pro_supported(heads, d, L, P, K) and not msda_pro_supported(heads, d, 4, 48, K)
+    starts = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    nv = int((shapes[:, 0] * shapes[:, 1]).sum())
+    value = torch.randn(cams, nv, heads, d, generator=g).to(d0)
+    query = torch.randn(nq, K, generator=g).to(d0)
+    lin_off = torch.nn.Linear(K, heads * L * P * 2).to(d0)
+    lin_aw = torch.nn.Linear(K, heads * L * P).to(d0)
+    with torch.no_grad():
+        lin_off.weight.normal_(0, 0.3, generator=None); lin_off.bias.normal_(0, 2.0)
+        lin_aw.weight.normal_(0, 0.3); lin_aw.bias.normal_(0, 0.5)
+        off = lin_off(query.double().float()).view(nq, heads, L, P, 2)
+        off64 = (query.double() @ lin_off.weight.double().T + lin_off.bias.double()).view(nq, heads, L, P, 2)
+        assert (off - off64).abs().max() < 1e-4
+        logits = lin_aw(query).view(nq, heads, L * P)
+    v = value
+    hm = False
+    if value_mode == "head_major":
+        v, hm = to_head_major(value), True
+    elif value_mode == "bf16":
+        v = value.to(torch.bfloat16)
+    if form == "cross_hw":
+        ref = (torch.rand(cams, nq, P, 2, generator=g) * 1.3 - 0.15).to(d0)
+        vis = (torch.rand(cams, nq, generator=g) < 0.4).to(d0)
+        vis[:, :7] = False                                             # queries no camera sees
+        want = msda_cross_inference(v, shapes.to(d0), starts.to(d0), ref, vis, off, logits, hm)
+        got = msda_pro_inference(v, shapes.to(d0), starts.to(d0), ref, 1, query, lin_off, lin_aw, L, P, hm, visible=vis)
+    else:
+        ref = (torch.rand(1, nq, L, P, 2, generator=g) * 1.2 - 0.1).to(d0)
+        want = msda_fused_inference(v, shapes.to(d0), starts.to(d0), ref, 2, off[None], logits[None], hm)
+        got = msda_pro_inference(v, shapes.to(d0), starts.to(d0), ref, 2, query[None], lin_off, lin_aw, L, P, hm)
+    torch.cuda.synchronize()
+    assert got.shape == want.shape and torch.isfinite(got).all()
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() <= 2e-5 * scale, ((got - want).abs().max().item(), scale)
