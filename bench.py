@@ -175,7 +175,8 @@ def main():
         render_rays(vol, rays, cfg, outputs=out)
         e1.record()
     torch.cuda.synchronize()
-    kern_ms = sum(e0.elapsed_time(e1) for e0, e1 in evs) / len(evs)
+    per_launch = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+    kern_ms = sum(per_launch) / len(per_launch)
     alg_bytes, vol_bytes, per_ray_out = algorithmic_bytes(vol, n_rays, n_sem)
     achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
     touch_bytes = n_rays * cfg.n_samples * 8 * (4 + (0 if vol.feat is None else (n_rgb + n_sem) * vol.feat.element_size()))
@@ -183,7 +184,9 @@ def main():
         "bound": "hbm", "kernel": f"render_fwd_pixgrid<NF={vol.feat.shape[3] if vol.feat is not None else 0}>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 5),
         "traffic": None,  # rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE per launch: see profiles/ (filled by hand per round)
-        "kernel_ms": round(kern_ms, 4), "algorithmic_bytes": alg_bytes,
+        "kernel_ms": round(kern_ms, 4),
+        "kernel_ms_min_median_max": [round(per_launch[0], 4), round(per_launch[len(per_launch) // 2], 4), round(per_launch[-1], 4)],
+        "algorithmic_bytes": alg_bytes,
         "note": ("compulsory bytes = volume once + per-ray outputs; the march is gather/VALU bound "
                  "(volume <= 64 MB sits in L2 / Infinity Cache), touched bytes through L1 per launch = %d" % touch_bytes),
         "touch_GBps": round(touch_bytes / (kern_ms * 1e-3) / 1e9, 1),
@@ -390,9 +393,25 @@ def main():
         dist.barrier(); torch.cuda.synchronize()
         t2 = torch.tensor([time.perf_counter() - c0], device=dev, dtype=torch.float64)
         dist.all_reduce(t2, op=dist.ReduceOp.MAX)
-        strong = {"mode": "one frame split into row blocks over the ranks + all-reduce of the rendered-depth sum",
+        strong = {"expected_bound": ("launch + all-reduce latency: a whole frame is ~0.37 ms on one GPU, so a 1/N row block "
+                                     "(~0.37/N ms of kernel) sits next to ~10 us of launch and ~20-40 us of a small RCCL "
+                                     "all-reduce per step; do not expect linear strong scaling of a single frame"),
+                  "mode": "one frame split into row blocks over the ranks + all-reduce of the rendered-depth sum",
                   "rays_per_s": round(fr.n_rays * args.steps / t2.item(), 1),
                   "ms_per_frame": round(t2.item() / args.steps * 1e3, 4), "rays_per_rank": mine.n_rays}
+
+    # which devices / which backend actually ran (the driver can check N distinct GPUs under RCCL)
+    props = torch.cuda.get_device_properties(dev)
+    me = {"rank": rank, "device_index": dev_index, "name": props.name,
+          "uuid": str(getattr(props, "uuid", "")) or None, "pci_bus_id": getattr(props, "pci_bus_id", None)}
+    if world > 1:
+        seen = [None] * world
+        dist.all_gather_object(seen, me)
+        ranks_seen = {"backend": dist.get_backend(), "world_size": world, "ranks": seen,
+                      "distinct_devices": len({(r["uuid"], r["pci_bus_id"], r["device_index"]) for r in seen})}
+    else:
+        ranks_seen = {"backend": None, "world_size": 1, "ranks": [me], "distinct_devices": 1,
+                      "launched_by": "torchrun" if "RANK" in os.environ else "python"}
 
     if rank == 0:
         line = {
@@ -405,7 +424,7 @@ def main():
                        "rays_per_step_per_gpu": n_rays, "inv_s": args.inv_s, "preheat_steps": args.preheat,
                        "path": "exact" if args.exact else ("fast" + ("" if cfg.skip else ", no skip") + ("" if cfg.face_safe else ", no face_safe")),
                        "sharding": (f"one frame split by rows x{world}" if split else f"frame-per-rank x{world}")},
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "ranks_seen": ranks_seen,
         }
         if parity:
             line["parity"] = parity

@@ -357,15 +357,31 @@ class NeuSHead(BaseModule):
             raise NotImplementedError("ray_shard needs a lattice ray mode ('fixed' / 'cellular')")
         return True
 
-    def _agree_on_lattice(self, rays, pix):
-        """'cellular' lattices are drawn with numpy's generator on every rank: rank 0's draw wins."""
-        lat = torch.tensor([rays.sx, rays.sy, rays.ox, rays.oy], dtype=torch.float64,
-                           device=pix.device if dist.get_backend() == 'nccl' else 'cpu')   # RCCL moves device memory only
+    def _agree_on_lattice(self, rays, pix, vol=None):
+        """'cellular' lattices are drawn with numpy's generator on every rank: rank 0's draw wins.  The same
+        broadcast carries a fingerprint of rank 0's frame — the camera matrices and a strided sample of the SDF volume:
+        ray sharding splits ONE frame over the ranks, so a launch that feeds every rank its own
+        frame (the reference's DistributedSampler, dataset/__init__.py:86-87) would stitch row blocks of different
+        scenes together and sum gradients of unrelated volumes; that raises here instead."""
+        dev = pix.device if dist.get_backend() == 'nccl' else 'cpu'                         # RCCL moves device memory only
+        finger = [rays.img2lidar.double().sum().reshape(1), rays.img2lidar.double().abs().sum().reshape(1)]
+        if vol is not None:
+            flat = vol.sdf.detach().reshape(-1)
+            finger.append(flat[::max(1, flat.numel() // 4096)].double().sum().reshape(1))
+        mine = torch.cat([torch.tensor([rays.sx, rays.sy, rays.ox, rays.oy], dtype=torch.float64, device=pix.device)] +
+                         [f.to(pix.device) for f in finger]).to(dev)
+        lat = mine.clone()
         dist.broadcast(lat, 0)
-        sx, sy, ox, oy = (float(np.float32(v)) for v in lat.tolist())
+        same = torch.isclose(lat[4:], mine[4:], rtol=1e-6, atol=1e-9).all().to(torch.int32).reshape(1)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)          # every rank learns of a mismatch anywhere, so all raise together
+        if int(same.item()) == 0:
+            raise RuntimeError("NeuSHead(ray_shard=True): the ranks hold DIFFERENT frames (camera matrices / field volume differ "
+                               "from rank 0's). Ray sharding splits one frame over the ranks; feed every rank the same batch "
+                               "(no DistributedSampler) or turn ray_shard off for frame-per-GPU data parallelism.")
+        sx, sy, ox, oy = (float(np.float32(v)) for v in lat[:4].tolist())
         if (sx, sy, ox, oy) != (rays.sx, rays.sy, rays.ox, rays.oy):
             rays = RaySet(img2lidar=rays.img2lidar, nx=rays.nx, ny=rays.ny, sx=sx, sy=sy, ox=ox, oy=oy)
-            pix = RaySampler.pixels(rays.ny, rays.nx, *lat.tolist(), pix.device)
+            pix = RaySampler.pixels(rays.ny, rays.nx, *lat[:4].tolist(), pix.device)
         return rays, pix
 
     # ---- reference API -----------------------------------------------------------------
@@ -469,7 +485,7 @@ class NeuSHead(BaseModule):
             # the volume is replicated, the rays are split.  Each rank renders (and later
             # back-propagates) its row block; dL/d(volume) is summed over the ranks by ONE all-reduce.
             from ... import dist as sdist
-            rays, pix = self._agree_on_lattice(rays, pix)
+            rays, pix = self._agree_on_lattice(rays, pix, vol)
             full_rays, rays = rays, sdist.shard_rays(rays)
             vol = SDFVolume(vol.mapping, sdist.replicate_grad_sum(vol.sdf), sdist.replicate_grad_sum(vol.feat),
                             vol.n_rgb, vol.n_sem)

@@ -76,6 +76,17 @@ def _worker(rank, ws, port, ret):
             scale = a.abs().max().item()
             if (a - b).abs().max().item() > 1e-4 * scale + 1e-9:
                 msgs.append(f"param {n} grad: max diff {(a - b).abs().max().item():.3e} of {scale:.3e}")
+        # ---- guard: ray sharding splits ONE frame; ranks that were fed different frames must all raise ----
+        h = build(True).eval()
+        rep, metas, imgs = th.make_inputs()
+        if rank == 1:
+            metas[0]['temImg2lidar'] = np.array(metas[0]['temImg2lidar']) + 0.5
+        try:
+            h(rep, metas, global_iter=0)
+            msgs.append("different frames on the ranks did not raise")
+        except RuntimeError as e:
+            if "DIFFERENT frames" not in str(e):
+                raise
         ret[rank] = msgs
     except Exception as e:   # surface the failure in the parent
         import traceback
