@@ -11,10 +11,14 @@ with NO data-path collective:
   * train:             ``replicate_grad_sum`` marks the replicated field volume: identity in
                        forward, ONE all-reduce(sum) of dL/d(volume) in backward (the exchange step
                        of SURVEY §8e cfg3); every rank renders its row block and
-                       ``gather_rays_autograd`` rebuilds the full-frame per-ray / per-sample tensors
-                       the (lattice-shaped) losses consume — its backward hands each rank the slice
-                       of the gradient that belongs to its rays.  ``all_reduce_mean`` reports the
-                       global rendered-depth loss.
+                       ``gather_rays_autograd`` rebuilds the full-frame PER-RAY tensors the
+                       (lattice-shaped) losses consume — its backward hands each rank the slice of the
+                       gradient that belongs to its rays.  The PER-SAMPLE tensors (weights / ts / deltas /
+                       sdf / eik_grad: 206 MB at the shipped training size) stay local: the head hands
+                       them over as ``LocalRows`` / tagged tensors and the losses that consume them
+                       reduce them to per-ray terms on the local rows first (``loss/reproj.py``,
+                       ``EikonalLoss``), gathering 5 floats per ray instead.  ``all_reduce_mean`` reports
+                       the global rendered-depth loss.
 ``NeuSHead(ray_shard=True)`` (or SELFOCC_RAY_SHARD=1) switches the head to this mode; bench.py
 ``--shard rays`` times it.  The reference itself only has frame-per-GPU DDP (train.py:86-91).
 """
@@ -164,3 +168,58 @@ def replicate_grad_sum(t):
     if t is None or world()[1] == 1:
         return t
     return _GradSum.apply(t)
+
+
+class RayShard:
+    """What a loss needs to know about a ray-sharded head output: the UNSHARDED lattice, this rank's shard of it and
+    the pixel coordinates of the local rays (one camera's rows, shared by all cameras)."""
+
+    def __init__(self, full: RaySet, local: RaySet, pix_local):
+        self.full, self.local, self.pix_local = full, local, pix_local
+        self.rank, self.world_size = world()
+
+    @property
+    def rays_per_cam_local(self):
+        return self.local.nx * self.local.ny
+
+    @property
+    def rays_per_cam_full(self):
+        return self.full.nx * self.full.ny
+
+
+class LocalRows(list):
+    """Per-camera list of per-sample tensors that hold only THIS RANK's rows of the lattice (ray-sharded training).
+    Losses that declare ``supports_ray_shard`` reduce them to per-ray terms locally and gather those (``.shard``)."""
+
+    def __init__(self, items, shard: RayShard):
+        super().__init__(items)
+        self.shard = shard
+
+
+def tag_local(t, shard: RayShard):
+    """Mark a tensor as holding only this rank's samples (e.g. eik_grad)."""
+    t._so_shard = shard
+    return t
+
+
+def shard_of(x):
+    """The RayShard of a head output (LocalRows / tagged tensor), or None."""
+    if isinstance(x, LocalRows):
+        return x.shard
+    return getattr(x, '_so_shard', None)
+
+
+def global_value_local_grad(local):
+    """A per-rank partial sum whose parts add up to the loss term over ALL ranks: forward value = the global sum (what
+    gets logged / compared), backward = the local part only (each rank back-propagates its own samples; the replicated
+    volume's gradient is summed over the ranks by ``replicate_grad_sum``)."""
+    if world()[1] == 1:
+        return local
+    tot = local.detach().clone()
+    if tot.is_cuda and dist.get_backend() == 'gloo':
+        h = tot.cpu()
+        dist.all_reduce(h)
+        tot = h.to(local.device)
+    else:
+        dist.all_reduce(tot)
+    return local + (tot - local.detach())

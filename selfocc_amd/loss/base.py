@@ -13,8 +13,18 @@ class BaseLoss(nn.Module):
         self.loss_func = lambda: 0
         self.writer = None
 
+    supports_ray_shard = False      # True: the loss reduces LocalRows / tagged per-sample inputs locally (dist.py)
+
     def forward(self, inputs):
-        return self.weight * self.loss_func(**{arg: inputs[key] for arg, key in self.input_dict.items()})
+        args = {arg: inputs[key] for arg, key in self.input_dict.items()}
+        if not self.supports_ray_shard:
+            from ..dist import shard_of
+            for arg, v in args.items():
+                if shard_of(v) is not None:
+                    raise NotImplementedError(
+                        f"{type(self).__name__} received '{arg}' from a ray-sharded head (per-sample tensors of this rank's "
+                        f"rows only) but does not reduce them locally; run it with NeuSHead(ray_shard=False)")
+        return self.weight * self.loss_func(**args)
 
 
 @OPENOCC_LOSS.register_module()

@@ -68,6 +68,8 @@ _INVALID = torch.diag(torch.tensor([1.0, 1.0, -1.0, 1.0]))
 
 
 class _ReprojBase(BaseLoss):
+    supports_ray_shard = True
+
     def __init__(self, weight=1.0, input_dict=None, **kwargs):
         super().__init__(weight)
         self.input_dict = input_dict if input_dict is not None else {
@@ -90,6 +92,24 @@ class _ReprojBase(BaseLoss):
         else:
             t = torch.stack(vals, dim=0).to(like)
         return t.reshape(-1, num_cams, 4, 4).float()
+
+    @staticmethod
+    def _local_rows(shard, per_ray_full):
+        """rows of a full-lattice per-ray tensor (R, ...) of ONE camera that belong to this rank's block"""
+        from ..dist import row_block
+        r0, r1 = row_block(shard.full.ny, shard.rank, shard.world_size)
+        return per_ray_full.reshape(shard.full.ny, shard.full.nx, *per_ray_full.shape[1:])[r0:r1].reshape(
+            -1, *per_ray_full.shape[1:])
+
+    @staticmethod
+    def _gather_per_ray(shard, l1, comb, any_valid):
+        """(N, R_local), (N, R_local, 3), (N, R_local) of this rank's rows -> the full-lattice (N, R) / (N, R, 3) terms:
+        ONE all-gather of 5 floats per ray; its backward hands every rank the gradient of its own rows."""
+        from ..dist import gather_rays_autograd
+        n = l1.shape[0]
+        pack = torch.cat([l1[..., None], comb, any_valid[..., None]], -1)               # (N, R_local, 5)
+        full = gather_rays_autograd(pack.reshape(-1, 5), shard.full).reshape(n, -1, 5)   # lattice order: cams, rows, cols
+        return full[..., 0], full[..., 1:4], full[..., 4]
 
     def _sample_lattice(self, pix, img, padding_mode):
         """bilinear sample of one camera image (3, H, W) at the ray pixels -> (R, 3)."""
@@ -138,15 +158,24 @@ class ReprojLossMonoMultiNewCombine(_ReprojBase):
         # the fused sampling kernel is per camera here; the lattice sampling, SSIM, masks and the minimum run
         # batched over the cameras (same per-element arithmetic, ~6x fewer launches of tiny kernels).
         rgb_curr = self._sample_lattice_all(pix, curr_imgs[0].float(), 'border')                   # (N, R, 3)
+        # ray-sharded head: weights / ts hold this rank's rows only — the per-sample kernel runs on them, its three
+        # per-ray results are gathered into the full lattice (everything below needs whole images: SSIM, minimum)
+        from ..dist import shard_of
+        shard = shard_of(weights)
+        rays_k = num_rays if shard is None else shard.rays_per_cam_local
+        pix_k = pix if shard is None else shard.pix_local.float().contiguous()
         l1s, combs, valids = [], [], []
         for cam, (weight, t) in enumerate(zip(weights, ts)):
             l1, comb, any_valid = ReprojSampleFunction.apply(
-                weight.reshape(num_rays, -1), t.reshape(num_rays, -1),
-                None if deltas is None else deltas[cam].detach().reshape(num_rays, -1), pix, rgb_curr[cam],
+                weight.reshape(rays_k, -1), t.reshape(rays_k, -1),
+                None if deltas is None else deltas[cam].detach().reshape(rays_k, -1), pix_k,
+                rgb_curr[cam] if shard is None else self._local_rows(shard, rgb_curr[cam]).contiguous(),
                 T_prev[cam], T_next[cam], prev_imgs[0, cam].float(), next_imgs[0, cam].float(),
                 self.img_size[0], self.img_size[1])
             l1s.append(l1); combs.append(comb); valids.append(any_valid)
         l1, comb, any_valid = torch.stack(l1s), torch.stack(combs), torch.stack(valids)             # (N, R[, 3])
+        if shard is not None:
+            l1, comb, any_valid = self._gather_per_ray(shard, l1, comb, any_valid)
         im = lambda x: x.reshape(num_cams, *self.ray_resize, self.dims).permute(0, 3, 1, 2)
         prev_next = l1
         if not self.no_ssim:
@@ -183,15 +212,25 @@ class ReprojLossMonoMultiNew(_ReprojBase):
         T_next = self._transforms(metas, 'img2nextImg', ts[0], num_cams)[0]
         pix = ms_rays.float().contiguous()
         invalid = _INVALID.to(pix.device)
+        from ..dist import shard_of
+        shard = shard_of(weights)        # ray-sharded head: per-sample inputs are this rank's rows (see the Combine loss)
+        rays_k = num_rays if shard is None else shard.rays_per_cam_local
+        pix_k = pix if shard is None else shard.pix_local.float().contiguous()
         tot = 0.
         for cam, (weight, t) in enumerate(zip(weights, ts)):
             target_curr = self._sample_lattice(pix, curr_imgs[0, cam].float(), 'zeros')
-            w2, t2 = weight.reshape(num_rays, -1), t.reshape(num_rays, -1)
-            d2 = None if deltas is None else deltas[cam].detach().reshape(num_rays, -1)
+            target_k = target_curr if shard is None else self._local_rows(shard, target_curr).contiguous()
+            w2, t2 = weight.reshape(rays_k, -1), t.reshape(rays_k, -1)
+            d2 = None if deltas is None else deltas[cam].detach().reshape(rays_k, -1)
             cands = []
             for T, img in ((T_prev[cam], prev_imgs[0, cam].float()), (T_next[cam], next_imgs[0, cam].float())):
-                l1, comb, any_valid = ReprojSampleFunction.apply(w2, t2, d2, pix, target_curr, T, invalid, img, img,
+                l1, comb, any_valid = ReprojSampleFunction.apply(w2, t2, d2, pix_k, target_k, T, invalid, img, img,
                                                                  self.img_size[0], self.img_size[1])
+                if shard is not None:      # one camera's rows: gather as a 1-camera lattice
+                    from ..render import RaySet
+                    one = RaySet(img2lidar=shard.full.img2lidar[:1], nx=shard.full.nx, ny=shard.full.ny)
+                    l1, comb, any_valid = (x[0] for x in self._gather_per_ray(
+                        type(shard)(one, shard.local, shard.pix_local), l1[None], comb[None], any_valid[None]))
                 loss = l1
                 if not self.no_ssim:
                     im = lambda x: x.reshape(1, *self.ray_resize, self.dims).permute(0, 3, 1, 2)

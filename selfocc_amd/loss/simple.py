@@ -91,7 +91,21 @@ class EikonalLoss(BaseLoss):
     def __init__(self, weight=1.0, input_dict=None, **kwargs):
         super().__init__(weight)
         self.input_dict = input_dict or {'eik_grad': 'eik_grad'}
-        self.loss_func = lambda eik_grad: ((eik_grad.norm(2, dim=-1) - 1) ** 2).mean()
+        self.loss_func = self.eikonal
+
+    supports_ray_shard = True
+
+    @staticmethod
+    def eikonal(eik_grad):
+        from ..dist import shard_of, global_value_local_grad
+        sq = (eik_grad.norm(2, dim=-1) - 1) ** 2
+        shard = shard_of(eik_grad)
+        if shard is None:
+            return sq.mean()
+        # ray-sharded head: this rank's samples only; the mean runs over the samples of ALL ranks
+        n_cams = shard.full.img2lidar.shape[0]
+        n_global = sq.numel() // (n_cams * shard.rays_per_cam_local) * n_cams * shard.rays_per_cam_full
+        return global_value_local_grad(sq.sum() / n_global)
 
 
 @OPENOCC_LOSS.register_module()

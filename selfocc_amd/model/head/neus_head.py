@@ -499,8 +499,17 @@ class NeuSHead(BaseModule):
             inv_s = sdist.replicate_grad_sum(inv_s)       # d/d(variance) is a sum over all rays as well
         out = render_rays_autograd(vol, inv_s, rays, cfg, want_grad_samples=True, t_rand=t_rand, bkgd_rays=bk)
         self.last_inv_s = inv_s.detach()          # device tensor (the reference logs output['inv_s'], neus_head.py:631-633)
+        shard = None
         if full_rays is not None:
-            out = {k: sdist.gather_rays_autograd(v, full_rays) for k, v in out.items()}
+            # per-ray tensors are gathered into full-frame maps (5 - 30 floats per ray); the per-sample tensors stay on the
+            # rank that rendered them (206 MB per iteration at the shipped training size) and reach the losses as
+            # LocalRows / tagged tensors (selfocc_amd/dist.py) — the losses reduce them to per-ray terms first
+            per_sample = ('weights', 'ts', 'deltas', 'sdf', 'grad')
+            local_out = {k: out[k] for k in per_sample if k in out}
+            out = {k: (v if k in per_sample else sdist.gather_rays_autograd(v, full_rays)) for k, v in out.items()}
+            out.update(local_out)
+            n_local = rays.nx * rays.ny
+            shard = sdist.RayShard(full_rays, rays, RaySampler.pixels(rays.ny, rays.nx, rays.sx, rays.sy, rays.ox, rays.oy, device))
             rays = full_rays
 
         shp = (1, num_cams, num_rays)
@@ -508,7 +517,11 @@ class NeuSHead(BaseModule):
         rgb = out['rgb'].reshape(*shp, 3) if 'rgb' in out else depth.new_empty(*shp, 0)
         weights, ts, deltas = out['weights'], out['ts'], out['deltas']       # (N, S)
         per_cam = lambda t: [c.reshape(-1) for c in t.reshape(num_cams, -1).chunk(num_cams, 0)]
-        ray_idx = [torch.arange(num_rays, device=device).unsqueeze(-1).repeat(1, S).flatten()] * num_cams
+        ray_idx = [torch.arange(num_rays if shard is None else n_local, device=device).unsqueeze(-1).repeat(1, S).flatten()] * num_cams
+        if shard is not None:
+            per_cam_full = per_cam
+            per_cam = lambda t: sdist.LocalRows(per_cam_full(t), shard)
+            ray_idx = sdist.LocalRows(ray_idx, shard)
         if rays.pixel_grid:
             origin, direction = self.img2lidar(metas, pix)
             direction = direction.flatten(0, 2)
@@ -520,7 +533,8 @@ class NeuSHead(BaseModule):
         outputs = {'ms_depths': [depth], 'ms_colors': [rgb], 'ms_accs': [acc], 'ms_fars': [fars], 'ms_rays': pix,
                    'origin': origin, 'direction': direction, 'direction_norm': direction_norm,
                    'ray_indices': ray_idx, 'weights': per_cam(weights), 'ts': per_cam(ts), 'deltas': per_cam(deltas),
-                   'eik_grad': out['grad'].reshape(-1, 3), 'uniform_sdf': None}
+                   'eik_grad': out['grad'].reshape(-1, 3) if shard is None else sdist.tag_local(out['grad'].reshape(-1, 3), shard),
+                   'uniform_sdf': None}
         if self.return_uniform_sdf:
             outputs['uniform_sdf'] = self.get_uniform_sdf(self.aabb, self.resolution, device, True)[0]
         if self.return_max_depth:
@@ -539,7 +553,7 @@ class NeuSHead(BaseModule):
             outputs['ms_colors'] = [rgb[:, h:]]
             for k in ('ray_indices', 'weights', 'ts', 'deltas', 'sample_sdf'):
                 if k in outputs:
-                    outputs[k] = outputs[k][:h]
+                    outputs[k] = outputs[k][:h] if shard is None else sdist.LocalRows(outputs[k][:h], shard)
             if 'sem' in outputs:
                 outputs['sem'] = [outputs['sem'][0][:, h:]]
         return outputs

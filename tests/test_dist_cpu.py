@@ -118,3 +118,64 @@ def test_sharded_autograd_equals_unsharded_world2_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert all(ret.get(r) for r in range(ws)), dict(ret)
+
+
+def _worker_local_terms(rank, ws, port, ret):
+    """Sharded loss terms: a per-rank partial sum reports the GLOBAL value and back-propagates the local part only; a
+    loss class that does not know how to reduce local per-sample inputs refuses them."""
+    from selfocc_amd.dist import global_value_local_grad, LocalRows, RayShard, tag_local
+    from selfocc_amd.render import RaySet
+    from selfocc_amd.loss import EikonalLoss, SecondGradLoss
+    from selfocc_amd.loss.base import BaseLoss
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        ok = True
+        x = torch.tensor([1.0 + rank, 2.0], requires_grad=True)
+        v = global_value_local_grad((x ** 2).sum())
+        v.backward()
+        ok &= abs(v.item() - ((1 + 4) + (4 + 4))) < 1e-6 and torch.allclose(x.grad, 2 * x.detach())
+        # EikonalLoss on this rank's samples == its share of the global mean (value: the global mean on every rank)
+        full = RaySet(img2lidar=torch.eye(4)[None].repeat(2, 1, 1), nx=5, ny=7, sx=1.0, sy=1.0)
+        from selfocc_amd.dist import shard_rays, row_block
+        local = shard_rays(full)
+        shard = RayShard(full, local, torch.zeros(local.nx * local.ny, 2))
+        S = 3
+        g = torch.Generator().manual_seed(0)
+        grads_all = torch.randn(2, 7, 5, S, 3, generator=g, dtype=torch.float64)
+        r0, r1 = row_block(7, rank, ws)
+        mine = grads_all[:, r0:r1].reshape(-1, 3).clone().requires_grad_(True)
+        val = EikonalLoss(weight=1.0)(dict(eik_grad=tag_local(mine, shard)))
+        want = ((grads_all.reshape(-1, 3).norm(2, dim=-1) - 1) ** 2).mean()
+        ok &= bool(torch.allclose(val.detach(), want, rtol=1e-12))
+        val.backward()
+        ref = grads_all.reshape(-1, 3).clone().requires_grad_(True)
+        ((ref.norm(2, dim=-1) - 1) ** 2).mean().backward()
+        ok &= bool(torch.allclose(mine.grad, ref.grad.reshape(2, 7, 5, S, 3)[:, r0:r1].reshape(-1, 3), rtol=1e-12))
+
+        class Naive(BaseLoss):          # a loss that would silently average local rows as if they were the frame
+            def __init__(self):
+                super().__init__(1.0, {'ts': 'ts'})
+                self.loss_func = lambda ts: torch.stack(list(ts)).mean()
+        try:
+            Naive()(dict(ts=LocalRows([torch.ones(4)], shard)))
+            ok = False
+        except NotImplementedError:
+            pass
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_loss_terms_world2_gloo():
+    ws = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_local_terms, args=(r, ws, port, ret)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(ret.get(r) for r in range(ws)), dict(ret)

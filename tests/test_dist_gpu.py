@@ -60,7 +60,15 @@ def _worker(rank, ws, port, ret):
                                  'ms_rays': 'ms_rays'}),
                 dict(type='RGBLossMS', weight=0.1, img_size=[64, 64], no_ssim=False, ray_resize=[7, 10],
                      input_dict={'ms_colors': 'ms_colors', 'ms_rays': 'ms_rays', 'gt_imgs': 'curr_imgs'}),
+                dict(type='ReprojLossMonoMultiNew', weight=0.5, no_ssim=False, img_size=[64, 64], ray_resize=[7, 10],
+                     input_dict={'curr_imgs': 'curr_imgs', 'prev_imgs': 'prev_imgs', 'next_imgs': 'next_imgs',
+                                 'ray_indices': 'ray_indices', 'weights': 'weights', 'ts': 'ts', 'metas': 'metas',
+                                 'ms_rays': 'ms_rays', 'deltas': 'deltas'}),
                 dict(type='EikonalLoss', weight=0.1)]))
+            if shard:      # the per-sample tensors stayed on the rank that rendered them (no 206 MB all-gather)
+                from selfocc_amd.dist import LocalRows, shard_of
+                assert isinstance(out['weights'], LocalRows) and shard_of(out['eik_grad']) is not None
+                assert out['weights'][0].numel() < 7 * 10 * 32 and out['ms_depths'][0].shape == (1, 2, 70)
             total, _ = loss_fn(dict(out, metas=metas, **imgs))
             total.backward()
             grads.append(([r.grad.clone() for r in rep],
