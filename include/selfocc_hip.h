@@ -250,6 +250,20 @@ int selfocc_msda_pro_fwd(const void *value, const int32_t *shapes, const int32_t
                          int32_t nq, int32_t heads, int32_t d, int32_t L, int32_t P, int32_t K, int32_t value_stride,
                          int32_t value_layout, int32_t value_dtype, void *stream);
 
+/* selfocc_msda_cross_fwd for head-major float32 `value` with the coarse FPN levels staged in LDS (csrc/msda_lds.hip): the
+ * work is cut per (camera, head) pair, a block keeps the pair's levels >= l0 (the largest tail of levels that fits
+ * 128 KB: 24x50 + 12x25 pixels at the shipped size) in LDS and gathers those levels with ds_read_b128, the fine levels
+ * from global memory as before; per-camera results go to `workspace` (selfocc_msda_cross_lds_workspace bytes) and are
+ * summed in camera order / divided by the visible-camera count by a second kernel.  Same results as
+ * selfocc_msda_cross_fwd up to the association of the camera sum.  Supported: d = 16, L <= 4, 33 <= P <= 64 (one
+ * (query, head) group per wavefront: the zh / wz planes).  host_shapes: HOST copy of `shapes`. */
+int selfocc_msda_cross_lds_supported(const int32_t *host_shapes, int32_t heads, int32_t d, int32_t L, int32_t P);
+size_t selfocc_msda_cross_lds_workspace(int32_t cams, int32_t nq, int32_t heads, int32_t d);
+int selfocc_msda_cross_lds_fwd(const float *value, const int32_t *shapes, const int32_t *starts, const int32_t *host_shapes,
+                               const float *ref, const uint8_t *vis, const float *off_raw, const float *logits, float *out,
+                               int32_t cams, int32_t nv, int32_t nq, int32_t heads, int32_t d, int32_t L, int32_t P,
+                               void *workspace, size_t workspace_bytes, void *stream);
+
 /* Training counterpart of selfocc_msda_cross_fwd: g_out (nq, heads*d) is the gradient of the camera MEAN;
  * returns g_value (cams,nv,heads,d; zero-initialised by the caller), g_off (nq,heads,L,P,2) and
  * g_logits (nq,heads,L*P) — sums over the visible cameras / count.  host_shapes and workspace as for

@@ -5,6 +5,9 @@ model/encoder/bevformer/attention/image_cross_attention.py:340-342 and
 model/encoder/tpvformer/attention/cross_view_hybrid_attention.py:111-113.
 The arithmetic is csrc/msda.hip behind selfocc_msda_fwd / selfocc_msda_bwd.
 """
+import ctypes as C
+import os
+
 import torch
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
@@ -165,6 +168,22 @@ def msda_fused_inference(value, spatial_shapes, level_start_index, reference_poi
     return out
 
 
+# inference camera loop of the P >= 33 planes (zh / wz) re-cut per (camera, head) with the coarse FPN levels of `value` staged in
+# LDS (csrc/msda_lds.hip).  OFF by default: measured 312 vs 204 us per call on the zh plane — the
+# staging itself gains 5 %, the (camera, head)-stationary block structure it needs costs 60 %.  env SELFOCC_MSDA_LDS=1 for the A/B.
+CROSS_LDS = os.environ.get('SELFOCC_MSDA_LDS', '0') == '1'
+_CROSS_LDS_WS = {}
+
+
+def _cross_lds_workspace(device, nbytes):
+    """per (device, stream) scratch for the per-camera partial results (rewritten by every launch on that stream)"""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _CROSS_LDS_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _CROSS_LDS_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return ws
+
+
 def msda_cross_inference(value, spatial_shapes, level_start_index, reference_points_cam, visible,
                          sampling_offsets, attention_logits, head_major=False):
     """Inference-only camera-loop op (no autograd): the sampling stage of BEVCrossAttention
@@ -191,6 +210,16 @@ def msda_cross_inference(value, spatial_shapes, level_start_index, reference_poi
     assert ref.shape == (cams, nq, P, 2) and vis.shape == (cams, nq)
     sh, st = _i32(spatial_shapes, value.device), _i32(level_start_index, value.device)
     out = torch.empty(nq, heads * d, device=value.device, dtype=torch.float32)
+    host = getattr(spatial_shapes, '_so_host', None)
+    if (CROSS_LDS and head_major and vdt == abi.DTYPE_F32 and vstride == 0 and host is not None and nq > 0):
+        hs = (C.c_int32 * len(host))(*host)
+        if lib().selfocc_msda_cross_lds_supported(hs, heads, d, L, P):
+            # zh / wz planes: per (camera, head) blocks with the coarse FPN levels in LDS (csrc/msda_lds.hip)
+            ws = _cross_lds_workspace(value.device, int(lib().selfocc_msda_cross_lds_workspace(cams, nq, heads, d)))
+            check(lib().selfocc_msda_cross_lds_fwd(ptr(value), ptr(sh), ptr(st), hs, ptr(ref), ptr(vis), ptr(off), ptr(lg),
+                                                   ptr(out), cams, nv, nq, heads, d, L, P, ptr(ws), ws.numel(),
+                                                   current_stream(value.device)), "selfocc_msda_cross_lds_fwd")
+            return out
     check(lib().selfocc_msda_cross_fwd(ptr(value), ptr(sh), ptr(st), ptr(ref), ptr(vis), ptr(off), ptr(lg),
                                        ptr(out), cams, nv, nq, heads, d, L, P, vstride, int(bool(head_major)), vdt,
                                        current_stream(value.device)),

@@ -436,3 +436,41 @@ def test_msda_prologue_fused_vs_separate_linears(hip, form, value_mode):
     assert got.shape == want.shape and torch.isfinite(got).all()
     scale = want.abs().max().item()
     assert (got - want).abs().max().item() <= 2e-5 * scale, ((got - want).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize("shapes,P", [([[24, 50], [12, 25], [6, 13], [3, 7]], 48), ([[20, 30], [10, 15], [5, 8]], 33),
+                                      ([[96, 200], [48, 100], [24, 50], [12, 25]], 48)])
+def test_msda_cross_lds_staged_levels_vs_camera_loop(hip, shapes, P):
+    """selfocc_msda_cross_lds_fwd (csrc/msda_lds.hip: per (camera, head) blocks, coarse FPN levels gathered from LDS, per-camera
+    partials summed in camera order) == selfocc_msda_cross_fwd on the zh / wz-plane form: 6 cameras, 48 pillar points per
+    level, most points outside the image, queries no camera sees; incl. the shipped FPN sizes (levels 2 + 3 staged)."""
+    import selfocc_amd.msda as M
+    d0 = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    heads, d, cams, nq = 6, 16, 6, 1203
+    L = len(shapes)
+    sh = torch.tensor(shapes, device=d0)
+    sh._so_host = [int(v) for hw in shapes for v in hw]
+    st = torch.cat([sh.new_zeros(1), (sh[:, 0] * sh[:, 1]).cumsum(0)[:-1]])
+    nv = int((sh[:, 0] * sh[:, 1]).sum())
+    value = M.to_head_major(torch.randn(cams, nv, heads, d, generator=g).to(d0))
+    ref = (torch.rand(cams, nq, P, 2, generator=g) * 2.0 - 0.5).to(d0)          # half of the pillar points miss the image
+    vis = (torch.rand(cams, nq, generator=g) < 0.3).to(d0)
+    vis[:, :5] = False
+    off = (torch.randn(nq, heads, L, P, 2, generator=g) * 2.0).to(d0)
+    logits = torch.randn(nq, heads, L * P, generator=g).to(d0)
+    hs = (M.C.c_int32 * len(sh._so_host))(*sh._so_host)
+    assert M.lib().selfocc_msda_cross_lds_supported(hs, heads, d, L, P) == 1
+    assert M.lib().selfocc_msda_cross_lds_supported(hs, heads, d, L, 8) == 0     # the hw plane stays on the other kernels
+    old = M.CROSS_LDS
+    try:
+        M.CROSS_LDS = False
+        want = M.msda_cross_inference(value, sh, st, ref, vis, off, logits, True)
+        M.CROSS_LDS = True
+        got = M.msda_cross_inference(value, sh, st, ref, vis, off, logits, True)
+    finally:
+        M.CROSS_LDS = old
+    torch.cuda.synchronize()
+    assert torch.isfinite(got).all() and (got[:5] == 0).all()
+    scale = want.abs().max().item()
+    assert (got - want).abs().max().item() <= 2e-6 * scale, ((got - want).abs().max().item(), scale)
