@@ -19,9 +19,11 @@ import csv, glob, collections
 for f in sorted(glob.glob("$R/gpurun_out/pmc_$TAG/p*/p_counter_collection.csv")):
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(f)):
-        if 'render_fwd' in r['Kernel_Name'] or 'brickify' in r['Kernel_Name']:
-            agg[r['Kernel_Name'].split('(')[0][-60:]][r['Counter_Name']].append(float(r['Counter_Value']))
+        import re
+        m = re.search(r'(render_fwd_\w+<[^>]*>|sdf_brickify_kernel)', r['Kernel_Name'])
+        if m:
+            agg[m.group(1)][r['Counter_Name']].append(float(r['Counter_Value']))
     for kn, d in agg.items():
         for k, v in d.items():
-            print(f"{kn:62s} {k:28s} n={len(v)} mean={sum(v)/len(v):.5g}")
+            print(f"{kn:46s} {k:28s} n={len(v)} mean={sum(v)/len(v):.5g}")
 PY
