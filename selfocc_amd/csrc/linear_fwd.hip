@@ -36,6 +36,7 @@
 // The HBM side is far from its limit (torch fill_ writes the same 100 MB in 16 us = 6 TB/s).
 #include "so_device.h"
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 
 namespace {
@@ -267,6 +268,148 @@ __global__ __launch_bounds__(WAVES * 64) void linear_fwd16_kernel(LinearFwdArgs 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same projection on the bf16 matrix pipe with an EXACT three-way split (round 3).  f32 MFMA on gfx950 runs at the
+// vector rate (64 FLOP / clk / SIMD); v_mfma_f32_16x16x32_bf16 does 16 x that.  Every float32 is the exact sum of three
+// bfloat16 (8 + 8 + 8 mantissa bits: x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2), the residuals are exact in
+// float32), so x w = sum_ij xi wj, and the six products with i + j <= 4 carry everything above 2^-24 |x w|: float32-level
+// accuracy (the tests' 2e-6 against the float64 product) for 6 bf16 MFMAs of 16 cycles per 32 k instead of 8 f32 MFMAs
+// of 32 cycles — 2.67 x fewer matrix-pipe cycles.  Products of bfloat16 pairs are exact in the float32 accumulator; the
+// three small terms are accumulated first.
+//   * W: split once per persistent block into three bf16 planes in LDS ([column][K + 8]: 16-byte reads, conflict-free);
+//   * x: a wave owns 32 rows (two 16-row MFMA tiles share every B read: at 16 rows the LDS stream, 54 KB per tile, would
+//     be the bound); lane (m, kb) holds x[row m][32 ks + 8 kb ..+8], split in registers per k step;
+//   * epilogues: the accumulator layout is that of the f32 kernel, so bias / ReLU / residual / LayerNorm / head-major
+//     stores are the same functions.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+SO_DEVFN void so_split3(const float (&x)[8], bf16x8 &a1, bf16x8 &a2, bf16x8 &a3) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 b1 = (__bf16)x[j];
+        const float r1 = x[j] - (float)b1;
+        const __bf16 b2 = (__bf16)r1;
+        const float r2 = r1 - (float)b2;
+        a1[j] = b1; a2[j] = b2; a3[j] = (__bf16)r2;
+    }
+}
+
+template <int KS /* K / 32 */, bool LN, int NT /* 32-column tiles per block */, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void linear_fwd_b3_kernel(LinearFwdArgs a) {
+    constexpr int K = 32 * KS, KPB = K + 8, NT16 = 2 * NT, THREADS = WAVES * 64, NCOL = 32 * NT;
+    extern __shared__ __attribute__((aligned(16))) __bf16 wb[];    // [3][NCOL][KPB]
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int n = lane & 15, kb = lane >> 4;
+    const unsigned logical = so_lin_xcd_block();
+    const int cb = __builtin_amdgcn_readfirstlane((int)(logical % (unsigned)a.ncb));
+    const long long rc = __builtin_amdgcn_readfirstlane((int)(logical / (unsigned)a.ncb));
+    const int n0 = a.col0 + cb * 96;
+    const long long nwt = (a.T + 31) / 32, wt_step = (long long)WAVES * a.groups;
+    // ---- stage W: 8 consecutive k of one column per thread and step, split into the three planes ----
+    {
+        constexpr int NV = NCOL * (K / 8);
+        for (int idx = threadIdx.x; idx < NV; idx += THREADS) {
+            const int r = idx / (K / 8), k8 = idx - r * (K / 8);
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (n0 + r < a.N) {
+                const float4 lo = ((const float4 *)(a.w + (size_t)(n0 + r) * K))[2 * k8], hi = ((const float4 *)(a.w + (size_t)(n0 + r) * K))[2 * k8 + 1];
+                v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+            }
+            bf16x8 w1, w2, w3;
+            so_split3(v, w1, w2, w3);
+            *(bf16x8 *)(wb + (size_t)r * KPB + 8 * k8) = w1;
+            *(bf16x8 *)(wb + (size_t)(NCOL + r) * KPB + 8 * k8) = w2;
+            *(bf16x8 *)(wb + (size_t)(2 * NCOL + r) * KPB + 8 * k8) = w3;
+        }
+    }
+    __syncthreads();
+
+    const bool full_cols = a.N - n0 >= 32 * NT;
+    const float relu_lo = a.relu ? 0.0f : -__builtin_huge_valf();
+    float bv[NT16], gv[NT16], bt[NT16];
+    bool cok[NT16];
+#pragma unroll
+    for (int t = 0; t < NT16; ++t) {
+        const int col = n0 + 16 * t + n;
+        cok[t] = col < a.N;
+        bv[t] = (a.bias && cok[t]) ? a.bias[col] : 0.0f;
+        gv[t] = (LN && cok[t]) ? a.gamma[col] : 0.0f;
+        bt[t] = (LN && cok[t]) ? a.beta[col] : 0.0f;
+    }
+
+    for (long long wt = rc * WAVES + wave; wt < nwt; wt += wt_step) {
+        const long long row0 = wt * 32;
+        const int rem = (int)min(32LL, a.T - row0);
+        // raw x of both 16-row halves, all k steps in flight at once
+        float xr[2][KS][8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int rl = min(16 * h + n, rem - 1);
+            const float *xb = a.x + (row0 + rl) * K + 8 * kb;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const float4 lo = *(const float4 *)(xb + 32 * ks), hi = *(const float4 *)(xb + 32 * ks + 4);
+                xr[h][ks][0] = lo.x; xr[h][ks][1] = lo.y; xr[h][ks][2] = lo.z; xr[h][ks][3] = lo.w;
+                xr[h][ks][4] = hi.x; xr[h][ks][5] = hi.y; xr[h][ks][6] = hi.z; xr[h][ks][7] = hi.w;
+            }
+        }
+        f32x4 acc[2][NT16];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int t = 0; t < NT16; ++t)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[h][t][j] = 0.0f;
+        const __bf16 *bbase = wb + (size_t)n * KPB + 8 * kb;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 a1[2], a2[2], a3[2];
+            so_split3(xr[0][ks], a1[0], a2[0], a3[0]);
+            so_split3(xr[1][ks], a1[1], a2[1], a3[1]);
+#pragma unroll
+            for (int t = 0; t < NT16; ++t) {
+                const __bf16 *bp = bbase + (size_t)(16 * t) * KPB + 32 * ks;
+                const bf16x8 b1 = *(const bf16x8 *)bp, b2 = *(const bf16x8 *)(bp + (size_t)NCOL * KPB),
+                             b3 = *(const bf16x8 *)(bp + (size_t)2 * NCOL * KPB);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {      // small terms first
+                    acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[h], b1, acc[h][t], 0, 0, 0);
+                    acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[h], b3, acc[h][t], 0, 0, 0);
+                    acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[h], b2, acc[h][t], 0, 0, 0);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[h], b1, acc[h][t], 0, 0, 0);
+                    acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[h], b2, acc[h][t], 0, 0, 0);
+                    acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[h], b1, acc[h][t], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long r0 = row0 + 16 * h;
+            const int rm = rem - 16 * h;
+            if (rm <= 0) break;
+            const int rmc = min(rm, 16);
+            const float *rb = a.residual ? a.residual + r0 * a.ldr + n0 : nullptr;
+            float *yb = a.y + r0 * a.ldy + n0;
+            float *pb = (LN && a.y_pre) ? a.y_pre + r0 * a.N : nullptr;
+            float *mb = (LN && a.mean) ? a.mean + r0 : nullptr, *sb = (LN && a.mean) ? a.rstd + r0 : nullptr;
+            int no = n;
+            asm volatile("" : "+v"(no));
+            if (!LN && NT == 3 && a.hm_nv > 0) {
+                if constexpr (!LN && NT == 3)
+                    so_linear_epilogue16_hm<NT16>(acc[h], bv, relu_lo, a.y + (size_t)cb * a.hm_sg, r0, rmc, a.hm_nv, no, kb);
+            } else if (rmc == 16 && full_cols)
+                so_linear_epilogue16<LN, true, NT16>(acc[h], bv, gv, bt, cok, relu_lo, rb, a.ldr, yb, a.ldy, pb, mb, sb, a.N, a.eps,
+                                                     rmc, no, kb);
+            else
+                so_linear_epilogue16<LN, false, NT16>(acc[h], bv, gv, bt, cok, relu_lo, rb, a.ldr, yb, a.ldy, pb, mb, sb, a.N, a.eps,
+                                                      rmc, no, kb);
+        }
+    }
+}
+
 bool so_linear_fwd_ok(long long T, int N, int K) {
     if (!(K == 32 || K == 64 || K == 96 || K == 128 || K == 192)) return false;
     return T >= 1 && N >= 1 && (long long)N * K < (1LL << 30) && T < (1LL << 40);
@@ -306,6 +449,59 @@ static int so_linear_fwd_launch(const float *x, const float *w, const float *bia
         a.ncb = pass == 0 ? ncb_full : 1;
         a.col0 = pass == 0 ? 0 : 96 * ncb_full;
         if ((pass == 0 && ncb_full == 0) || (pass == 1 && tail_nt == 0)) continue;
+        // round 3: the bf16 three-way-split kernel (same results to float32 rounding, 2.67 x fewer matrix-pipe cycles);
+        // SELFOCC_LINEAR_B3=0 keeps the f32-MFMA kernel (A/B)
+        static const bool b3_env = !(getenv("SELFOCC_LINEAR_B3") && atoi(getenv("SELFOCC_LINEAR_B3")) == 0);
+        // where it pays (measured inside the eval encoder, profiles/r3_h_*): enough 32-row tiles per block to amortise the
+        // three-plane split of W at block start (the 6 - 8 k-row zh / wz planes at N = 96 ran 17 vs 9 us), and K <= 128 (at
+        // K = 192 the planes take 115 KB: one block per CU, one wave per SIMD)
+        const bool use_b3 = b3_env && K <= 128 && (T >= 16384 || N >= 384);
+        if (use_b3) {
+            const size_t lds_b3 = (size_t)3 * nt * 32 * (K + 8) * 2;
+            long long per_cu3 = std::max<long long>(1, std::min<long long>(2, (160 * 1024) / (long long)(lds_b3 + 512)));
+            const long long nwt3 = (T + 31) / 32;
+            long long groups3 = std::max(1LL, 256 * per_cu3 / a.ncb);
+            groups3 = std::min(groups3, (nwt3 + 3) / 4);
+            a.groups = (int)groups3;
+            const long long nblk3 = groups3 * a.ncb;
+#define SO_B3_1(KS_, LN_, NT_)                                                                                        \
+    do {                                                                                                             \
+        /* the attribute is per device: set once per (device, instantiation) — the call is a driver round trip of tens of */ \
+        /* microseconds, which at ~45 launches per frame would make the host the bottleneck                                */ \
+        static std::atomic<unsigned long long> done_mask{0};                                                         \
+        int dev_ = 0;                                                                                                \
+        (void)hipGetDevice(&dev_);                                                                                   \
+        const unsigned long long bit_ = 1ull << (dev_ & 63);                                                         \
+        if (lds_b3 > 48 * 1024 && !(done_mask.load(std::memory_order_relaxed) & bit_)) {                             \
+            (void)hipFuncSetAttribute((const void *)linear_fwd_b3_kernel<KS_, LN_, NT_, 4>,                          \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);                 \
+            done_mask.fetch_or(bit_, std::memory_order_relaxed);                                                     \
+        }                                                                                                            \
+        hipLaunchKernelGGL((linear_fwd_b3_kernel<KS_, LN_, NT_, 4>), dim3((unsigned)nblk3), dim3(256), lds_b3, st, a); \
+    } while (0)
+#define SO_B3_2(KS_, LN_)                                                                                             \
+    do {                                                                                                             \
+        if (nt == 3) SO_B3_1(KS_, LN_, 3);                                                                           \
+        else if (nt == 2) SO_B3_1(KS_, LN_, 2);                                                                      \
+        else SO_B3_1(KS_, LN_, 1);                                                                                   \
+    } while (0)
+#define SO_B3_3(KS_)                                                                                                  \
+    do {                                                                                                             \
+        if (ln) SO_B3_2(KS_, true);                                                                                  \
+        else SO_B3_2(KS_, false);                                                                                    \
+    } while (0)
+            switch (K) {
+                case 32: SO_B3_3(1); break;
+                case 64: SO_B3_3(2); break;
+                case 96: SO_B3_3(3); break;
+                case 128: SO_B3_3(4); break;
+                default: SO_B3_3(6); break;
+            }
+#undef SO_B3_3
+#undef SO_B3_2
+#undef SO_B3_1
+            continue;
+        }
         const size_t lds_blk = (size_t)nt * 32 * (K + 4) * sizeof(float);
         static const long long percu_env = getenv("SELFOCC_LINEAR_PERCU") ? atoll(getenv("SELFOCC_LINEAR_PERCU")) : 0;  // dev A/B
         // persistent grid: two 4-wave blocks per CU (measured with the prefetches: 1 / 2 / 3 per CU = 495 / 483 / 527 us over
