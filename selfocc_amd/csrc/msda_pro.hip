@@ -23,6 +23,7 @@
 // 108); the zh / wz planes (3 L P = 576: 221 KB per head, 6 425 queries) keep the separate linears.
 #include "so_device.h"
 #include <algorithm>
+#include <atomic>
 
 namespace {
 
@@ -42,11 +43,26 @@ struct MsdaProArgs {
     MsdaDims dm;
 };
 
-constexpr int kProK = 96, kProKP = 100, kProKQ = 24, kProWaves = 16;
+constexpr int kProK = 96, kProKPB = 104;       // K; bf16 elements per LDS weight row (208 B: 16-byte reads on distinct banks)
 
-template <int D, int LOGG, int NT16, bool CROSS, typename VT>
+// float32 = exact sum of three bfloat16 (csrc/linear_fwd.hip: linear_fwd_b3_kernel): the prologue's product runs on the
+// bf16 matrix pipe as six MFMAs per 32 k — float32-level accuracy, 2.67 x fewer matrix-pipe cycles than f32 MFMA, and,
+// unlike f32 MFMA (which executes at the vector rate and showed no overlap), off the lanes the other waves' gathers need
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+SO_DEVFN void so_pro_split3(const float (&x)[8], bf16x8 &a1, bf16x8 &a2, bf16x8 &a3) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 b1 = (__bf16)x[j];
+        const float r1 = x[j] - (float)b1;
+        const __bf16 b2 = (__bf16)r1;
+        const float r2 = r1 - (float)b2;
+        a1[j] = b1; a2[j] = b2; a3[j] = (__bf16)r2;
+    }
+}
+
+template <int D, int LOGG, int NT16, bool CROSS, typename VT, int kProWaves>
 __global__ __launch_bounds__(kProWaves * 64) void msda_pro_fwd_kernel(MsdaProArgs a) {
-    constexpr int K = kProK, KP = kProKP, KQ = kProKQ;
+    constexpr int K = kProK, KPB = kProKPB, NROW = NT16 * 16;
     constexpr int G = 1 << LOGG;
     constexpr int QL = D / 4, LOGQ = so_ilog2(QL);
     constexpr int NJ = LOGG > LOGQ ? LOGG - LOGQ : 0;
@@ -54,12 +70,12 @@ __global__ __launch_bounds__(kProWaves * 64) void msda_pro_fwd_kernel(MsdaProArg
     constexpr int RS = NT16 * 16 + 1;                    // row stride of the result tile (odd: rows on different banks)
     constexpr int GPW = 64 / G;                          // (query, head) groups a wave samples at once
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *wl = lds;                                     // [NT16 * 16][KP]: this head's rows of W_off then W_aw
+    __bf16 *wb = (__bf16 *)lds;                          // [3 planes][NT16 * 16][KPB]: this head's rows of W_off then W_aw
     __shared__ int s_next;
     const MsdaDims dm = a.dm;
     const int LP = dm.L * dm.P, NC = 3 * LP;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    float *outl = lds + NT16 * 16 * KP + wave * (16 * RS);
+    float *outl = lds + (3 * NROW * KPB * 2) / 4 + wave * (16 * RS);
     const unsigned lb = so_xcd_block();
     const int h = (int)(lb / (unsigned)a.nbh), bi = (int)(lb - (unsigned)h * a.nbh);
     // this block's contiguous range of 16-query tiles
@@ -67,18 +83,28 @@ __global__ __launch_bounds__(kProWaves * 64) void msda_pro_fwd_kernel(MsdaProArg
     if (threadIdx.x == 0) s_next = t_lo + kProWaves;     // tiles t_lo .. t_lo + 15 are the waves' first ones
     const long long T = (long long)dm.bs * dm.nq;        // rows of x
 
-    // ---- stage the head's weight rows: column c < 2 LP -> W_off row h * 2LP + c, else W_aw row h * LP + c - 2LP ----
+    // ---- stage the head's weight rows (column c < 2 LP -> W_off row h * 2LP + c, else W_aw row h * LP + c - 2LP), split
+    // into the three bf16 planes: 8 consecutive k of one row per thread and step ----
     {
-        constexpr int NV = NT16 * 16 * (K / 4);
+        constexpr int NV = NROW * (K / 8);
         for (int idx = threadIdx.x; idx < NV; idx += kProWaves * 64) {
-            const int r = idx / (K / 4), k4 = idx - r * (K / 4);
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (r < 2 * LP) v = ((const float4 *)(a.w_off + (size_t)(h * 2 * LP + r) * K))[k4];
-            else if (r < NC) v = ((const float4 *)(a.w_aw + (size_t)(h * LP + r - 2 * LP) * K))[k4];
-            *(float4 *)(wl + r * KP + 4 * k4) = v;
+            const int r = idx / (K / 8), k8 = idx - r * (K / 8);
+            const float *src = nullptr;
+            if (r < 2 * LP) src = a.w_off + (size_t)(h * 2 * LP + r) * K;
+            else if (r < NC) src = a.w_aw + (size_t)(h * LP + r - 2 * LP) * K;
+            float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (src) {
+                const float4 lo = ((const float4 *)src)[2 * k8], hi = ((const float4 *)src)[2 * k8 + 1];
+                v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+            }
+            bf16x8 w1, w2, w3;
+            so_pro_split3(v, w1, w2, w3);
+            *(bf16x8 *)(wb + (size_t)r * KPB + 8 * k8) = w1;
+            *(bf16x8 *)(wb + (size_t)(NROW + r) * KPB + 8 * k8) = w2;
+            *(bf16x8 *)(wb + (size_t)(2 * NROW + r) * KPB + 8 * k8) = w3;
         }
     }
-    const int n = lane & 15, kq = lane >> 4;
+    const int n = lane & 15, kq = lane >> 4;     // MFMA lane roles: row / column n, k block (bf16 operands) = row group (result) kq
     float bv[NT16];
 #pragma unroll
     for (int t = 0; t < NT16; ++t) {
@@ -96,46 +122,40 @@ __global__ __launch_bounds__(kProWaves * 64) void msda_pro_fwd_kernel(MsdaProArg
     for (int tile = t_lo + wave; tile < t_hi;) {
         const long long r0 = (long long)tile * 16;
         const int rm = (int)min(16LL, T - r0);
-        // ---- 1. off / logits of the tile's 16 queries for head h: f32 MFMA ----
+        // ---- 1. off / logits of the tile's 16 queries for head h: six bf16 MFMAs per 32 k (exact three-way split) ----
         {
-            float av[KQ];
-            const float *xb = a.x + r0 * K;
-            const unsigned xoff = (unsigned)(min(n, rm - 1) * K + 4 * kq);
+            bf16x8 a1[3], a2[3], a3[3];
+            {
+                const float *xb = a.x + (r0 + min(n, rm - 1)) * K + 8 * kq;
+                float xr[3][8];
 #pragma unroll
-            for (int q = 0; q < KQ / 4; ++q) {
-                const float4 v = *(const float4 *)(xb + xoff + 16 * q);
-                av[4 * q] = v.x; av[4 * q + 1] = v.y; av[4 * q + 2] = v.z; av[4 * q + 3] = v.w;
-            }
-            const float *bbase = wl + n * KP + 4 * kq;      // the same k permutation: k = 16 q + 4 kq + j
-#pragma unroll
-            for (int tp = 0; tp < (NT16 + 1) / 2; ++tp) {
-                constexpr int QN = KQ / 4;
-                const bool two = 2 * tp + 1 < NT16;
-                f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-#ifndef SO_PRO_NO_MFMA      /* A/B: the kernel without its MFMA phase (wrong results) = what the prologue costs */
-#pragma unroll
-                for (int q = 0; q < QN; ++q) {
-                    const float4 b0 = *(const float4 *)(bbase + 32 * tp * KP + 16 * q);
-                    float4 b1 = b0;
-                    if (two) b1 = *(const float4 *)(bbase + (32 * tp + 16) * KP + 16 * q);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q], b0.x, acc0, 0, 0, 0);
-                    if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q], b1.x, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q + 1], b0.y, acc0, 0, 0, 0);
-                    if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q + 1], b1.y, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q + 2], b0.z, acc0, 0, 0, 0);
-                    if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q + 2], b1.z, acc1, 0, 0, 0);
-                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q + 3], b0.w, acc0, 0, 0, 0);
-                    if (two) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[4 * q + 3], b1.w, acc1, 0, 0, 0);
+                for (int ks = 0; ks < 3; ++ks) {
+                    const float4 lo = *(const float4 *)(xb + 32 * ks), hi = *(const float4 *)(xb + 32 * ks + 4);
+                    xr[ks][0] = lo.x; xr[ks][1] = lo.y; xr[ks][2] = lo.z; xr[ks][3] = lo.w;
+                    xr[ks][4] = hi.x; xr[ks][5] = hi.y; xr[ks][6] = hi.z; xr[ks][7] = hi.w;
                 }
-#else
-                acc0[0] = av[tp] + bbase[32 * tp * KP]; acc1[0] = av[tp + 4];
-#endif
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) so_pro_split3(xr[ks], a1[ks], a2[ks], a3[ks]);
+            }
+            const __bf16 *bbase = wb + (size_t)n * KPB + 8 * kq;
+#pragma unroll
+            for (int t = 0; t < NT16; ++t) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < 3; ++ks) {
+                    const __bf16 *bp = bbase + (size_t)(16 * t) * KPB + 32 * ks;
+                    const bf16x8 b1 = *(const bf16x8 *)bp, b2 = *(const bf16x8 *)(bp + (size_t)NROW * KPB),
+                                 b3 = *(const bf16x8 *)(bp + (size_t)2 * NROW * KPB);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[ks], b1, acc, 0, 0, 0);      // small terms first
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[ks], b3, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[ks], b2, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[ks], b1, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[ks], b2, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[ks], b1, acc, 0, 0, 0);
+                }
                 // ---- 2. accumulator layout (lane: column n of rows 4 kq + j) -> row-major result tile in LDS ----
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    outl[(4 * kq + j) * RS + 32 * tp + n] = acc0[j] + bv[2 * tp];
-                    if (two) outl[(4 * kq + j) * RS + 32 * tp + 16 + n] = acc1[j] + bv[2 * tp + 1];
-                }
+                for (int j = 0; j < 4; ++j) outl[(4 * kq + j) * RS + 16 * t + n] = acc[j] + bv[t];
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -315,20 +335,27 @@ extern "C" int selfocc_msda_pro_fwd(const void *value, const int32_t *shapes, co
     a.nbh = std::max(1, std::min(so_num_cus() / heads, a.n_tiles));
     a.dm = MsdaDims{bs, nv, nq, heads, L, P, 0, value_stride, value_layout};
     const unsigned blocks = (unsigned)(a.nbh * heads);
-#define SO_LAUNCH_PRO(LG, NT, CR, VTT)                                                                                  \
+#define SO_LAUNCH_PRO(LG, NT, CR, VTT, WV)                                                                              \
     do {                                                                                                                \
-        const size_t shm = ((size_t)NT * 16 * kProKP + (size_t)kProWaves * 16 * (NT * 16 + 1)) * sizeof(float);         \
-        (void)hipFuncSetAttribute((const void *)msda_pro_fwd_kernel<16, LG, NT, CR, VTT>,                               \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);                                \
-        hipLaunchKernelGGL((msda_pro_fwd_kernel<16, LG, NT, CR, VTT>), dim3(blocks), dim3(kProWaves * 64), shm, st, a); \
+        const size_t shm = (size_t)3 * NT * 16 * kProKPB * 2 + (size_t)WV * 16 * (NT * 16 + 1) * sizeof(float);         \
+        static std::atomic<unsigned long long> done_mask{0};      /* per-device attribute: one driver call per device */ \
+        int dev_ = 0;                                                                                                   \
+        (void)hipGetDevice(&dev_);                                                                                      \
+        if (!(done_mask.load(std::memory_order_relaxed) & (1ull << (dev_ & 63)))) {                                     \
+            (void)hipFuncSetAttribute((const void *)msda_pro_fwd_kernel<16, LG, NT, CR, VTT, WV>,                       \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);                    \
+            done_mask.fetch_or(1ull << (dev_ & 63), std::memory_order_relaxed);                                         \
+        }                                                                                                               \
+        hipLaunchKernelGGL((msda_pro_fwd_kernel<16, LG, NT, CR, VTT, WV>), dim3(blocks), dim3(WV * 64), shm, st, a);    \
     } while (0)
-#define SO_LAUNCH_PRO_V(LG, NT, CR)                                          \
-    do {                                                                     \
-        if (value_dtype == SO_DTYPE_BF16) SO_LAUNCH_PRO(LG, NT, CR, uint16_t); \
-        else SO_LAUNCH_PRO(LG, NT, CR, float);                               \
+#define SO_LAUNCH_PRO_V(LG, NT, CR, WV)                                          \
+    do {                                                                         \
+        if (value_dtype == SO_DTYPE_BF16) SO_LAUNCH_PRO(LG, NT, CR, uint16_t, WV); \
+        else SO_LAUNCH_PRO(LG, NT, CR, float, WV);                               \
     } while (0)
-    if (logG == 5) { if (cross) SO_LAUNCH_PRO_V(5, 6, true); else SO_LAUNCH_PRO_V(5, 6, false); }
-    else { if (cross) SO_LAUNCH_PRO_V(3, 7, true); else SO_LAUNCH_PRO_V(3, 7, false); }
+    // waves per block: what the 160 KB of LDS leave next to the three weight planes (16 at 3LP <= 96, 12 at <= 112)
+    if (logG == 5) { if (cross) SO_LAUNCH_PRO_V(5, 6, true, 16); else SO_LAUNCH_PRO_V(5, 6, false, 16); }
+    else { if (cross) SO_LAUNCH_PRO_V(3, 7, true, 12); else SO_LAUNCH_PRO_V(3, 7, false, 12); }
 #undef SO_LAUNCH_PRO_V
 #undef SO_LAUNCH_PRO
     return so_launch_status();
