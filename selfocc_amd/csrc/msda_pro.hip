@@ -7,20 +7,23 @@
 //     A = softmax(logits), loc = ref + off / (W_l, H_l), out = MSDA(value, loc, A)
 // i.e. it writes 3 * heads * L * P floats per query to memory (152 MB on the hw plane of nuscenes_occ, 204 MB for the
 // cross-view self-attention, per layer) only to read them back in the sampling kernel.  Here the two linears are an
-// f32-MFMA tile in the sampling kernel's prologue: a (query, head) needs 3 * L * P of those outputs, a block works on
+// MFMA tile in the sampling kernel's prologue (on the bf16 matrix pipe through an exact three-way split: float32 accuracy): a (query, head) needs 3 * L * P of those outputs, a block works on
 // ONE head (head-outer order, as in msda.hip), so only that head's 3 * L * P rows of the weights are needed — 96 rows
 // x 96 inputs = 36 KB on the hw plane — and they stay in LDS for the lifetime of a persistent 16-wave block.
 //
 //   per wave, per tile of 16 consecutive queries:
-//     1. x tile (16 x 96) straight into the MFMA A layout (K / 16 float4 loads per lane, k permuted as in
-//        linear_fwd.hip), W^T from LDS: v_mfma_f32_16x16x4_f32, NT16 = ceil(3 L P / 16) accumulator tiles;
+//     1. x tile (16 x 96) straight into the MFMA A layout (lane (row, k block): 8 consecutive k per 32-k step), split into
+//        three bfloat16 parts in registers; W^T (three bf16 planes) from LDS: six v_mfma_f32_16x16x32_bf16 per 32 k and
+//        16-column tile, NT16 = ceil(3 L P / 16) tiles;
 //     2. bias added, the 16 x 3LP result parked in a wave-private LDS tile (accumulator layout -> row layout);
 //     3. the sampling stage of msda_fused_fwd_kernel / msda_cross_fwd_kernel unchanged — softmax over the group's logits,
 //        offsets / (W_l, H_l), bilinear set-up, channel-team gathers, camera loop, group reduce — reading its logits
 //        and offsets from that tile instead of global memory.
-// f32 MFMA on gfx950 is an exact fmaf chain, so off / logits differ from the separate Linear only in summation order.
-// Applies where a head's weight slice fits LDS next to 16 result tiles: 3 L P <= 112 (hw plane: 96, self-attention:
-// 108); the zh / wz planes (3 L P = 576: 221 KB per head, 6 425 queries) keep the separate linears.
+// The split is exact (csrc/linear_fwd.hip: linear_fwd_b3_kernel), so off / logits differ from the separate Linear by float32
+// rounding only.  (The first version used f32 MFMA: same results, but f32 MFMA runs at the vector rate and did not hide
+// under the gathers — 381 / 387 us per call instead of 352 / 322)
+// Applies where a head's weight slice (3 planes x 3LP x 208 B) fits LDS next to 16 (12) result tiles: 3 L P <= 112 (hw
+// plane: 96, self-attention: 108); the zh / wz planes (3 L P = 576: 221 KB per head, 6 425 queries) keep the separate linears.
 #include "so_device.h"
 #include <algorithm>
 #include <atomic>
