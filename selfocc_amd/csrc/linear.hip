@@ -28,6 +28,7 @@
 // operand cost more than the overlap buys) — dropped.
 #include "so_device.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -143,6 +144,133 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_kernel(const float *__res
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same reduction on the bf16 matrix pipe with the exact three-way split of linear_fwd.hip (round 3): every loaded
+// float32 of dY and X becomes three bfloat16 (x = x1 + x2 + x3 exactly), six v_mfma_f32_32x32x16_bf16 (the products with
+// i + j <= 4, small terms first) replace eight v_mfma_f32_32x32x2_f32 per 16 rows — 2.67 x fewer matrix-pipe cycles at
+// float32-level accuracy.  Operand layout of the 16-row step (reduction index = row):
+//     A[m = n][k = row]: lane (i, kb) <- dY[r + 8 kb + j][n0 + 32 t + i], j < 8     (per j: 32 consecutive floats of a row)
+//     B[k = row][col]:   lane (i, kb) <- X[r + 8 kb + j][32 u + i]
+// X's parts are split once per step and shared by the NTW tile rows; dY's parts per tile row.  The bias gradient is the
+// float32 running sum of the raw A operand, as before.  Accumulator layout and everything after the loop are the f32
+// kernel's.
+typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+
+SO_DEVFN void so_wsplit3(const float (&x)[8], bf16x8w &a1, bf16x8w &a2, bf16x8w &a3) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 b1 = (__bf16)x[j];
+        const float r1 = x[j] - (float)b1;
+        const __bf16 b2 = (__bf16)r1;
+        const float r2 = r1 - (float)b2;
+        a1[j] = b1; a2[j] = b2; a3[j] = (__bf16)r2;
+    }
+}
+
+template <int KT, int NTW>
+__global__ __launch_bounds__(256, 2) void linear_wgrad_b3_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                                 float *__restrict__ part_w, float *__restrict__ part_b,
+                                                                 long long T, int N, int K, long long rows_per_block) {
+    __shared__ float red[NTW * KT * 1024];
+    __shared__ float red_b[4][NTW * 32];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = lane & 31, half = lane >> 5;                       // half = k block (rows 8 half .. 8 half + 7 of a step)
+    const int chunk = blockIdx.x;
+    const int n0 = blockIdx.y * (NTW * 32);
+    const long long r_blk = (long long)chunk * rows_per_block;
+    const long long rpw = rows_per_block / 4;
+    const long long r0 = r_blk + wave * rpw, r1 = min(T, r0 + rpw);
+
+    f32x16 acc[NTW][KT];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int u = 0; u < KT; ++u)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[t][u][v] = 0.0f;
+    float bsum[NTW];
+    bool ncol[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) { bsum[t] = 0.0f; ncol[t] = n0 + t * 32 + i < N; }
+
+    for (long long r = r0; r < r1; r += 16) {
+        float a[NTW][8], b[KT][8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const long long rr = r + 8 * half + j;
+            const bool ok = rr < r1;
+            const float *dyr = dy + rr * N + n0 + i;
+            const float *xr = x + rr * K + i;
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) a[t][j] = (ok && ncol[t]) ? dyr[t * 32] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < KT; ++u) b[u][j] = ok ? xr[u * 32] : 0.0f;
+        }
+        bf16x8w b1[KT], b2[KT], b3[KT];
+#pragma unroll
+        for (int u = 0; u < KT; ++u) so_wsplit3(b[u], b1[u], b2[u], b3[u]);
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bsum[t] += a[t][j];
+            bf16x8w a1, a2, a3;
+            so_wsplit3(a[t], a1, a2, a3);
+#pragma unroll
+            for (int u = 0; u < KT; ++u) {
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, b1[u], acc[t][u], 0, 0, 0);
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3[u], acc[t][u], 0, 0, 0);
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2[u], acc[t][u], 0, 0, 0);
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1[u], acc[t][u], 0, 0, 0);
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2[u], acc[t][u], 0, 0, 0);
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1[u], acc[t][u], 0, 0, 0);
+            }
+        }
+    }
+
+    // block reduction and stores: as in linear_wgrad_kernel
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) bsum[t] += __shfl_xor(bsum[t], 32, 64);
+    if (half == 0) {
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) red_b[wave][t * 32 + i] = bsum[t];
+    }
+    for (int w = 1; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int u = 0; u < KT; ++u)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) red[((t * KT + u) * 16 + v) * 64 + lane] = acc[t][u][v];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int u = 0; u < KT; ++u)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) acc[t][u][v] += red[((t * KT + u) * 16 + v) * 64 + lane];
+        }
+        __syncthreads();
+    }
+    if (wave != 0) return;
+    float *pw = part_w + (size_t)chunk * N * K;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int n = n0 + t * 32 + (v & 3) + 8 * (v >> 2) + 4 * half;
+            if (n >= N) continue;
+#pragma unroll
+            for (int u = 0; u < KT; ++u) pw[(size_t)n * K + u * 32 + i] = acc[t][u][v];
+        }
+        if (half == 0 && ncol[t])
+            part_b[(size_t)chunk * N + n0 + t * 32 + i] =
+                (red_b[0][t * 32 + i] + red_b[1][t * 32 + i]) + (red_b[2][t * 32 + i] + red_b[3][t * 32 + i]);
+    }
+}
+
 // dW / db = sum over the chunks in a fixed order: wave w of a block adds the chunks c = w (mod 4) of 64 consecutive
 // elements (8 loads in flight), the four waves are combined through LDS
 __global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(const float *__restrict__ part_w,
@@ -227,9 +355,17 @@ extern "C" int selfocc_linear_wgrad(const float *dy, const float *x, float *dw, 
     float *part_w = (float *)workspace, *part_b = part_w + (size_t)p.chunks * N * K;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)p.chunks, (unsigned)p.ngroups);
+    // round 3: bf16 three-way-split kernel (same results to float32 rounding); SELFOCC_LINEAR_B3=0 keeps the f32-MFMA one
+    static const bool use_b3 = !(getenv("SELFOCC_LINEAR_B3") && atoi(getenv("SELFOCC_LINEAR_B3")) == 0);
 #define SO_LAUNCH(KT_, NTW_)                                                                                       \
-    hipLaunchKernelGGL((linear_wgrad_kernel<KT_, NTW_>), grid, dim3(256), 0, st, dy, x, part_w, part_b, T, N, K,     \
-                       p.rows_per_block)
+    do {                                                                                                          \
+        if (use_b3 && KT_ <= 3)                                                                                   \
+            hipLaunchKernelGGL((linear_wgrad_b3_kernel<KT_, NTW_>), grid, dim3(256), 0, st, dy, x, part_w, part_b, T, N, K, \
+                               p.rows_per_block);                                                                 \
+        else                                                                                                      \
+            hipLaunchKernelGGL((linear_wgrad_kernel<KT_, NTW_>), grid, dim3(256), 0, st, dy, x, part_w, part_b, T, N, K,  \
+                               p.rows_per_block);                                                                 \
+    } while (0)
     switch (p.kt) {
         case 1: SO_LAUNCH(1, 4); break;
         case 2: SO_LAUNCH(2, 4); break;
