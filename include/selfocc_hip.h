@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SELFOCC_ABI_VERSION 24
+#define SELFOCC_ABI_VERSION 25
 
 int selfocc_abi_version(void);
 const char *selfocc_last_error(void);
@@ -480,6 +480,18 @@ int selfocc_linear_fwd(const float *x, const float *w, const float *bias, const 
  * nv >= 16, T a multiple of nv, T * N < 2^31.  flags: SO_LINEAR_RELU. */
 int selfocc_linear_fwd_heads(const float *x, const float *w, const float *bias, float *y, int64_t T, int32_t N, int32_t K,
                              int32_t nv, uint32_t flags, void *stream);
+
+/* Input gradient of a tall Linear: dx (T, K) = dy (T, N) W (N, K), W as nn.Linear stores it (out_features N x in_features K).
+ * Replaces the `grad_output @ weight` GEMM torch's autograd runs for every nn.Linear of the encoder
+ * (/root/reference/model/encoder/tpvformer/tpvformer_encoder.py:257-291 -> mmcv FFN / MSDeformableAttention projections,
+ * /root/reference/model/encoder/tpvformer/attention/image_cross_attention.py:296-345); same bf16 three-way split as
+ * selfocc_linear_fwd (float32-level accuracy); W is split and transposed into `workspace` first (one tiny launch), the
+ * reduction over N then runs in 32-wide steps with dy streamed once.
+ * supported: N % 8 == 0, 8 <= N <= 4096; K in {96, 192, 288, 384}.  Returns 0 / SELFOCC_ERR_*. */
+int selfocc_linear_dgrad_supported(int64_t T, int32_t N, int32_t K);
+size_t selfocc_linear_dgrad_workspace(int32_t N, int32_t K);   /* bytes: the three bf16 planes of W^T, 16-byte aligned */
+int selfocc_linear_dgrad(const float *dy, const float *w, float *dx, int64_t T, int32_t N, int32_t K, void *workspace,
+                         int64_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Fused temporal reprojection photometric term.  Replaces the per-sample part of

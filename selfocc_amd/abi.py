@@ -6,7 +6,7 @@ its exported symbols being callable with these layouts.
 """
 import ctypes as C
 
-ABI_VERSION = 24
+ABI_VERSION = 25
 
 # enums ---------------------------------------------------------------------------
 RAYS_EXPLICIT, RAYS_PIXEL_GRID = 0, 1
@@ -135,6 +135,9 @@ SYMBOLS = {
     "selfocc_linear_fwd_supported": (C.c_int, [C.c_int64, _i, _i]),
     "selfocc_linear_fwd": (C.c_int, [_p] * 4 + [_i, _p, _p, C.c_float, _p, _i, _p, _p, _p, C.c_int64, _i, _i, C.c_uint32, _p]),
     "selfocc_linear_fwd_heads": (C.c_int, [_p] * 4 + [C.c_int64, _i, _i, _i, C.c_uint32, _p]),
+    "selfocc_linear_dgrad_supported": (C.c_int, [C.c_int64, _i, _i]),
+    "selfocc_linear_dgrad_workspace": (C.c_size_t, [_i, _i]),
+    "selfocc_linear_dgrad": (C.c_int, [_p] * 3 + [C.c_int64, _i, _i, _p, C.c_int64, _p]),
     "selfocc_ssim_fwd": (C.c_int, [_p] * 4 + [_i] * 4 + [_p, _p]),
     "selfocc_ssim_bwd": (C.c_int, [_p] * 4 + [_i] * 4 + [_p, _p, _p, _p]),
     "selfocc_reproj_fwd": (C.c_int, [C.POINTER(SoReprojArgs), _p]),

@@ -22,6 +22,8 @@
 #include "so_device.h"
 #include <hip/hip_bf16.h>
 #include <algorithm>
+#include <atomic>
+#include <cstdlib>
 
 namespace {
 
@@ -203,6 +205,185 @@ __global__ __launch_bounds__(kFieldFwdWaves * 64) void field_volume_kernel(Field
                 a.sdf[mm] = val;
             } else if (n - 1 < a.feat_stride) {
                 const float f = n < a.out_dim ? val : 0.0f;   // padding channels of the feature volume
+                if (BF16) ((__hip_bfloat16 *)a.feat)[(size_t)mm * a.feat_stride + (n - 1)] = __float2bfloat16(f);
+                else ((float *)a.feat)[(size_t)mm * a.feat_stride + (n - 1)] = f;
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// The same forward with both GEMMs on the bf16 matrix pipe through the exact three-way split of linear_fwd.hip (round 3;
+// C = 96, one hidden layer).  f32 MFMA on gfx950 executes at the vector rate and competes with the 96 + 96 Softplus
+// evaluations per voxel for the same lanes; v_mfma_f32_32x32x16_bf16 does 16 x the rate on the matrix pipe.  Every operand
+// is the exact sum of three bfloat16 and the six products with i + j <= 4 are accumulated in float32: float32-level
+// accuracy (tests/test_field_gpu.py unchanged), 2.67 x fewer matrix-pipe cycles.  The transposed chain survives as is:
+//   hidden layer  Y^T = W1 X^T: A = W1 (three bf16 planes in LDS, lane (unit i, kb) reads W1[32 ct + i][48 kb + 8 s ..+8]),
+//                 B = the lane's own Softplus(x) run x[voxel i][48 half + 8 s ..+8], s < 6 (k labelling free, as before);
+//   result        acc[ct][v] = y[voxel i][unit 32 ct + 8 (v >> 2) + 4 half + (v & 3)] — so the 8 hidden units a lane owns
+//                 for output step (ct, p) are acc[ct][8 p .. 8 p + 7]: consecutive registers = the A operand of the output
+//                 layer, W2 (three planes) read from LDS at units 32 ct + 16 p + 4 half + {0..3, 8..11}.
+constexpr int kFieldB3Waves = 12, kFieldB3KPB = 104;
+typedef __bf16 bf16x8f __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4f __attribute__((ext_vector_type(4)));
+
+SO_DEVFN void so_fsplit3(const float (&x)[8], bf16x8f &a1, bf16x8f &a2, bf16x8f &a3) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 b1 = (__bf16)x[j];
+        const float r1 = x[j] - (float)b1;
+        const __bf16 b2 = (__bf16)r1;
+        const float r2 = r1 - (float)b2;
+        a1[j] = b1; a2[j] = b2; a3[j] = (__bf16)r2;
+    }
+}
+
+template <bool BF16>
+__global__ __launch_bounds__(kFieldB3Waves * 64) void field_volume_b3_kernel(FieldArgs a) {
+    constexpr int C = 96, KS = 48, NT = 3, KPB = kFieldB3KPB, THREADS = kFieldB3Waves * 64;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    __bf16 *w1b = (__bf16 *)smem;                          // [3 planes][96 units][KPB]
+    __bf16 *w2b = w1b + (size_t)3 * C * KPB;               // [3 planes][32 outputs][KPB] (zero rows beyond out_dim)
+    float *b1s = (float *)(w2b + (size_t)3 * 32 * KPB);    // [96]
+    float *w2r = b1s + C;                                  // [96] row 0 of W2 in float32 (the SDF-only dot)
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, half = lane >> 5;
+
+    for (int e = threadIdx.x; e < (C + 32) * (C / 8); e += THREADS) {
+        const int r = e / (C / 8), k8 = e - r * (C / 8);
+        const float *src = r < C ? a.w_hidden + (size_t)r * C : (r - C < a.out_dim ? a.w_out + (size_t)(r - C) * C : nullptr);
+        float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (src) {
+            const float4 lo = ((const float4 *)src)[2 * k8], hi = ((const float4 *)src)[2 * k8 + 1];
+            v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+        }
+        bf16x8f p1, p2, p3;
+        so_fsplit3(v, p1, p2, p3);
+        __bf16 *dst = r < C ? w1b + (size_t)r * KPB : w2b + (size_t)(r - C) * KPB;
+        const size_t ps = r < C ? (size_t)C * KPB : (size_t)32 * KPB;
+        *(bf16x8f *)(dst + 8 * k8) = p1;
+        *(bf16x8f *)(dst + ps + 8 * k8) = p2;
+        *(bf16x8f *)(dst + 2 * ps + 8 * k8) = p3;
+    }
+    for (int e = threadIdx.x; e < C; e += THREADS) { b1s[e] = a.b_hidden[e]; w2r[e] = a.w_out[e]; }
+    __syncthreads();
+
+    for (int tile = blockIdx.x * kFieldB3Waves + wave; tile < a.n_tiles; tile += gridDim.x * kFieldB3Waves) {
+        const unsigned m = (unsigned)tile * 32u + (unsigned)i;
+        const unsigned mc = m < (unsigned)a.M ? m : (unsigned)a.M - 1u;
+        const unsigned hwi = mc / (unsigned)a.D;
+        const unsigned d = mc - hwi * (unsigned)a.D;
+        const unsigned h = hwi / (unsigned)a.W, w = hwi - h * (unsigned)a.W;
+        const float4 *p0 = (const float4 *)(a.hw + (size_t)hwi * C + half * KS);
+        const float4 *p1 = (const float4 *)(a.zh + ((size_t)d * a.H + h) * C + half * KS);
+        const float4 *p2 = (const float4 *)(a.wz + ((size_t)w * a.D + d) * C + half * KS);
+        // hidden layer, transposed: acc[ct][v] = y[voxel i][unit 32 ct + 8 (v >> 2) + 4 half + (v & 3)].  Per 8-k step: the
+        // lane's Softplus(hw + zh + wz) run (voxel i, inputs 48 half + 8 s ..+8) is split once and used by the three unit tiles
+        f32x16 acc[NT];
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[ct][v] = 0.0f;
+        const __bf16 *abase = w1b + (size_t)i * KPB + half * KS;
+        float4 xn[6];       // the next step's three plane rows (2 float4 each): one step of prefetch, no more (registers)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { xn[q] = p0[q]; xn[2 + q] = p1[q]; xn[4 + q] = p2[q]; }
+#pragma unroll
+        for (int s = 0; s < 6; ++s) {
+            float xv[8];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float4 x0 = xn[q], x1 = xn[2 + q], x2 = xn[4 + q];
+                xv[4 * q + 0] = so_softplus((x0.x + x1.x) + x2.x);
+                xv[4 * q + 1] = so_softplus((x0.y + x1.y) + x2.y);
+                xv[4 * q + 2] = so_softplus((x0.z + x1.z) + x2.z);
+                xv[4 * q + 3] = so_softplus((x0.w + x1.w) + x2.w);
+            }
+            if (s < 5) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q) { xn[q] = p0[2 * s + 2 + q]; xn[2 + q] = p1[2 * s + 2 + q]; xn[4 + q] = p2[2 * s + 2 + q]; }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            bf16x8f xb1, xb2, xb3;
+            so_fsplit3(xv, xb1, xb2, xb3);
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+                const __bf16 *ap = abase + (size_t)(32 * ct) * KPB + 8 * s;
+                const bf16x8f a1 = *(const bf16x8f *)ap, a2 = *(const bf16x8f *)(ap + (size_t)C * KPB),
+                              a3 = *(const bf16x8f *)(ap + (size_t)2 * C * KPB);
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, xb1, acc[ct], 0, 0, 0);      // small terms first
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xb3, acc[ct], 0, 0, 0);
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, xb2, acc[ct], 0, 0, 0);
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, xb1, acc[ct], 0, 0, 0);
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xb2, acc[ct], 0, 0, 0);
+                acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, xb1, acc[ct], 0, 0, 0);
+            }
+        }
+        if (a.out_dim == 1) {      // SDF only (the depth configs): 48 fmas + one exchange, as in the f32 kernel
+            float dot = 0.0f;
+#pragma unroll
+            for (int ct = 0; ct < NT; ++ct) {
+#pragma unroll
+                for (int aa = 0; aa < 4; ++aa) {
+                    const int u0 = 32 * ct + 8 * aa + 4 * half;
+                    const float4 bb = *(const float4 *)(b1s + u0);
+                    const float4 w2 = *(const float4 *)(w2r + u0);
+                    dot = fmaf(so_softplus(acc[ct][4 * aa + 0] + bb.x), w2.x, dot);
+                    dot = fmaf(so_softplus(acc[ct][4 * aa + 1] + bb.y), w2.y, dot);
+                    dot = fmaf(so_softplus(acc[ct][4 * aa + 2] + bb.z), w2.z, dot);
+                    dot = fmaf(so_softplus(acc[ct][4 * aa + 3] + bb.w), w2.w, dot);
+                }
+            }
+            dot += __shfl_xor(dot, 32, 64);
+            if (half == 0 && m < (unsigned)a.M) a.sdf[m] = dot + a.b_out[0];
+            continue;
+        }
+        // output layer: o[voxel][channel] += z[voxel][unit] W2[channel][unit]; step (ct, p): the lane's units acc[ct][8 p ..+8]
+        f32x16 o;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) o[v] = 0.0f;
+        const __bf16 *w2row = w2b + (size_t)i * KPB + 4 * half;
+#pragma unroll
+        for (int ct = 0; ct < NT; ++ct) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                float z[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int v = 8 * p + j, u = 32 * ct + 8 * (v >> 2) + 4 * half + (v & 3);
+                    z[j] = so_softplus(acc[ct][v] + b1s[u]);
+                }
+                bf16x8f z1, z2, z3;
+                so_fsplit3(z, z1, z2, z3);
+                bf16x8f wq[3];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    const __bf16 *wp = w2row + (size_t)pl * 32 * KPB + 32 * ct + 16 * p;
+                    const bf16x4f lo = *(const bf16x4f *)wp, hi = *(const bf16x4f *)(wp + 8);
+                    wq[pl][0] = lo[0]; wq[pl][1] = lo[1]; wq[pl][2] = lo[2]; wq[pl][3] = lo[3];
+                    wq[pl][4] = hi[0]; wq[pl][5] = hi[1]; wq[pl][6] = hi[2]; wq[pl][7] = hi[3];
+                }
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(z3, wq[0], o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(z1, wq[2], o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(z2, wq[1], o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(z2, wq[0], o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(z1, wq[1], o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(z1, wq[0], o, 0, 0, 0);
+            }
+        }
+        const int n = i;
+        const float bias = n < a.out_dim ? a.b_out[n] : 0.0f;
+#pragma unroll
+        for (int v = 0; v < 16; ++v) {
+            const int r = (v & 3) + 8 * (v >> 2) + 4 * half;
+            const long long mm = (long long)tile * 32 + r;
+            if (mm >= a.M) continue;
+            const float val = o[v] + bias;
+            if (n == 0) {
+                a.sdf[mm] = val;
+            } else if (n - 1 < a.feat_stride) {
+                const float f = n < a.out_dim ? val : 0.0f;
                 if (BF16) ((__hip_bfloat16 *)a.feat)[(size_t)mm * a.feat_stride + (n - 1)] = __float2bfloat16(f);
                 else ((float *)a.feat)[(size_t)mm * a.feat_stride + (n - 1)] = f;
             }
@@ -525,12 +706,29 @@ extern "C" int selfocc_field_volume_fwd(const float *hw, const float *zh, const 
     SO_REQUIRE(M < (1LL << 31) - 64, "field_volume: volume too large");
     FieldArgs a{hw, zh, wz, H, W, D, w_hidden, b_hidden, w_out, b_out, n_hidden, out_dim, sdf, feat, feat_stride, M,
                 (int)((M + 31) / 32)};
+    hipStream_t st = (hipStream_t)stream;
+    // round 3: both GEMMs on the bf16 matrix pipe (exact three-way split); SELFOCC_FIELD_B3=0 keeps the f32-MFMA kernel
+    static const bool use_b3 = !(getenv("SELFOCC_FIELD_B3") && atoi(getenv("SELFOCC_FIELD_B3")) == 0);
+    if (use_b3 && C == 96 && n_hidden == 1) {
+        const size_t shm3 = (size_t)3 * (96 + 32) * kFieldB3KPB * 2 + 2 * 96 * sizeof(float);
+        const int blocks3 = std::min((a.n_tiles + kFieldB3Waves - 1) / kFieldB3Waves, 256);      // one 12-wave block per CU
+        static std::atomic<unsigned long long> done3{0};
+        int dev3 = 0;
+        (void)hipGetDevice(&dev3);
+        if (!(done3.load(std::memory_order_relaxed) & (1ull << (dev3 & 63)))) {
+            (void)hipFuncSetAttribute((const void *)field_volume_b3_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            (void)hipFuncSetAttribute((const void *)field_volume_b3_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+            done3.fetch_or(1ull << (dev3 & 63), std::memory_order_relaxed);
+        }
+        if (feat_dtype == SO_DTYPE_BF16) hipLaunchKernelGGL(field_volume_b3_kernel<true>, dim3(blocks3), dim3(kFieldB3Waves * 64), shm3, st, a);
+        else hipLaunchKernelGGL(field_volume_b3_kernel<false>, dim3(blocks3), dim3(kFieldB3Waves * 64), shm3, st, a);
+        return so_launch_status();
+    }
     const int nw = kFieldFwdWaves;
     const size_t shm = ((size_t)(C + 32) * (C + 4) + C) * sizeof(float);
     // persistent blocks: as many as the LDS of a CU holds (52 KB each at C = 96 -> 3 per CU), at most one tile each
     const int per_cu = std::max(1, std::min(4, (int)((160 * 1024) / (shm + 1024))));
     const int blocks = std::min((a.n_tiles + nw - 1) / nw, 256 * per_cu);
-    hipStream_t st = (hipStream_t)stream;
 #define SO_LAUNCH(CC, BF)                                                                                    \
     {                                                                                                        \
         /* per launch: the attribute is per device (a process may drive several GPUs) */                     \

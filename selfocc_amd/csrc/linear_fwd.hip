@@ -410,6 +410,180 @@ __global__ __launch_bounds__(WAVES * 64) void linear_fwd_b3_kernel(LinearFwdArgs
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Input gradient of a tall Linear, dx = dy W (round 3: the training encoder's dgrad GEMMs, 2.7 ms per iteration on the
+// vendor library), on the b3 scheme without LDS:
+//   1. linear_dgrad_split_kernel: W (N, K) as stored -> three bf16 planes [p][column c < K][k < Npad] (transposed: the B
+//      operand wants 8 consecutive reduction indices per lane; zero beyond N), <= 442 KB, one tiny launch;
+//   2. linear_dgrad_b3_kernel: a wave owns 32 rows x 96 columns and walks the reduction in 32-wide steps; dy streams from
+//      HBM straight into the A operand (split in registers), the B operand's three planes come from global memory — every
+//      wave of the chip reads the same <= 442 KB, so they are vector-L1 / L2 hits (18 KB per step and wave: ~1/2 of the L1 rate
+//      the MFMAs of the step leave room for).  No staging, no barriers: the first version of this kernel staged 96-wide chunks
+//      of W through LDS and was a chain of load -> barrier -> stage -> barrier -> MFMA latencies (63 us at 66 049 x 384 x 96
+//      where the dy stream takes 16).
+__global__ __launch_bounds__(256) void linear_dgrad_split_kernel(const float *w, __bf16 *planes, int N, int K, int Npad) {
+    const int nk8 = Npad / 8;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < K * nk8; idx += gridDim.x * 256) {
+        const int k8 = idx / K, c = idx - k8 * K;                 // consecutive threads: consecutive columns (coalesced reads)
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int kk = 8 * k8 + j;
+            v[j] = kk < N ? w[(size_t)kk * K + c] : 0.0f;
+        }
+        bf16x8 w1, w2, w3;
+        so_split3(v, w1, w2, w3);
+        const size_t o = (size_t)c * Npad + 8 * k8, ps = (size_t)K * Npad;
+        *(bf16x8 *)(planes + o) = w1;
+        *(bf16x8 *)(planes + ps + o) = w2;
+        *(bf16x8 *)(planes + 2 * ps + o) = w3;
+    }
+}
+
+struct LinearDgradArgs {
+    const float *dy;         // (T, N)
+    const __bf16 *planes;    // [3][K][Npad], Npad = 96 nchunks
+    float *dx;               // (T, K)
+    long long T;
+    int N, K, Npad, groups;
+};
+
+// Work items = (32-row tile of the wave, 96-wide chunk of the reduction), walked in order by the block's four waves together.
+// Before the MFMAs of item i every lane issues the dy loads of item i + 1, so that the HBM stream and the matrix pipe overlap
+// inside one wave; the chunk's planes are copied from L2 between two barriers, which the CU's other block (60 KB of LDS each)
+// covers with its MFMAs.
+template <int DUMMY>
+__global__ __launch_bounds__(256) void linear_dgrad_b3_kernel(LinearDgradArgs a) {
+    constexpr int KC = 96, KS = 3, KPB = KC + 8, NT16 = 6, NCOL = 96, WAVES = 4, THREADS = 256;
+    constexpr int NST = (3 * NCOL * (KC / 8) + THREADS - 1) / THREADS;     // 16-byte staging copies per thread and chunk: 14
+    extern __shared__ __attribute__((aligned(16))) __bf16 wb[];            // [3][NCOL][KPB]
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int n = lane & 15, kb = lane >> 4;
+    const unsigned logical = so_lin_xcd_block();
+    const int ncb = a.K / 96;
+    const int cb = __builtin_amdgcn_readfirstlane((int)(logical % (unsigned)ncb));
+    const long long rc = __builtin_amdgcn_readfirstlane((int)(logical / (unsigned)ncb));
+    const int n0 = cb * 96;
+    const long long nwt = (a.T + 31) / 32, wt_step = (long long)WAVES * a.groups;
+    const int nchunks = a.Npad / KC;
+    const long long npass = (nwt - rc * WAVES + wt_step - 1) / wt_step;    // passes of this block (uniform), >= 1 by the grid size
+    const long long nitems = npass * nchunks;
+    const size_t ps = (size_t)a.K * a.Npad;
+
+    float xc[2][KS][8], xn[2][KS][8];
+    auto tile_row0 = [&](long long pass) { return min(rc * WAVES + pass * wt_step + wave, nwt - 1) * 32; };
+    auto load_item = [&](long long it) {            // dy run of item it -> xn
+        const long long pass = it / nchunks;
+        const int c = (int)(it - pass * nchunks), k0 = c * KC;
+        const long long row0 = tile_row0(pass);
+        const int rem = (int)min(32LL, a.T - row0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float *xb = a.dy + (row0 + min(16 * h + n, rem - 1)) * a.N + k0 + 8 * kb;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                float4 lo = make_float4(0.f, 0.f, 0.f, 0.f), hi = lo;
+                if (k0 + 32 * ks + 8 * kb < a.N) { lo = *(const float4 *)(xb + 32 * ks); hi = *(const float4 *)(xb + 32 * ks + 4); }
+                xn[h][ks][0] = lo.x; xn[h][ks][1] = lo.y; xn[h][ks][2] = lo.z; xn[h][ks][3] = lo.w;
+                xn[h][ks][4] = hi.x; xn[h][ks][5] = hi.y; xn[h][ks][6] = hi.z; xn[h][ks][7] = hi.w;
+            }
+        }
+    };
+    load_item(0);
+    f32x4 acc[2][NT16];
+    const float zero6[NT16] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const bool cok[NT16] = {true, true, true, true, true, true};
+    for (long long it = 0; it < nitems; ++it) {
+        const long long pass = it / nchunks;
+        const int c = (int)(it - pass * nchunks);
+        if (nchunks > 1 || it == 0) {
+            __syncthreads();                         // the previous chunk's B reads are done
+            // the chunk's planes: 3 x 96 x 12 16-byte runs, straight copies (L2 hits: every block of the chip reads the same)
+#pragma unroll 2
+            for (int j0 = 0; j0 < NST; j0 += 7) {
+                bf16x8 sv[7];
+                int so[7];
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    const int idx = min((int)threadIdx.x + (j0 + j) * THREADS, 3 * NCOL * (KC / 8) - 1);
+                    const int pl = idx / (NCOL * (KC / 8)), rem = idx - pl * (NCOL * (KC / 8));
+                    const int r = rem / (KC / 8), k8 = rem - r * (KC / 8);
+                    sv[j] = *(const bf16x8 *)(a.planes + pl * ps + (size_t)(n0 + r) * a.Npad + c * KC + 8 * k8);
+                    so[j] = (pl * NCOL + r) * KPB + 8 * k8;
+                }
+#pragma unroll
+                for (int j = 0; j < 7; ++j) *(bf16x8 *)(wb + so[j]) = sv[j];      // (the clamped tail rewrites the last run)
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) xc[h][ks][j] = xn[h][ks][j];
+        if (it + 1 < nitems) load_item(it + 1);
+        if (c == 0) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int t = 0; t < NT16; ++t)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[h][t][j] = 0.0f;
+        }
+        const __bf16 *bbase = wb + (size_t)n * KPB + 8 * kb;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 a1[2], a2[2], a3[2];
+            so_split3(xc[0][ks], a1[0], a2[0], a3[0]);
+            so_split3(xc[1][ks], a1[1], a2[1], a3[1]);
+#pragma unroll
+            for (int t = 0; t < NT16; ++t) {
+                const __bf16 *bp = bbase + (size_t)(16 * t) * KPB + 32 * ks;
+                const bf16x8 b1 = *(const bf16x8 *)bp, b2 = *(const bf16x8 *)(bp + (size_t)NCOL * KPB),
+                             b3 = *(const bf16x8 *)(bp + (size_t)2 * NCOL * KPB);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {      // small terms first
+                    acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[h], b1, acc[h][t], 0, 0, 0);
+                    acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[h], b3, acc[h][t], 0, 0, 0);
+                    acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[h], b2, acc[h][t], 0, 0, 0);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[h], b1, acc[h][t], 0, 0, 0);
+                    acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[h], b2, acc[h][t], 0, 0, 0);
+                    acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[h], b1, acc[h][t], 0, 0, 0);
+                }
+            }
+        }
+        if (c != nchunks - 1) continue;
+        const long long wt = rc * WAVES + pass * wt_step + wave;
+        if (wt >= nwt) continue;
+        const long long row0 = wt * 32;
+        const int rem = (int)min(32LL, a.T - row0);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long long r0 = row0 + 16 * h;
+            const int rm = rem - 16 * h;
+            if (rm <= 0) break;
+            const int rmc = min(rm, 16);
+            float *yb = a.dx + r0 * a.K + n0;
+            int no = n;
+            asm volatile("" : "+v"(no));
+            if (rmc == 16)
+                so_linear_epilogue16<false, true, NT16>(acc[h], zero6, zero6, zero6, cok, -__builtin_huge_valf(), nullptr, 0, yb, a.K,
+                                                        nullptr, nullptr, nullptr, a.K, 0.0f, rmc, no, kb);
+            else
+                so_linear_epilogue16<false, false, NT16>(acc[h], zero6, zero6, zero6, cok, -__builtin_huge_valf(), nullptr, 0, yb, a.K,
+                                                         nullptr, nullptr, nullptr, a.K, 0.0f, rmc, no, kb);
+        }
+    }
+}
+
+bool so_linear_dgrad_ok(long long T, int N, int K) {     // N = the layer's output features (reduced), K = its input features
+    return T >= 1 && T < (1LL << 40) && N >= 8 && N % 8 == 0 && N <= 4096 && K >= 96 && K % 96 == 0 && K <= 384;
+}
+
 bool so_linear_fwd_ok(long long T, int N, int K) {
     if (!(K == 32 || K == 64 || K == 96 || K == 128 || K == 192)) return false;
     return T >= 1 && N >= 1 && (long long)N * K < (1LL << 30) && T < (1LL << 40);
@@ -564,4 +738,45 @@ extern "C" int selfocc_linear_fwd_heads(const float *x, const float *w, const fl
     SO_REQUIRE((long long)T * N < (1LL << 31), "linear_fwd_heads: output too large for 32-bit offsets");
     return so_linear_fwd_launch(x, w, bias, nullptr, 0, nullptr, nullptr, 0.0f, y, N, nullptr, nullptr, nullptr, T, N, K, flags, nv,
                                 stream);
+}
+
+// dx = dy W for a tall Linear (the input gradient; replaces the `dy @ weight` GEMM of torch.nn.functional.linear's backward
+// on the encoder's projections, /root/reference/model/encoder/tpvformer/tpvformer_encoder.py:257-291 runs them under autograd)
+extern "C" int selfocc_linear_dgrad_supported(int64_t T, int32_t N, int32_t K) { return so_linear_dgrad_ok(T, N, K) ? 1 : 0; }
+
+extern "C" size_t selfocc_linear_dgrad_workspace(int32_t N, int32_t K) {
+    return (size_t)3 * K * ((N + 95) / 96 * 96) * 2;
+}
+
+extern "C" int selfocc_linear_dgrad(const float *dy, const float *w, float *dx, int64_t T, int32_t N, int32_t K, void *workspace,
+                                    int64_t workspace_bytes, void *stream) {
+    SO_REQUIRE(so_linear_dgrad_ok(T, N, K), "linear_dgrad: unsupported shape (T = %lld rows, N = %d reduced features (multiple of 8, "
+               "<= 4096), K = %d input features (96, 192, 288 or 384))", (long long)T, N, K);
+    SO_REQUIRE(dy && w && dx && workspace, "linear_dgrad: NULL pointer");
+    SO_REQUIRE(workspace_bytes >= (int64_t)selfocc_linear_dgrad_workspace(N, K), "linear_dgrad: workspace of %lld bytes, need %lld",
+               (long long)workspace_bytes, (long long)selfocc_linear_dgrad_workspace(N, K));
+    SO_REQUIRE(((uintptr_t)workspace & 15) == 0, "linear_dgrad: workspace must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    const int Npad = (N + 95) / 96 * 96;
+    hipLaunchKernelGGL(linear_dgrad_split_kernel, dim3((unsigned)std::min(256, (K * (Npad / 8) + 255) / 256)), dim3(256), 0, st, w,
+                       (__bf16 *)workspace, N, K, Npad);
+    LinearDgradArgs a;
+    a.dy = dy; a.planes = (const __bf16 *)workspace; a.dx = dx; a.T = T; a.N = N; a.K = K; a.Npad = Npad;
+    const int ncb = K / 96;
+    const long long nwt = (T + 31) / 32;
+    static const int percu = getenv("SELFOCC_DGRAD_PERCU") ? atoi(getenv("SELFOCC_DGRAD_PERCU")) : 2;      // dev A/B
+    long long groups = std::max<long long>(1, 256 * percu / ncb);
+    groups = std::min<long long>(groups, (nwt + 3) / 4);
+    a.groups = (int)groups;
+    const size_t lds = (size_t)3 * 96 * (96 + 8) * 2;
+    static std::atomic<unsigned long long> done_mask{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done_mask.load(std::memory_order_relaxed) & bit)) {
+        (void)hipFuncSetAttribute((const void *)linear_dgrad_b3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        done_mask.fetch_or(bit, std::memory_order_relaxed);
+    }
+    hipLaunchKernelGGL(linear_dgrad_b3_kernel<0>, dim3((unsigned)(groups * ncb)), dim3(256), lds, st, a);
+    return so_launch_status();
 }

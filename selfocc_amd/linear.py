@@ -26,6 +26,26 @@ def linear_wgrad(dy, x, with_bias=True):
     return dw, db
 
 
+def dgrad_supported(rows, n_out, n_in):
+    return lib().selfocc_linear_dgrad_supported(int(rows), int(n_out), int(n_in)) == 1
+
+
+def linear_dgrad(dy, weight):
+    """dx (T, K) = dy (T, N) @ weight (N, K), float32 CUDA(HIP) (csrc/linear_fwd.hip, linear_dgrad_b3_kernel)."""
+    if not dy.is_cuda:
+        raise RuntimeError("linear_dgrad needs CUDA(HIP) tensors: selfocc_amd has no CPU fallback")
+    T, N = dy.shape
+    K = weight.shape[1]
+    assert weight.shape[0] == N and dy.dtype == torch.float32 and weight.dtype == torch.float32
+    dy, weight = dy.contiguous(), weight.contiguous()
+    dx = torch.empty(T, K, device=dy.device, dtype=torch.float32)
+    nbytes = int(lib().selfocc_linear_dgrad_workspace(N, K))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dy.device)
+    check(lib().selfocc_linear_dgrad(ptr(dy), ptr(weight), ptr(dx), T, N, K, ptr(ws), nbytes, current_stream(dy.device)),
+          "selfocc_linear_dgrad")
+    return dx
+
+
 def linear_fwd_supported(rows, n_out, n_in):
     return lib().selfocc_linear_fwd_supported(int(rows), int(n_out), int(n_in)) == 1
 

@@ -10,7 +10,7 @@ import torch
 import torch.nn as nn
 
 from ..registry import MODELS
-from ..linear import (linear_wgrad, wgrad_supported, linear_fwd, linear_fwd_supported, linear_fwd_heads,
+from ..linear import (linear_wgrad, wgrad_supported, linear_fwd, linear_fwd_supported, linear_fwd_heads, linear_dgrad, dgrad_supported,
                       linear_fwd_heads_supported)
 from ..msda import (MultiScaleDeformableAttnFunction, msda_fused_inference, MSDAFusedFunction, to_head_major,
                     msda_pro_supported, msda_pro_inference,
@@ -114,6 +114,9 @@ def build_activation_layer(cfg):
 
 # weight / bias gradients of _TallLinear through selfocc_linear_wgrad (False: batched GEMMs + torch reductions, A/B)
 FUSED_WGRAD = True
+# input gradient of the tall Linears on the bf16x3 kernel (csrc/linear_fwd.hip, selfocc_linear_dgrad) instead of the vendor GEMM
+FUSED_DGRAD = os.environ.get('SELFOCC_LINEAR_DGRAD', '1') == '1'
+DGRAD_MIN_ROWS = 32768      # below: too few 32-row tiles for 1 024 SIMDs, the vendor GEMM splits the reduction
 # forward of the tall projections (and, in inference, the residual add / LayerNorm that follow them) through
 # selfocc_linear_fwd (csrc/linear_fwd.hip); False: torch.addmm + separate elementwise kernels (A/B)
 FUSED_LINEAR_FWD = os.environ.get('SELFOCC_FUSED_LINEAR', '1') == '1'
@@ -143,6 +146,31 @@ def value_proj_head_major(lin_weight, lin_bias, value2d, nv, num_heads):
             return None
         return _TallLinearHeads.apply(value2d, lin_weight, lin_bias, nv)
     return linear_fwd_heads(value2d, lin_weight, lin_bias, nv)
+
+
+# training: the three TPV planes' value projections of the same image features as ONE projection / ONE backward
+# (_TallLinearHeadsMulti): the 59 MB input is read once per layer instead of three times in each direction, one input
+# gradient instead of three + two accumulations (env SELFOCC_MERGED_VALUE_PROJ_TRAIN=0: per plane, as round 2)
+MERGED_VALUE_PROJ_TRAIN = os.environ.get('SELFOCC_MERGED_VALUE_PROJ_TRAIN', '1') == '1'
+
+
+def value_proj_head_major_multi(lins, value2d, nv, num_heads):
+    """[(B, 6, nv, 16)] * G: the head-major projections of (B * nv, K) rows through G nn.Linear(K, 96) in one launch
+    under autograd, or None when the shape / mode does not qualify (the caller then projects per plane)."""
+    if not (HEAD_MAJOR_PROJ and HEAD_MAJOR_PROJ_TRAIN and MERGED_VALUE_PROJ_TRAIN and FUSED_LINEAR_FWD
+            and not torch.is_autocast_enabled() and torch.is_grad_enabled() and value2d.is_cuda
+            and value2d.dtype == torch.float32 and num_heads == 6):
+        return None
+    K = value2d.shape[1]
+    if any(l.bias is None or tuple(l.weight.shape) != (96, K) or l.weight.dtype != torch.float32 for l in lins):
+        return None
+    rows = value2d.shape[0]
+    if rows < LINEAR_FWD_MIN_ROWS or not linear_fwd_heads_supported(rows, 96 * len(lins), K, nv):
+        return None
+    if not (value2d.requires_grad or any(l.weight.requires_grad for l in lins)):
+        return None
+    wb = [t for l in lins for t in (l.weight, l.bias)]
+    return list(_TallLinearHeadsMulti.apply(value2d, nv, *wb))
 
 
 def _linear_fwd_ok(x2d, weight):
@@ -213,6 +241,13 @@ class _TallLinear(torch.autograd.Function):
         return _tall_linear_backward(x, weight, dy, ctx.has_bias)
 
 
+def _dgrad(dy, weight):
+    if (FUSED_DGRAD and dy.is_cuda and dy.dtype == torch.float32 and dy.shape[0] >= DGRAD_MIN_ROWS
+            and dgrad_supported(dy.shape[0], weight.shape[0], weight.shape[1])):
+        return linear_dgrad(dy, weight)
+    return dy @ weight
+
+
 def _tall_linear_backward(x, weight, dy, has_bias):
         """(dx, dW, db) of y = x W^T + b for a row-major dy (shared by _TallLinear and _TallLinearHeads)."""
         dy = dy.contiguous().to(x.dtype)
@@ -221,7 +256,7 @@ def _tall_linear_backward(x, weight, dy, has_bias):
                 and wgrad_supported(T, dy.shape[1], x.shape[1])):
             # one MFMA pass over dy and x for dW and db (csrc/linear.hip) instead of batched GEMMs + two reductions
             dw, db = linear_wgrad(dy, x, has_bias)
-            return dy @ weight, dw, db
+            return _dgrad(dy, weight), dw, db
         G = max(1, min(256, T // 2048))  # ~2 k+ rows per batched GEMM: enough workgroups, small partial-sum tensor
         R = T // G                       # rows per batched GEMM
         Tp = R * G
@@ -244,6 +279,30 @@ def _tall_linear_backward(x, weight, dy, has_bias):
         return dy @ weight, dw, (db if has_bias else None)
 
 
+class _TallLinearReLU(torch.autograd.Function):
+    """relu(x W^T + b) as one node (the FFN's first layer): the forward is one selfocc_linear_fwd launch with the ReLU in
+    its epilogue; the backward masks dy with the saved output and continues as _TallLinear.  (nn.ReLU(inplace=True) on
+    the view _TallLinear returns costs autograd a CopySlices: four extra 60 MB copies and a fill per layer.)"""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, x, weight, bias):
+        if FUSED_LINEAR_FWD and _linear_fwd_ok(x, weight):
+            y = linear_fwd(x, weight, bias, relu=True)
+        else:
+            y = torch.relu(torch.addmm(bias, x, weight.t()) if bias is not None else x @ weight.t())
+        ctx.save_for_backward(x, weight, y)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        dy = torch.ops.aten.threshold_backward(dy.contiguous().to(y.dtype), y, 0)
+        return _tall_linear_backward(x, weight, dy, ctx.has_bias)
+
+
 class _TallLinearHeads(torch.autograd.Function):
     """value_proj with a HEAD-MAJOR result under autograd: forward = selfocc_linear_fwd_heads (the projection writes the
     (G, B, 6, nv, 16) layout the MSDA kernels gather fastest from, forward and backward point kernels alike); backward
@@ -263,6 +322,38 @@ class _TallLinearHeads(torch.autograd.Function):
         G, B, H, nv, d = dy_hm.shape
         dy = dy_hm.permute(1, 3, 0, 2, 4).reshape(B * nv, G * H * d)        # (b, pix, g, h, c): one transposing copy
         return (*_tall_linear_backward(x, weight, dy, ctx.has_bias), None)
+
+
+class _TallLinearHeadsMulti(torch.autograd.Function):
+    """G value projections of the SAME rows (the TPV planes' value_proj of one layer): one selfocc_linear_fwd_heads launch
+    with the stacked (G * 96, K) weight, one head-major tensor per group; backward = one weight-gradient and one
+    input-gradient pass over the row-major (rows, G * 96) gradient assembled from the G head-major ones."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, x, nv, *wb):
+        w = torch.cat(wb[0::2], 0)
+        b = torch.cat(wb[1::2], 0)
+        ctx.save_for_backward(x, w)
+        ctx.G = len(wb) // 2
+        return tuple(linear_fwd_heads(x, w, b, nv).unbind(0))
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, *gys):
+        x, w = ctx.saved_tensors
+        G = ctx.G
+        B, H, nv, d = next(g for g in gys if g is not None).shape
+        dy = x.new_empty(B, nv, G, H, d)                       # (b, pix, g, h, c): row-major (rows, G * 96)
+        for g, gy in enumerate(gys):
+            if gy is None:
+                dy[:, :, g].zero_()
+            else:
+                dy[:, :, g].copy_(gy.permute(0, 2, 1, 3))      # one transposing copy per group
+        dx, dw, db = _tall_linear_backward(x, w, dy.view(B * nv, G * H * d), True)
+        n = H * d
+        grads = [t for g in range(G) for t in (dw[g * n:(g + 1) * n], db[g * n:(g + 1) * n])]
+        return (dx, None, *grads)
 
 
 class TallLinear(nn.Linear):
@@ -318,7 +409,16 @@ class FFN(BaseModule):
         return post_norm(out) if post_norm is not None else out
 
     def _forward_plain(self, x, identity=None):
-        out = self.layers(x)
+        lin0 = self.layers[0][0]
+        rows = x.numel() // max(x.shape[-1], 1)
+        if (FUSED_FFN_RELU and self.num_fcs == 2 and torch.is_grad_enabled() and x.is_cuda and isinstance(lin0, TallLinear)
+                and isinstance(self.layers[0][1], nn.ReLU) and rows >= lin0.min_rows
+                and (x.requires_grad or lin0.weight.requires_grad)):
+            h = _TallLinearReLU.apply(x.reshape(rows, x.shape[-1]), lin0.weight, lin0.bias)
+            h = self.layers[0][2](h.view(*x.shape[:-1], lin0.weight.shape[0]))
+            out = self.layers[2](self.layers[1](h))
+        else:
+            out = self.layers(x)
         if not self.add_identity:
             return self.dropout_layer(out)
         if identity is None:
@@ -326,6 +426,8 @@ class FFN(BaseModule):
         return identity + self.dropout_layer(out)
 
 
+# training: the FFN's Linear + ReLU as one autograd node (_TallLinearReLU); env SELFOCC_FUSED_FFN_RELU=0: nn.Sequential
+FUSED_FFN_RELU = os.environ.get('SELFOCC_FUSED_FFN_RELU', '1') == '1'
 # training path of deformable_sampling: fused prologue + MSDA in both directions (msda.MSDAFusedFunction)
 FUSED_TRAINING = True
 # inference: the sampling_offsets / attention_weights Linears inside the sampling kernel's prologue (csrc/msda_pro.hip)

@@ -194,8 +194,9 @@ class BEVCrossAttention(BaseModule):
             slots = msda_pro_inference(v, spatial_shapes, level_start_index, reference_points_cams[:, 0], 1, query[0],
                                        da.sampling_offsets, da.attention_weights, L, P, hm, visible=visible)[None]
         else:
-            off = da.sampling_offsets(query[0]).view(-1, heads, L, P, 2)
-            logits = da.attention_weights(query[0]).view(-1, heads, L * P)
+            q2 = query.reshape(-1, query.shape[-1])   # bs == 1; a view, not query[0]: select's backward is a zero fill + a copy
+            off = da.sampling_offsets(q2).view(-1, heads, L, P, 2)
+            logits = da.attention_weights(q2).view(-1, heads, L * P)
             if host_shapes is None:
                 slots = msda_cross_inference(v, spatial_shapes, level_start_index, reference_points_cams[:, 0], visible,
                                              off, logits, hm)[None]
@@ -275,6 +276,17 @@ class TPVCrossAttention(BaseModule):
                     vpre = list(v_all.view(cams, l, 3, heads, C // heads).permute(2, 0, 3, 1, 4).contiguous())
                 else:
                     vpre = [v_all[..., i * C:(i + 1) * C] for i in range(3)]
+        elif (torch.is_grad_enabled() and value.is_cuda and query[0].shape[0] == 1 and value.shape[2] == 1
+              and all(a.camera_loop for a in self.attns)):
+            # training: the three planes' value projections of the same image features are one autograd node
+            # (bricks._TallLinearHeadsMulti): one projection, one weight / input gradient pass per layer
+            cams, l = value.shape[0], value.shape[1]
+            das = [a.deformable_attention for a in self.attns]
+            v3 = bricks.value_proj_head_major_multi([da.value_proj for da in das],
+                                                    value.permute(2, 0, 1, 3).reshape(cams * l, self.embed_dims), l,
+                                                    das[0].num_heads) if len({da.num_heads for da in das}) == 1 else None
+            if v3 is not None:
+                vpre = v3          # (cams, heads, l, d) each: `_forward_camera_loop` takes a 4-d value_pre as head-major
         return [self.attns[i](query[i], key, value, residual[i] if residual is not None else None,
                               spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                               reference_points_cams=reference_points_cams[i], bev_masks=tpv_masks[i],

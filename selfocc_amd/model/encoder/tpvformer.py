@@ -9,6 +9,7 @@ BEVFormerEncoder      <- model/encoder/bevformer/bevformer_encoder.py:18-224
 Same registry names, constructor kwargs, buffers / parameter names and forward contracts.
 """
 import copy
+import os
 
 import torch
 import torch.nn as nn
@@ -119,6 +120,29 @@ def cat_planes(planes):
     return first.as_strided((1, n, C), (n * C, C, 1), first.storage_offset())
 
 
+class _Planes(tuple):
+    """The three TPV planes as the torch.split views of ONE concatenated (1, N, C) tensor, which is kept (``cat``): the
+    encoder layer alternates between the per-plane form (image cross-attention) and the concatenated form (cross-view
+    self-attention, norm, ffn), and under autograd ``torch.cat(torch.split(t))`` is a 30 MB copy forward plus another one
+    backward, six times per layer.  Taking ``cat`` back is the same function of ``t`` without either copy."""
+    cat = None
+
+
+def _as_cat(q):
+    if torch.is_tensor(q):
+        return q
+    c = getattr(q, 'cat', None)
+    return c if c is not None else cat_planes(list(q))
+
+
+def _as_planes(q, sizes):
+    if not torch.is_tensor(q):
+        return q
+    p = _Planes(torch.split(q, sizes, 1))
+    p.cat = q
+    return p
+
+
 class _FormerLayerBase(BaseModule):
     """attention / norm / ffn stack driven by ``operation_order`` (mmcv BaseTransformerLayer idiom)."""
 
@@ -183,12 +207,13 @@ class TPVFormerLayer(_FormerLayerBase):
         norm_i = attn_i = ffn_i = 0
         identity = query
         device = query[0].device
-        cat = lambda planes: planes if self.multi_plane_ffn_norm else cat_planes(list(planes))
-        split = lambda t: t if self.multi_plane_ffn_norm else torch.split(t, sizes, 1)
+        # `query` / `identity` are a concatenated tensor or the planes (see _Planes); each step takes the form it needs
+        mp = self.multi_plane_ffn_norm
+        cat = (lambda q: tuple(_as_planes(q, sizes))) if mp else _as_cat
         # inference: a `norm` that directly follows an attention / ffn step rides in that step's last projection
         # (selfocc_linear_fwd: output_proj + residual + LayerNorm in one launch) instead of re-reading the planes
         # (post-norm layers only: with pre_norm the un-normalised tensor is still needed as the next identity)
-        fuse_norm = (not torch.is_grad_enabled() and not self.training and not self.multi_plane_ffn_norm
+        fuse_norm = (not torch.is_grad_enabled() and not self.training and not mp
                      and not self.pre_norm and query[0].is_cuda)
         skip_norm = False
         ops = self.operation_order
@@ -199,30 +224,30 @@ class TPVFormerLayer(_FormerLayerBase):
                 skip_norm = True
             if op == 'self_attn':   # cross-view hybrid attention: the 3 planes are the 3 "levels"
                 ss, lsi = _plane_shapes(H, W, Z, device)     # constants: uploaded once, not once per layer call
-                q = cat_planes(list(query))
-                q = self.attentions[attn_i](q, q, q, cat_planes(list(identity)) if self.pre_norm else None,
-                                            query_pos=tpv_pos_cat, reference_points=ref_2d,
-                                            spatial_shapes=ss, level_start_index=lsi, post_norm=post_norm, **kwargs)
-                query = torch.split(q, sizes, 1)
+                q = _as_cat(query)
+                query = self.attentions[attn_i](q, q, q, _as_cat(identity) if self.pre_norm else None,
+                                                query_pos=tpv_pos_cat, reference_points=ref_2d,
+                                                spatial_shapes=ss, level_start_index=lsi, post_norm=post_norm, **kwargs)
                 attn_i += 1
                 identity = query
             elif op == 'norm':
                 if skip_norm:       # already applied inside the previous step
                     skip_norm = False
                 else:
-                    query = split(self.norms[norm_i](cat(query)))
+                    query = self.norms[norm_i](cat(query))
                 norm_i += 1
             elif op == 'cross_attn':  # image cross-attention, per plane
-                query = self.attentions[attn_i](query, key, value, identity if self.pre_norm else None,
+                query = self.attentions[attn_i](_as_planes(query, sizes), key, value,
+                                                _as_planes(identity, sizes) if self.pre_norm else None,
                                                 spatial_shapes=spatial_shapes, level_start_index=level_start_index,
                                                 reference_points_cams=reference_points_cams, tpv_masks=tpv_masks,
                                                 post_norm=post_norm, **kwargs)
                 attn_i += 1
                 identity = query
             elif op == 'ffn':
-                query = split(self.ffns[ffn_i](cat(query), cat(identity) if self.pre_norm else None, post_norm=post_norm))
+                query = self.ffns[ffn_i](cat(query), cat(identity) if self.pre_norm else None, post_norm=post_norm)
                 ffn_i += 1
-        return query
+        return _as_planes(query, sizes)
 
 
 @MODELS.register_module()
@@ -295,17 +320,74 @@ class _EncoderBase(BaseModule):
     def _flatten_feats(self, img_feats):
         """4 x (B, N, C, h, w) -> (N, sum hw, B, C) + cam / level embeddings, spatial shapes, level starts."""
         device = img_feats[0].device
-        flat, shapes = [], []
-        for lvl, feat in enumerate(img_feats):
-            _, _, _, h, w = feat.shape
-            feat = feat.flatten(3).permute(1, 0, 3, 2)           # N, B, hw, C
-            feat = feat + self.cams_embeds[:, None, None, :].to(feat.dtype)
-            feat = feat + self.level_embeds[None, None, lvl:lvl + 1, :].to(feat.dtype)
-            shapes.append((h, w))
-            flat.append(feat)
-        flat = torch.cat(flat, 2).permute(0, 2, 1, 3)
-        spatial_shapes, level_start_index = _level_shapes(tuple(shapes), device)
+        shapes = tuple((f.shape[3], f.shape[4]) for f in img_feats)
+        if img_feats[0].is_cuda and torch.is_grad_enabled() and FLATTEN_FEATS_FUNCTION:
+            flat = _FlattenFeats.apply(self.cams_embeds, self.level_embeds, *img_feats)
+        else:
+            flat = _flatten_feats(self.cams_embeds, self.level_embeds, img_feats)
+        spatial_shapes, level_start_index = _level_shapes(shapes, device)
         return flat, spatial_shapes, level_start_index
+
+
+def _flatten_feats(cams_embeds, level_embeds, img_feats):
+    flat = []
+    for lvl, feat in enumerate(img_feats):
+        feat = feat.flatten(3).permute(1, 0, 3, 2)           # N, B, hw, C
+        feat = feat + cams_embeds[:, None, None, :].to(feat.dtype)
+        feat = feat + level_embeds[None, None, lvl:lvl + 1, :].to(feat.dtype)
+        flat.append(feat)
+    return torch.cat(flat, 2).permute(0, 2, 1, 3)
+
+
+# training: the embedding gradients of _flatten_feats through column sums in two stages (env SELFOCC_FLATTEN_FEATS_FN=0:
+# torch autograd, whose reduction of a (6, 1, 19 200, 96) gradient to (6, 1, 1, 96) takes 0.22 ms, twice per level)
+FLATTEN_FEATS_FUNCTION = os.environ.get('SELFOCC_FLATTEN_FEATS_FN', '1') == '1'
+
+
+def _colsum(t):
+    """(N, R, C) -> (N, C) in two stages: the first has N * R / 128 * C outputs to parallelise over."""
+    N, R, C = t.shape
+    k = 128
+    main = R // k * k
+    out = t.new_zeros(N, C)
+    if main:
+        out = out + t[:, :main].reshape(N, main // k, k, C).sum(2).sum(1)
+    if main < R:
+        out = out + t[:, main:].sum(1)
+    return out
+
+
+class _FlattenFeats(torch.autograd.Function):
+    """_flatten_feats with a hand-written backward: d cams_embeds[n] / d level_embeds[l] are column sums of the flat
+    gradient over (level slice, batch) — computed once per (camera, level) and combined — and the image-feature gradient
+    is the slice itself, transposed back."""
+
+    @staticmethod
+    def forward(ctx, cams_embeds, level_embeds, *img_feats):
+        ctx.shapes = [tuple(f.shape) for f in img_feats]
+        ctx.dtypes = (cams_embeds.dtype, level_embeds.dtype)
+        ctx.n_levels = level_embeds.shape[0]
+        return _flatten_feats(cams_embeds, level_embeds, img_feats)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):                                    # (N, S, B, C)
+        N, S, B, C = g.shape
+        g = g.contiguous()
+        per, feats, s0 = [], [], 0
+        for i, (b, n, c, h, w) in enumerate(ctx.shapes):
+            seg = g[:, s0:s0 + h * w]                        # (N, hw, B, C)
+            s0 += h * w
+            per.append(_colsum(seg.reshape(N, h * w * B, C).float()))          # (N, C) of this level
+            feats.append(seg.permute(2, 0, 3, 1).reshape(b, n, c, h, w) if ctx.needs_input_grad[2 + i] else None)
+        per = torch.stack(per)                               # (L, N, C)
+        g_cam = per.sum(0).to(ctx.dtypes[0]) if ctx.needs_input_grad[0] else None
+        g_lvl = None
+        if ctx.needs_input_grad[1]:
+            g_lvl = per.new_zeros(ctx.n_levels, C)           # levels beyond the maps handed in keep a zero gradient
+            g_lvl[:per.shape[0]] = per.sum(1)
+            g_lvl = g_lvl.to(ctx.dtypes[1])
+        return (g_cam, g_lvl, *feats)
 
 
 @MODELS.register_module()

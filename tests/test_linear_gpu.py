@@ -140,3 +140,48 @@ def test_linear_fwd_heads_is_the_head_major_projection(hip, B, nv, G, K):
     assert torch.equal(linear_fwd_heads(x, w, b, nv, relu=True), want.clamp_min(0))
     with pytest.raises(RuntimeError):
         linear_fwd_heads(x, w[:95], b[:95], nv)            # N must be whole 96-column groups
+
+
+# ---- selfocc_linear_dgrad (csrc/linear_fwd.hip): dx = dy W, the reduction over the layer's outputs looped in 96-wide chunks ----
+# (T, N = reduced, K = columns of dx): the training encoder's shapes (offsets / weights / value / output projections, FFN)
+DGRAD_SHAPES = [(66049, 384, 96), (66049, 192, 96), (6425, 768, 96), (78899, 96, 96), (78899, 48, 96), (78899, 192, 96),
+                (78899, 96, 192), (4099, 1152, 96), (8193, 200, 96), (70, 8, 96), (1, 96, 96), (33, 104, 288), (257, 2304, 384)]
+
+
+@pytest.mark.parametrize("T,N,K", DGRAD_SHAPES)
+def test_linear_dgrad_matches_f64(hip, T, N, K):
+    from selfocc_amd.linear import linear_dgrad, dgrad_supported
+    assert dgrad_supported(T, N, K)
+    g = torch.Generator().manual_seed(T + N + K)
+    dy = torch.randn(T, N, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.3).cuda()
+    dx = linear_dgrad(dy, w)
+    want = dy.double() @ w.double()
+    scale = want.abs().max().item()
+    # float32-level accuracy from the exact three-way bfloat16 split (the vendor f32 GEMM measures the same 1e-6 here)
+    assert (dx.double() - want).abs().max().item() < 3e-6 * max(scale, 1.0)
+    assert torch.equal(dx, linear_dgrad(dy, w))
+
+
+def test_linear_dgrad_unsupported_shape_is_loud(hip):
+    from selfocc_amd.linear import linear_dgrad, dgrad_supported
+    assert not dgrad_supported(1000, 100, 96) and not dgrad_supported(1000, 96, 100)
+    with pytest.raises(RuntimeError):
+        linear_dgrad(torch.randn(1000, 96).cuda(), torch.randn(96, 100).cuda())
+
+
+def test_tall_linear_backward_uses_fused_dgrad(hip, monkeypatch):
+    from selfocc_amd.model import bricks
+    import selfocc_amd.linear as L
+    calls = []
+    real = L.linear_dgrad
+    monkeypatch.setattr(bricks, "linear_dgrad", lambda dy, w: (calls.append(dy.shape), real(dy, w))[1])
+    torch.manual_seed(0)
+    lin = bricks.TallLinear(96, 384).cuda()
+    T = bricks.DGRAD_MIN_ROWS + 77
+    x = torch.randn(1, T, 96).cuda().requires_grad_(True)
+    g = torch.randn(1, T, 384).cuda()
+    lin(x).backward(g)
+    assert calls == [torch.Size([T, 384])]
+    want = g.double().reshape(T, 384) @ lin.weight.double()
+    assert (x.grad.double().reshape(T, 96) - want).abs().max().item() < 3e-6 * want.abs().max().item()
