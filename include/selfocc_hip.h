@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SELFOCC_ABI_VERSION 25
+#define SELFOCC_ABI_VERSION 26
 
 int selfocc_abi_version(void);
 const char *selfocc_last_error(void);
@@ -427,6 +427,14 @@ size_t selfocc_layernorm_bwd_workspace(int64_t rows, int32_t C);
 int selfocc_layernorm_bwd(const float *x, const float *gamma, const float *mean, const float *rstd,
                           const float *dy, float *dx, float *dgamma, float *dbeta, int64_t rows, int32_t C,
                           void *workspace, size_t workspace_bytes, void *stream);
+
+/* The image features as the encoders' `value`: n_levels maps (B, N, C, h_l, w_l) float32 -> out (N, sum h_l w_l, B, C) with
+ * out[n][start_l + p][b][c] = (feats[l][b][n][c][p] + cams_embeds[n][c]) + level_embeds[l][c]
+ * (/root/reference/model/encoder/tpvformer/tpvformer_encoder.py:261-277, bevformer/bevformer_encoder.py:194-210: two
+ * broadcast adds per level + cat + permute).  `feats`: HOST array of n_levels device pointers; host_hw[l] = h_l * w_l.
+ * 1 <= n_levels <= 8, C <= 512.  Returns 0 / SELFOCC_ERR_*. */
+int selfocc_flatten_feats(const float *const *feats, const int32_t *host_hw, int32_t n_levels, int32_t B, int32_t N, int32_t C,
+                          const float *cams_embeds, const float *level_embeds, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * point_sampling of the TPV / BEV encoders (model/encoder/bevformer/utils.py:114-170): project the pillar reference

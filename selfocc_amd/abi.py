@@ -6,7 +6,7 @@ its exported symbols being callable with these layouts.
 """
 import ctypes as C
 
-ABI_VERSION = 25
+ABI_VERSION = 26
 
 # enums ---------------------------------------------------------------------------
 RAYS_EXPLICIT, RAYS_PIXEL_GRID = 0, 1
@@ -128,6 +128,7 @@ SYMBOLS = {
     "selfocc_layernorm_fwd": (C.c_int, [_p] * 6 + [C.c_int64, _i, C.c_float, _p]),
     "selfocc_layernorm_bwd_workspace": (C.c_size_t, [C.c_int64, _i]),
     "selfocc_layernorm_bwd": (C.c_int, [_p] * 8 + [C.c_int64, _i, _p, C.c_size_t, _p]),
+    "selfocc_flatten_feats": (C.c_int, [_p, _p, _i, _i, _i, _i, _p, _p, _p, _p]),
     "selfocc_point_sampling": (C.c_int, [_p] * 7 + [_i] * 4 + [C.c_float, C.c_float, _p]),
     "selfocc_linear_wgrad_supported": (C.c_int, [C.c_int64, _i, _i]),
     "selfocc_linear_wgrad_workspace": (C.c_size_t, [C.c_int64, _i, _i]),

@@ -323,13 +323,40 @@ class _EncoderBase(BaseModule):
         shapes = tuple((f.shape[3], f.shape[4]) for f in img_feats)
         if img_feats[0].is_cuda and torch.is_grad_enabled() and FLATTEN_FEATS_FUNCTION:
             flat = _FlattenFeats.apply(self.cams_embeds, self.level_embeds, *img_feats)
+        elif torch.is_grad_enabled() and (self.cams_embeds.requires_grad or any(f.requires_grad for f in img_feats)):
+            flat = _flatten_feats_torch(self.cams_embeds, self.level_embeds, img_feats)     # autograd through the torch ops
         else:
             flat = _flatten_feats(self.cams_embeds, self.level_embeds, img_feats)
         spatial_shapes, level_start_index = _level_shapes(shapes, device)
         return flat, spatial_shapes, level_start_index
 
 
+# the flatten as one HIP pass (csrc/geometry.hip, selfocc_flatten_feats) instead of 2 adds per level + cat; env
+# SELFOCC_FLATTEN_HIP=0: the torch ops
+FLATTEN_HIP = os.environ.get('SELFOCC_FLATTEN_HIP', '1') == '1'
+
+
 def _flatten_feats(cams_embeds, level_embeds, img_feats):
+    f0 = img_feats[0]
+    if (FLATTEN_HIP and f0.is_cuda and not torch.is_autocast_enabled() and 1 <= len(img_feats) <= 8 and f0.shape[2] <= 512
+            and all(f.dtype == torch.float32 and f.dim() == 5 and f.shape[:3] == f0.shape[:3] for f in img_feats)
+            and cams_embeds.dtype == torch.float32 and level_embeds.dtype == torch.float32
+            and cams_embeds.shape[0] == f0.shape[1] and level_embeds.shape[0] >= len(img_feats)):
+        import ctypes as C
+        from ..._lib import lib, check, ptr, current_stream
+        B, N, Cc = f0.shape[:3]
+        feats = [f.contiguous() for f in img_feats]
+        hw = [f.shape[3] * f.shape[4] for f in feats]
+        out = f0.new_empty(N, sum(hw), B, Cc)
+        ptrs = (C.c_void_p * len(feats))(*[f.data_ptr() for f in feats])
+        check(lib().selfocc_flatten_feats(ptrs, (C.c_int32 * len(hw))(*hw), len(feats), B, N, Cc,
+                                          ptr(cams_embeds.detach().contiguous()), ptr(level_embeds.detach().contiguous()),
+                                          ptr(out), current_stream(f0.device)), "selfocc_flatten_feats")
+        return out
+    return _flatten_feats_torch(cams_embeds, level_embeds, img_feats)
+
+
+def _flatten_feats_torch(cams_embeds, level_embeds, img_feats):
     flat = []
     for lvl, feat in enumerate(img_feats):
         feat = feat.flatten(3).permute(1, 0, 3, 2)           # N, B, hw, C

@@ -1,0 +1,98 @@
+"""GPU: the training-path glue of the encoders (round 3) against the torch formulation the reference runs under autograd.
+
+  * selfocc_flatten_feats == 2 broadcast adds per level + cat + permute (tpvformer_encoder.py:261-277), bit for bit;
+    _FlattenFeats' hand-written backward == autograd through those ops;
+  * _TallLinearHeadsMulti (one merged value projection per layer) == three nn.Linear + head-major transposes;
+  * _TallLinearReLU == nn.Linear -> nn.ReLU(inplace=True) (mmcv FFN's first layer).
+"""
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+D0 = torch.device("cuda:0")
+
+
+def _feats(B, N, C, shapes, seed=0, requires_grad=False):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(B, N, C, h, w, generator=g).to(D0).requires_grad_(requires_grad) for h, w in shapes]
+
+
+@pytest.mark.parametrize("B,N,C,shapes", [(1, 6, 96, [(96, 200), (48, 100), (24, 50), (12, 25)]),
+                                          (2, 3, 32, [(7, 9), (3, 5)]), (1, 1, 128, [(1, 1)]), (1, 2, 20, [(5, 13)] * 8)])
+def test_flatten_feats_hip_is_the_torch_formula_bit_for_bit(hip, B, N, C, shapes):
+    from selfocc_amd.model.encoder import tpvformer as T
+    feats = _feats(B, N, C, shapes)
+    cams, lvls = torch.randn(N, C, device=D0), torch.randn(len(shapes) + 1, C, device=D0)
+    with torch.no_grad():
+        got = T._flatten_feats(cams, lvls, feats)
+        want = T._flatten_feats_torch(cams, lvls, feats)
+    assert got.shape == want.shape == (N, sum(h * w for h, w in shapes), B, C)
+    assert got.is_contiguous() and torch.equal(got, want)
+
+
+def test_flatten_feats_rejects_bad_arguments(hip):
+    import ctypes as C
+    from selfocc_amd._lib import lib
+    assert lib().selfocc_flatten_feats(None, None, 0, 1, 1, 1, None, None, None, None) != 0
+    assert b"levels" in lib().selfocc_last_error()
+
+
+def test_flatten_feats_backward_vs_autograd(hip):
+    from selfocc_amd.model.encoder import tpvformer as T
+    shapes = [(24, 50), (12, 25), (5, 7)]
+    cams = torch.randn(3, 32, device=D0, requires_grad=True)
+    lvls = torch.randn(4, 32, device=D0, requires_grad=True)        # one level more than maps: its gradient row stays zero
+    fa, fb = _feats(2, 3, 32, shapes, 1, True), _feats(2, 3, 32, shapes, 1, True)
+    ya = T._FlattenFeats.apply(cams, lvls, *fa)
+    g = torch.randn_like(ya)
+    ga = torch.autograd.grad(ya, [cams, lvls] + fa, g)
+    yb = T._flatten_feats_torch(cams, lvls, fb)
+    gb = torch.autograd.grad(yb, [cams, lvls] + fb, g)
+    assert torch.equal(ya, yb)
+    for a, b in zip(ga, gb):
+        assert a.shape == b.shape
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-5 * b.abs().max().item())
+    assert torch.all(ga[1][3] == 0)
+
+
+def test_merged_value_projection_vs_three_linears(hip):
+    from selfocc_amd.model import bricks
+    torch.manual_seed(0)
+    cams, nv, K = 6, 2600, 96
+    lins = [nn.Linear(K, 96).to(D0) for _ in range(3)]
+    x = torch.randn(cams * nv, K, device=D0, requires_grad=True)
+    vs = bricks.value_proj_head_major_multi(lins, x, nv, 6)
+    assert vs is not None and len(vs) == 3 and vs[0].shape == (cams, 6, nv, 16)
+    gs = [torch.randn_like(v) for v in vs]
+    gs[1] = None                                                   # a plane whose result nobody used
+    torch.autograd.backward([v for v, g in zip(vs, gs) if g is not None], [g for g in gs if g is not None])
+    got = [x.grad.clone()] + [p.grad.clone() for l in lins for p in (l.weight, l.bias)]
+    x.grad = None
+    for l in lins:
+        l.weight.grad = l.bias.grad = None
+    want_vs = [l(x).view(cams, nv, 6, 16).permute(0, 2, 1, 3) for l in lins]
+    for v, w in zip(vs, want_vs):
+        assert torch.allclose(v, w, rtol=1e-5, atol=1e-5)
+    torch.autograd.backward([w for w, g in zip(want_vs, gs) if g is not None], [g for g in gs if g is not None])
+    want = [x.grad] + [p.grad if p.grad is not None else torch.zeros_like(p) for l in lins for p in (l.weight, l.bias)]
+    for a, b in zip(got, want):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * max(b.abs().max().item(), 1e-3))
+
+
+def test_ffn_fused_relu_vs_sequential(hip, monkeypatch):
+    from selfocc_amd.model import bricks
+    torch.manual_seed(0)
+    ffn = bricks.FFN(embed_dims=96, feedforward_channels=192, ffn_drop=0.0).to(D0).train()
+    x = torch.randn(1, 5000, 96, device=D0)
+    outs = []
+    for fused in (True, False):
+        monkeypatch.setattr(bricks, "FUSED_FFN_RELU", fused)
+        xi = x.clone().requires_grad_(True)
+        y = ffn(xi)
+        y.square().sum().backward()
+        outs.append([y.detach(), xi.grad] + [p.grad.clone() for p in ffn.parameters()])
+        for p in ffn.parameters():
+            p.grad = None
+    for a, b in zip(*outs):
+        assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * b.abs().max().item())
