@@ -193,8 +193,11 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_b3_kernel(const float *__
 #pragma unroll
     for (int t = 0; t < NTW; ++t) { bsum[t] = 0.0f; ncol[t] = n0 + t * 32 + i < N; }
 
-    for (long long r = r0; r < r1; r += 16) {
-        float a[NTW][8], b[KT][8];
+    // the operands of step r + 16 are loaded before the MFMAs of step r (NTW = 1: the registers are there): a wave has
+    // 2 - 3 neighbours on its SIMD, not enough to cover the HBM latency of 16 rows by themselves
+    constexpr bool PF = NTW == 1;      // (NTW = 2 with the second operand set: 255 registers, measured 58 -> 74 us)
+    float a[NTW][8], b[KT][8], an[PF ? NTW : 1][8], bn[PF ? KT : 1][8];
+    auto load_step = [&](long long r, float (&da)[NTW][8], float (&db)[KT][8]) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const long long rr = r + 8 * half + j;
@@ -202,9 +205,17 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_b3_kernel(const float *__
             const float *dyr = dy + rr * N + n0 + i;
             const float *xr = x + rr * K + i;
 #pragma unroll
-            for (int t = 0; t < NTW; ++t) a[t][j] = (ok && ncol[t]) ? dyr[t * 32] : 0.0f;
+            for (int t = 0; t < NTW; ++t) da[t][j] = (ok && ncol[t]) ? dyr[t * 32] : 0.0f;
 #pragma unroll
-            for (int u = 0; u < KT; ++u) b[u][j] = ok ? xr[u * 32] : 0.0f;
+            for (int u = 0; u < KT; ++u) db[u][j] = ok ? xr[u * 32] : 0.0f;
+        }
+    };
+    if constexpr (PF) load_step(r0, a, b);
+    for (long long r = r0; r < r1; r += 16) {
+        if constexpr (PF) {
+            if (r + 16 < r1) load_step(r + 16, an, bn);
+        } else {
+            load_step(r, a, b);
         }
         bf16x8w b1[KT], b2[KT], b3[KT];
 #pragma unroll
@@ -223,6 +234,15 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_b3_kernel(const float *__
                 acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b1[u], acc[t][u], 0, 0, 0);
                 acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b2[u], acc[t][u], 0, 0, 0);
                 acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1[u], acc[t][u], 0, 0, 0);
+            }
+        }
+        if constexpr (PF) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                for (int t = 0; t < NTW; ++t) a[t][j] = an[t][j];
+#pragma unroll
+                for (int u = 0; u < KT; ++u) b[u][j] = bn[u][j];
             }
         }
     }
@@ -310,7 +330,11 @@ struct WgradPlan {
 };
 
 bool so_wgrad_plan(long long T, int N, int K, WgradPlan &p) {
-    if (K == 96) { p.kt = 3; p.ntw = 3; }
+    static const int env_ntw = getenv("SELFOCC_WGRAD_NTW") ? atoi(getenv("SELFOCC_WGRAD_NTW")) : 0;        // dev A/B
+    static const int env_chunks = getenv("SELFOCC_WGRAD_CHUNKS") ? atoi(getenv("SELFOCC_WGRAD_CHUNKS")) : 0;
+    // K = 96: one or two 32-column tile rows of dY per wave (round 3, scripts/micro/wgrad_bench.py: N <= 96 had 128 blocks = one
+    // wave on half of the SIMDs with three; 40 -> 28 us at 66 049 x 96 x 96, 108 -> 84 us at 153 000 x 288 x 96 with two)
+    if (K == 96) { p.kt = 3; p.ntw = (env_ntw >= 1 && env_ntw <= 3) ? env_ntw : ((N <= 96 || T < 16384) ? 1 : 2); }
     else if (K == 192) { p.kt = 6; p.ntw = 2; }
     else if (K == 32) { p.kt = 1; p.ntw = 4; }
     else if (K == 64) { p.kt = 2; p.ntw = 4; }
@@ -320,8 +344,9 @@ bool so_wgrad_plan(long long T, int N, int K, WgradPlan &p) {
     const int nt = (N + 31) / 32;
     p.ngroups = (nt + p.ntw - 1) / p.ntw;
     // ~2 blocks per CU, at most 128 partial sums per element; at least 64 rows per block (16 per wave)
-    long long chunks = std::max(1LL, std::min((long long)(512 / std::max(1, std::min(p.ngroups, 512))), (T + 63) / 64));
-    chunks = std::min(chunks, 128LL);
+    const int target = env_chunks > 0 ? 4 * env_chunks : 512;
+    long long chunks = std::max(1LL, std::min((long long)(target / std::max(1, std::min(p.ngroups, target))), (T + 63) / 64));
+    chunks = std::min(chunks, env_chunks > 0 ? (long long)env_chunks : 128LL);
     long long rpb = (T + chunks - 1) / chunks;
     rpb = (rpb + 7) / 8 * 8;                          // rows per wave a multiple of 2
     chunks = (T + rpb - 1) / rpb;
@@ -369,7 +394,11 @@ extern "C" int selfocc_linear_wgrad(const float *dy, const float *x, float *dw, 
     switch (p.kt) {
         case 1: SO_LAUNCH(1, 4); break;
         case 2: SO_LAUNCH(2, 4); break;
-        case 3: SO_LAUNCH(3, 3); break;
+        case 3:
+            if (p.ntw == 1) SO_LAUNCH(3, 1);
+            else if (p.ntw == 2) SO_LAUNCH(3, 2);
+            else SO_LAUNCH(3, 3);
+            break;
         case 4: SO_LAUNCH(4, 3); break;
         default: SO_LAUNCH(6, 2); break;
     }
