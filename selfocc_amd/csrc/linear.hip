@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void linear_wgrad_b3_kernel(const float *__
 
     // the operands of step r + 16 are loaded before the MFMAs of step r (NTW = 1: the registers are there): a wave has
     // 2 - 3 neighbours on its SIMD, not enough to cover the HBM latency of 16 rows by themselves
-    constexpr bool PF = NTW == 1;      // (NTW = 2 with the second operand set: 255 registers, measured 58 -> 74 us)
+    constexpr bool PF = NTW == 1 && KT <= 3;      // (NTW = 2 with the second operand set: 255 registers, measured 58 -> 74 us)
     float a[NTW][8], b[KT][8], an[PF ? NTW : 1][8], bn[PF ? KT : 1][8];
     auto load_step = [&](long long r, float (&da)[NTW][8], float (&db)[KT][8]) {
 #pragma unroll
@@ -329,13 +329,19 @@ struct WgradPlan {
     long long rows_per_block;
 };
 
+// round 3: the bf16 three-way-split kernels (same results to float32 rounding); SELFOCC_LINEAR_B3=0 keeps the f32-MFMA ones
+bool so_wgrad_b3() {
+    static const bool on = !(getenv("SELFOCC_LINEAR_B3") && atoi(getenv("SELFOCC_LINEAR_B3")) == 0);
+    return on;
+}
+
 bool so_wgrad_plan(long long T, int N, int K, WgradPlan &p) {
     static const int env_ntw = getenv("SELFOCC_WGRAD_NTW") ? atoi(getenv("SELFOCC_WGRAD_NTW")) : 0;        // dev A/B
     static const int env_chunks = getenv("SELFOCC_WGRAD_CHUNKS") ? atoi(getenv("SELFOCC_WGRAD_CHUNKS")) : 0;
     // K = 96: one or two 32-column tile rows of dY per wave (round 3, scripts/micro/wgrad_bench.py: N <= 96 had 128 blocks = one
     // wave on half of the SIMDs with three; 40 -> 28 us at 66 049 x 96 x 96, 108 -> 84 us at 153 000 x 288 x 96 with two)
     if (K == 96) { p.kt = 3; p.ntw = (env_ntw >= 1 && env_ntw <= 3) ? env_ntw : ((N <= 96 || T < 16384) ? 1 : 2); }
-    else if (K == 192) { p.kt = 6; p.ntw = 2; }
+    else if (K == 192) { p.kt = 6; p.ntw = so_wgrad_b3() ? 1 : 2; }      // b3: one tile row (222 registers), 66 -> 44 us at 78 899 x 96 x 192
     else if (K == 32) { p.kt = 1; p.ntw = 4; }
     else if (K == 64) { p.kt = 2; p.ntw = 4; }
     else if (K == 128) { p.kt = 4; p.ntw = 3; }
@@ -380,8 +386,7 @@ extern "C" int selfocc_linear_wgrad(const float *dy, const float *x, float *dw, 
     float *part_w = (float *)workspace, *part_b = part_w + (size_t)p.chunks * N * K;
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)p.chunks, (unsigned)p.ngroups);
-    // round 3: bf16 three-way-split kernel (same results to float32 rounding); SELFOCC_LINEAR_B3=0 keeps the f32-MFMA one
-    static const bool use_b3 = !(getenv("SELFOCC_LINEAR_B3") && atoi(getenv("SELFOCC_LINEAR_B3")) == 0);
+    const bool use_b3 = so_wgrad_b3();
 #define SO_LAUNCH(KT_, NTW_)                                                                                       \
     do {                                                                                                          \
         if (use_b3 && KT_ <= 3)                                                                                   \
@@ -400,7 +405,10 @@ extern "C" int selfocc_linear_wgrad(const float *dy, const float *x, float *dw, 
             else SO_LAUNCH(3, 3);
             break;
         case 4: SO_LAUNCH(4, 3); break;
-        default: SO_LAUNCH(6, 2); break;
+        default:
+            if (use_b3 && p.ntw == 1) hipLaunchKernelGGL((linear_wgrad_b3_kernel<6, 1>), grid, dim3(256), 0, st, dy, x, part_w, part_b, T, N, K, p.rows_per_block);
+            else SO_LAUNCH(6, 2);
+            break;
     }
 #undef SO_LAUNCH
     const int NK = N * K;
