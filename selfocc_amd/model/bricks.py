@@ -238,7 +238,7 @@ class _TallLinear(torch.autograd.Function):
     @torch.amp.custom_bwd(device_type='cuda')
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
-        return _tall_linear_backward(x, weight, dy, ctx.has_bias)
+        return _tall_linear_backward(x, weight, dy, ctx.has_bias, ctx.needs_input_grad[0])
 
 
 def _dgrad(dy, weight):
@@ -248,7 +248,7 @@ def _dgrad(dy, weight):
     return dy @ weight
 
 
-def _tall_linear_backward(x, weight, dy, has_bias):
+def _tall_linear_backward(x, weight, dy, has_bias, need_dx=True):
         """(dx, dW, db) of y = x W^T + b for a row-major dy (shared by _TallLinear and _TallLinearHeads)."""
         dy = dy.contiguous().to(x.dtype)
         T = x.shape[0]
@@ -256,7 +256,7 @@ def _tall_linear_backward(x, weight, dy, has_bias):
                 and wgrad_supported(T, dy.shape[1], x.shape[1])):
             # one MFMA pass over dy and x for dW and db (csrc/linear.hip) instead of batched GEMMs + two reductions
             dw, db = linear_wgrad(dy, x, has_bias)
-            return _dgrad(dy, weight), dw, db
+            return (_dgrad(dy, weight) if need_dx else None), dw, db
         G = max(1, min(256, T // 2048))  # ~2 k+ rows per batched GEMM: enough workgroups, small partial-sum tensor
         R = T // G                       # rows per batched GEMM
         Tp = R * G
@@ -276,7 +276,7 @@ def _tall_linear_backward(x, weight, dy, has_bias):
             db = db + dy[Tp:].sum(0)
         if Tp < T:
             dw = dw + dy[Tp:].t() @ x[Tp:]
-        return dy @ weight, dw, (db if has_bias else None)
+        return (_dgrad(dy, weight) if need_dx else None), dw, (db if has_bias else None)
 
 
 class _TallLinearReLU(torch.autograd.Function):
@@ -300,7 +300,7 @@ class _TallLinearReLU(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight, y = ctx.saved_tensors
         dy = torch.ops.aten.threshold_backward(dy.contiguous().to(y.dtype), y, 0)
-        return _tall_linear_backward(x, weight, dy, ctx.has_bias)
+        return _tall_linear_backward(x, weight, dy, ctx.has_bias, ctx.needs_input_grad[0])
 
 
 class _TallLinearHeads(torch.autograd.Function):
@@ -321,7 +321,7 @@ class _TallLinearHeads(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         G, B, H, nv, d = dy_hm.shape
         dy = dy_hm.permute(1, 3, 0, 2, 4).reshape(B * nv, G * H * d)        # (b, pix, g, h, c): one transposing copy
-        return (*_tall_linear_backward(x, weight, dy, ctx.has_bias), None)
+        return (*_tall_linear_backward(x, weight, dy, ctx.has_bias, ctx.needs_input_grad[0]), None)
 
 
 class _TallLinearHeadsMulti(torch.autograd.Function):
@@ -350,7 +350,7 @@ class _TallLinearHeadsMulti(torch.autograd.Function):
                 dy[:, :, g].zero_()
             else:
                 dy[:, :, g].copy_(gy.permute(0, 2, 1, 3))      # one transposing copy per group
-        dx, dw, db = _tall_linear_backward(x, w, dy.view(B * nv, G * H * d), True)
+        dx, dw, db = _tall_linear_backward(x, w, dy.view(B * nv, G * H * d), True, ctx.needs_input_grad[0])
         n = H * d
         grads = [t for g in range(G) for t in (dw[g * n:(g + 1) * n], db[g * n:(g + 1) * n])]
         return (dx, None, *grads)
