@@ -243,11 +243,9 @@ def test_msda_cross_training_matches_per_camera_autograd(hip, P, L, D, cams):
     assert torch.allclose(a[3], b[3], rtol=1e-3, atol=1e-4 * b[3].abs().max().item())
 
 
-def test_msda_backward_full_size_banded_vs_atomic(hip):
-    """nuscenes_occ hw-plane cross-attention at FULL size (6 cams x 22016 queries x 6 heads x 4 levels x 8 points =
-    25.4 M points, FPN maps 96x200 .. 12x25): the banded LDS-f64 backward and the global-atomic backward agree;
-    grad_attw / grad_loc (no atomics in either) to float rounding, grad_value to the float-atomic noise."""
-    import selfocc_amd.msda as M
+def _full_size_case():
+    """nuscenes_occ hw-plane cross-attention at FULL size: 6 cams x 22016 queries x 6 heads x 4 levels x 8 points = 25.4 M
+    points on FPN maps 96x200 .. 12x25, spatially coherent sampling locations"""
     d = torch.device("cuda:0")
     g = torch.Generator(device=d).manual_seed(3)
     bs, nq, H, D, P = 6, 22016, 6, 16, 8
@@ -261,6 +259,32 @@ def test_msda_backward_full_size_banded_vs_atomic(hip):
     loc = base[None, :, None, None, None, :] + torch.randn(bs, nq, H, L, P, 2, device=d, generator=g) * 0.03
     attw = torch.softmax(torch.randn(bs, nq, H, L * P, device=d, generator=g), -1).view(bs, nq, H, L, P)
     gout = torch.randn(bs, nq, H * D, device=d, generator=g)
+    return d, shapes, starts, value, loc, attw, gout
+
+
+def test_msda_full_size_forward_backward_vs_oracle(hip):
+    """EVERY element of the full-size case against the C oracle (forward on all host threads, backward single-threaded,
+    ~10 s): output, grad_loc, grad_attw to float rounding; grad_value (up to ~2300 float adds per element on the 12x25
+    level, summed in a different order on each side) to 2e-4 of its scale."""
+    import oracle
+    d, shapes, starts, value, loc, attw, gout = _full_size_case()
+    v, lc, aw = (t.clone().requires_grad_(True) for t in (value, loc, attw))
+    out = MultiScaleDeformableAttnFunction.apply(v, shapes.to(d), starts.to(d), lc, aw, 64)
+    out.backward(gout)
+    want = oracle.msda_fwd(value.cpu(), shapes, starts, loc.cpu(), attw.cpu())
+    assert torch.allclose(out.detach().cpu(), want, rtol=1e-4, atol=1e-5)
+    gv, gl, ga = oracle.msda_bwd(value.cpu(), shapes, starts, loc.cpu(), attw.cpu(), gout.cpu())
+    assert torch.allclose(aw.grad.cpu(), ga, rtol=1e-4, atol=1e-5)
+    # grad_loc = (corner differences) x map size: up to ~200 x the value scale; relative to that scale
+    assert (lc.grad.cpu() - gl).abs().max().item() < 1e-4 * gl.abs().max().item()
+    assert (v.grad.cpu() - gv).abs().max().item() < 2e-4 * gv.abs().max().item()
+
+
+def test_msda_backward_full_size_banded_vs_atomic(hip):
+    """the full-size case: the banded LDS-f64 backward and the global-atomic backward agree;
+    grad_attw / grad_loc (no atomics in either) to float rounding, grad_value to the float-atomic noise."""
+    import selfocc_amd.msda as M
+    d, shapes, starts, value, loc, attw, gout = _full_size_case()
     res = {}
     for mode in ("banded", "atomic"):
         M.BACKWARD_MODE = mode
