@@ -20,9 +20,9 @@
 //   * the epilogue works on the accumulator layout (a lane holds one column of 4 rows; 16 lanes hold 16 consecutive
 //     columns of a row): bias / ReLU / residual per element, LayerNorm by two 4-step shuffle reductions per row.
 // f32 MFMA on gfx950 is an exact fmaf chain: float32 arithmetic, only the summation order differs from a BLAS.
-// Measured (scripts/micro/linear_fwd_bench.py, one layer's twelve projections): hipBLASLt 742 us -> 543 us; output_proj +
+// Measured (scripts/bench_linear.py, one layer's twelve projections): hipBLASLt 742 us -> 543 us; output_proj +
 // residual + LayerNorm of a 78 899 x 96 plane tensor 124 us (three torch kernels) -> 34 us.  What was tried on the way
-// (gpurun_out/linear_fwd_bench_*.txt): 32-row tiles on v_mfma_f32_32x32x2_f32 with three 16-register accumulators
+// (round-2 runs of scripts/bench_linear.py): 32-row tiles on v_mfma_f32_32x32x2_f32 with three 16-register accumulators
 // (118 - 164 VGPRs, 2 - 3 waves per SIMD, half as many work units: 576 - 672 us); more resident waves (4 per SIMD:
 // 612 us, 8-wave blocks 664 us) — fewer, longer-lived waves win because every extra resident block re-stages its
 // slice of W and scatters the output stream over more DRAM pages at once.  Then: the next tile's x operand loaded
