@@ -319,6 +319,27 @@ class _EncoderBase(BaseModule):
         nn.init.normal_(self.level_embeds)
         nn.init.normal_(self.cams_embeds)
 
+    def _positions(self, bs):
+        """The positional encodings (a Linear over constant Fourier features), batched, and — for several planes — their
+        concatenation.  Without autograd they depend on the layers' parameters only: computed once and kept until a
+        parameter changes (0.12 ms per TPV frame: three small GEMMs, their batch copies and a cat)."""
+        pe = self.positional_encoding
+
+        def build():
+            out = pe()
+            if isinstance(out, (list, tuple)):
+                pos = [p.unsqueeze(0).expand(bs, -1, -1) for p in out]
+                return pos, (None if torch.is_grad_enabled() else torch.cat(pos, dim=1))
+            return out.unsqueeze(0).expand(bs, -1, -1), None
+        if torch.is_grad_enabled():
+            return build()
+        key = (bs,) + tuple((None if p.is_inference() else p._version, p.data_ptr()) for p in pe.parameters())
+        hit = getattr(self, '_pos_cache', None)
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                hit = self._pos_cache = (key, build())
+        return hit[1]
+
     def _flatten_feats(self, img_feats):
         """4 x (B, N, C, h, w) -> (N, sum hw, B, C) + cam / level embeddings, spatial shapes, level starts."""
         device = img_feats[0].device
@@ -461,14 +482,16 @@ class TPVFormerEncoder(_EncoderBase):
         bs = tpv_query[0].shape[0]
         reference_points_cams, tpv_masks = [], []
         for ref_3d in (self.ref_3d_hw, self.ref_3d_zh, self.ref_3d_wz):
-            cam, mask = point_sampling(ref_3d.unsqueeze(0).repeat(bs, 1, 1, 1), img_metas)
+            cam, mask = point_sampling(ref_3d.unsqueeze(0).expand(bs, -1, -1, -1), img_metas)   # read-only: no copy at bs = 1
             reference_points_cams.append(cam)
             tpv_masks.append(mask)
-        ref_cross_view = self.cross_view_ref_points.clone().unsqueeze(0).expand(bs, -1, -1, -1, -1)
+        ref_cross_view = self.cross_view_ref_points.unsqueeze(0).expand(bs, -1, -1, -1, -1)      # read-only downstream
         # the camera-loop kernels need no re-batch plan (no host sync); a layer that cannot take that path
         # (batch > 1, shapes the banded scatter does not cover) builds its own
         plans = None
-        tpv_pos_cat = torch.cat(tpv_pos, dim=1)        # once per forward, not once per layer
+        tpv_pos_cat = kwargs.pop('tpv_pos_cat', None)
+        if tpv_pos_cat is None:
+            tpv_pos_cat = torch.cat(tpv_pos, dim=1)    # once per forward, not once per layer
         for layer in self.layers:
             tpv_query = layer(tpv_query, key, value, tpv_pos=tpv_pos, tpv_pos_cat=tpv_pos_cat, ref_2d=ref_cross_view,
                               spatial_shapes=spatial_shapes, level_start_index=level_start_index,
@@ -478,10 +501,10 @@ class TPVFormerEncoder(_EncoderBase):
 
     def forward(self, representation, ms_img_feats=None, metas=None, **kwargs):
         bs = ms_img_feats[0].shape[0]
-        tpv_pos = [pos.unsqueeze(0).repeat(bs, 1, 1) for pos in self.positional_encoding()]
+        tpv_pos, tpv_pos_cat = self._positions(bs)
         feat, spatial_shapes, level_start_index = self._flatten_feats(ms_img_feats)
         tpv = self.forward_layers(representation, feat, feat, tpv_pos=tpv_pos, spatial_shapes=spatial_shapes,
-                                  level_start_index=level_start_index, img_metas=metas)
+                                  level_start_index=level_start_index, img_metas=metas, tpv_pos_cat=tpv_pos_cat)
         return {'representation': tpv}
 
 
@@ -523,7 +546,7 @@ class BEVFormerEncoder(_EncoderBase):
 
     def forward(self, representation, ms_img_feats=None, metas=None, **kwargs):
         bs = ms_img_feats[0].shape[0]
-        bev_pos = self.positional_encoding().unsqueeze(0).repeat(bs, 1, 1)
+        bev_pos, _ = self._positions(bs)
         feat, spatial_shapes, level_start_index = self._flatten_feats(ms_img_feats)
         bev = self.forward_layers(representation, feat, feat, bev_pos=bev_pos, spatial_shapes=spatial_shapes,
                                   level_start_index=level_start_index, img_metas=metas)

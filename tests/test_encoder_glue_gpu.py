@@ -96,3 +96,26 @@ def test_ffn_fused_relu_vs_sequential(hip, monkeypatch):
             p.grad = None
     for a, b in zip(*outs):
         assert torch.allclose(a, b, rtol=1e-4, atol=1e-4 * b.abs().max().item())
+
+
+def test_cached_positional_encodings_follow_the_parameters(hip):
+    """eval frames reuse the planes' positional encodings; an in-place parameter update (optimizer step, load_state_dict)
+    invalidates them"""
+    import test_sync_free_gpu as S
+    th, lifter, enc, head, _ = S._stages(train=False)
+    metas, feats, _ = S._frame(th, 0)
+    with torch.no_grad():
+        torch.manual_seed(0)
+        for name, p in enc.named_parameters():      # the offset / weight projections start at zero weight (mmcv init):
+            if 'sampling_offsets.weight' in name or 'attention_weights.weight' in name:     # make them see the query
+                p.normal_(std=0.05)
+        a = enc(lifter(feats)['representation'], ms_img_feats=feats, metas=metas)['representation']
+        b = enc(lifter(feats)['representation'], ms_img_feats=feats, metas=metas)['representation']
+        assert all(torch.equal(x, y) for x, y in zip(a, b))
+        key0 = enc._pos_cache[0]
+        enc.positional_encoding.position_layer_hw.weight.mul_(1.5)
+        c = enc(lifter(feats)['representation'], ms_img_feats=feats, metas=metas)['representation']
+        assert enc._pos_cache[0] != key0 and not torch.equal(a[0], c[0])
+        del enc._pos_cache
+        d = enc(lifter(feats)['representation'], ms_img_feats=feats, metas=metas)['representation']
+        assert all(torch.equal(x, y) for x, y in zip(c, d))
