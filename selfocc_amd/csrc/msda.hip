@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256, SO_MSDA_FWD_WAVES(D)) void msda_fused_fwd_kern
 //   logits (nq, heads, L*P)      out (nq, heads*D) = sum_{cam visible} msda_cam(q) / max(#visible, 1)
 // ---------------------------------------------------------------------------------------
 template <int D, int LOGG, typename VT>
-__global__ __launch_bounds__(256, SO_MSDA_FWD_WAVES(D)) void msda_cross_fwd_kernel(const VT *__restrict__ value,
+__global__ __launch_bounds__(256, SO_MSDA_CROSS_WAVES(D, LOGG)) void msda_cross_fwd_kernel(const VT *__restrict__ value,
                                                              const int32_t *__restrict__ shapes,
                                                              const int32_t *__restrict__ starts,
                                                              const float *__restrict__ ref,

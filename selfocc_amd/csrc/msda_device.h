@@ -335,3 +335,6 @@ SO_DEVFN void so_group_reduce_store(float (&acc)[4], int j, bool live, float *o4
 // 4 waves / SIMD (<= 128 VGPRs) for the shipped head width: the camera-loop kernel otherwise takes 144 VGPRs (3 waves);
 // measured -1.5 % on the eval encoder, 5 / 6 waves spill (+20 % / +39 %)
 #define SO_MSDA_FWD_WAVES(D) ((D) <= 16 ? 4 : 1)
+// the camera loop at 16 channels with <= 16 lanes per (query, head) group (L * P <= 16: no shipped config) keeps 4+ groups'
+// state per lane round: 128 registers spilled 36 - 108 bytes; three waves per SIMD (170 registers) hold it
+#define SO_MSDA_CROSS_WAVES(D, LOGG) (((D) == 16 && (LOGG) <= 4) ? 3 : SO_MSDA_FWD_WAVES(D))

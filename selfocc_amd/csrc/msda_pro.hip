@@ -108,12 +108,10 @@ __global__ __launch_bounds__(kProWaves * 64) void msda_pro_fwd_kernel(MsdaProArg
         }
     }
     const int n = lane & 15, kq = lane >> 4;     // MFMA lane roles: row / column n, k block (bf16 operands) = row group (result) kq
-    float bv[NT16];
-#pragma unroll
-    for (int t = 0; t < NT16; ++t) {
-        const int c = 16 * t + n;
-        bv[t] = c < 2 * LP ? a.b_off[h * 2 * LP + c] : (c < NC ? a.b_aw[h * LP + c - 2 * LP] : 0.0f);
-    }
+    // the head's biases, one per result column, behind the waves' result tiles (in registers they were the 7 that spilled)
+    float *bias_s = lds + (3 * NROW * KPB * 2) / 4 + kProWaves * (16 * RS);
+    for (int c = threadIdx.x; c < NROW; c += kProWaves * 64)
+        bias_s[c] = c < 2 * LP ? a.b_off[h * 2 * LP + c] : (c < NC ? a.b_aw[h * LP + c - 2 * LP] : 0.0f);
     __syncthreads();
 
     const int pix_stride = so_pix_stride(dm, D);
@@ -157,8 +155,9 @@ __global__ __launch_bounds__(kProWaves * 64) void msda_pro_fwd_kernel(MsdaProArg
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[ks], b1, acc, 0, 0, 0);
                 }
                 // ---- 2. accumulator layout (lane: column n of rows 4 kq + j) -> row-major result tile in LDS ----
+                const float bvt = bias_s[16 * t + n];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) outl[(4 * kq + j) * RS + 16 * t + n] = acc[j] + bv[t];
+                for (int j = 0; j < 4; ++j) outl[(4 * kq + j) * RS + 16 * t + n] = acc[j] + bvt;
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -340,7 +339,8 @@ extern "C" int selfocc_msda_pro_fwd(const void *value, const int32_t *shapes, co
     const unsigned blocks = (unsigned)(a.nbh * heads);
 #define SO_LAUNCH_PRO(LG, NT, CR, VTT, WV)                                                                              \
     do {                                                                                                                \
-        const size_t shm = (size_t)3 * NT * 16 * kProKPB * 2 + (size_t)WV * 16 * (NT * 16 + 1) * sizeof(float);         \
+        const size_t shm = (size_t)3 * NT * 16 * kProKPB * 2 + (size_t)WV * 16 * (NT * 16 + 1) * sizeof(float) +        \
+                           (size_t)NT * 16 * sizeof(float);         \
         static std::atomic<unsigned long long> done_mask{0};      /* per-device attribute: one driver call per device */ \
         int dev_ = 0;                                                                                                   \
         (void)hipGetDevice(&dev_);                                                                                      \
