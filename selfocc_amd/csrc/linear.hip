@@ -336,14 +336,15 @@ bool so_wgrad_b3() {
 }
 
 bool so_wgrad_plan(long long T, int N, int K, WgradPlan &p) {
-    static const int env_ntw = getenv("SELFOCC_WGRAD_NTW") ? atoi(getenv("SELFOCC_WGRAD_NTW")) : 0;        // dev A/B
-    static const int env_chunks = getenv("SELFOCC_WGRAD_CHUNKS") ? atoi(getenv("SELFOCC_WGRAD_CHUNKS")) : 0;
-    // K = 96: one or two 32-column tile rows of dY per wave (round 3, scripts/micro/wgrad_bench.py: N <= 96 had 128 blocks = one
-    // wave on half of the SIMDs with three; 40 -> 28 us at 66 049 x 96 x 96, 108 -> 84 us at 153 000 x 288 x 96 with two)
-    if (K == 96) { p.kt = 3; p.ntw = (env_ntw >= 1 && env_ntw <= 3) ? env_ntw : ((N <= 96 || T < 16384) ? 1 : 2); }
-    else if (K == 192) { p.kt = 6; p.ntw = so_wgrad_b3() ? 1 : 2; }      // b3: one tile row (222 registers), 66 -> 44 us at 78 899 x 96 x 192
+    static const int env_chunks = getenv("SELFOCC_WGRAD_CHUNKS") ? atoi(getenv("SELFOCC_WGRAD_CHUNKS")) : 0;     // dev A/B
+    const bool b3 = so_wgrad_b3();
+    // tile rows of dY per wave (NTW).  bf16x3 kernels, K = 96: one or two (round 3, scripts/micro/wgrad_bench.py: N <= 96 had
+    // 128 blocks = one wave on half of the SIMDs with three; 40 -> 28 us at 66 049 x 96 x 96, 108 -> 84 us at 153 000 x 288 x 96
+    // with two); K = 192: one (222 registers; 66 -> 44 us at 78 899 x 96 x 192); K = 128 stays on the f32-MFMA kernel
+    if (K == 96) { p.kt = 3; p.ntw = b3 ? ((N <= 96 || T < 16384) ? 1 : 2) : 3; }
+    else if (K == 192) { p.kt = 6; p.ntw = b3 ? 1 : 2; }
     else if (K == 32) { p.kt = 1; p.ntw = 4; }
-    else if (K == 64) { p.kt = 2; p.ntw = 4; }
+    else if (K == 64) { p.kt = 2; p.ntw = b3 ? 2 : 4; }
     else if (K == 128) { p.kt = 4; p.ntw = 3; }
     else return false;
     if (T < 1 || N < 1 || (long long)N * K >= (1LL << 30)) return false;
@@ -387,30 +388,25 @@ extern "C" int selfocc_linear_wgrad(const float *dy, const float *x, float *dw, 
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid((unsigned)p.chunks, (unsigned)p.ngroups);
     const bool use_b3 = so_wgrad_b3();
-#define SO_LAUNCH(KT_, NTW_)                                                                                       \
-    do {                                                                                                          \
-        if (use_b3 && KT_ <= 3)                                                                                   \
-            hipLaunchKernelGGL((linear_wgrad_b3_kernel<KT_, NTW_>), grid, dim3(256), 0, st, dy, x, part_w, part_b, T, N, K, \
-                               p.rows_per_block);                                                                 \
-        else                                                                                                      \
-            hipLaunchKernelGGL((linear_wgrad_kernel<KT_, NTW_>), grid, dim3(256), 0, st, dy, x, part_w, part_b, T, N, K,  \
-                               p.rows_per_block);                                                                 \
-    } while (0)
+#define SO_LAUNCH_F32(KT_, NTW_)                                                                                   \
+    hipLaunchKernelGGL((linear_wgrad_kernel<KT_, NTW_>), grid, dim3(256), 0, st, dy, x, part_w, part_b, T, N, K, p.rows_per_block)
+#define SO_LAUNCH_B3(KT_, NTW_)                                                                                    \
+    hipLaunchKernelGGL((linear_wgrad_b3_kernel<KT_, NTW_>), grid, dim3(256), 0, st, dy, x, part_w, part_b, T, N, K, p.rows_per_block)
+    // (KT, NTW) pairs of the plan; only the pairs a plan can produce are instantiated (the b3 kernel at 3 x 3 / 4 x 3 / 6 x 2
+    // accumulator tiles needs more than 256 registers)
     switch (p.kt) {
-        case 1: SO_LAUNCH(1, 4); break;
-        case 2: SO_LAUNCH(2, 4); break;
+        case 1: if (use_b3) SO_LAUNCH_B3(1, 4); else SO_LAUNCH_F32(1, 4); break;
+        case 2: if (use_b3) SO_LAUNCH_B3(2, 2); else SO_LAUNCH_F32(2, 4); break;
         case 3:
-            if (p.ntw == 1) SO_LAUNCH(3, 1);
-            else if (p.ntw == 2) SO_LAUNCH(3, 2);
-            else SO_LAUNCH(3, 3);
+            if (!use_b3) SO_LAUNCH_F32(3, 3);
+            else if (p.ntw == 1) SO_LAUNCH_B3(3, 1);
+            else SO_LAUNCH_B3(3, 2);
             break;
-        case 4: SO_LAUNCH(4, 3); break;
-        default:
-            if (use_b3 && p.ntw == 1) hipLaunchKernelGGL((linear_wgrad_b3_kernel<6, 1>), grid, dim3(256), 0, st, dy, x, part_w, part_b, T, N, K, p.rows_per_block);
-            else SO_LAUNCH(6, 2);
-            break;
+        case 4: SO_LAUNCH_F32(4, 3); break;
+        default: if (use_b3) SO_LAUNCH_B3(6, 1); else SO_LAUNCH_F32(6, 2); break;
     }
-#undef SO_LAUNCH
+#undef SO_LAUNCH_F32
+#undef SO_LAUNCH_B3
     const int NK = N * K;
     hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((unsigned)((NK + N + 63) / 64)), dim3(256), 0, st, part_w, part_b,
                        dw, db, p.chunks, NK, N);
