@@ -486,7 +486,7 @@ def deformable_sampling(module, query, value, reference_points, spatial_shapes, 
             kind = {'level': 0, 'point': 1, 'level_point': 2}[per_level_reference]
             hm = HEAD_MAJOR_VALUE
             if v_hm is not None:
-                value, hm = v_hm[0], True
+                value, hm = v_hm.view(v_hm.shape[1:]), True      # G = 1: a view (select's backward is a zero fill + a copy)
             elif HEAD_MAJOR_VALUE:
                 value = to_head_major(value)
             if VALUE_BF16:
@@ -502,7 +502,7 @@ def deformable_sampling(module, query, value, reference_points, spatial_shapes, 
         kind = {'level': 0, 'point': 1, 'level_point': 2}[per_level_reference]
         hm = HEAD_MAJOR_VALUE
         if v_hm is not None:
-            value, hm = v_hm[0], True
+            value, hm = v_hm.view(v_hm.shape[1:]), True      # G = 1: a view (select's backward is a zero fill + a copy)
         elif HEAD_MAJOR_VALUE:
             value = to_head_major(value)
         if VALUE_BF16:
@@ -519,13 +519,13 @@ def deformable_sampling(module, query, value, reference_points, spatial_shapes, 
             kind = {'level': 0, 'point': 1, 'level_point': 2}[per_level_reference]
             hm = HEAD_MAJOR_VALUE
             if v_hm is not None:
-                value, hm = v_hm[0], True
+                value, hm = v_hm.view(v_hm.shape[1:]), True      # G = 1: a view (select's backward is a zero fill + a copy)
             elif HEAD_MAJOR_VALUE:
                 value = to_head_major(value)
             return MSDAFusedFunction.apply(value, spatial_shapes, level_start_index, reference_points, kind, off,
                                            logits, host, hm, VALUE_BF16)
     if v_hm is not None:      # (the unfused fallback below wants the mmcv layout)
-        value = v_hm[0].permute(0, 2, 1, 3).contiguous()
+        value = v_hm.view(v_hm.shape[1:]).permute(0, 2, 1, 3).contiguous()
     aw = module.attention_weights(query).view(bs, num_query, module.num_heads,
                                               module.num_levels * module.num_points).softmax(-1)
     aw = aw.view(bs, num_query, module.num_heads, module.num_levels, module.num_points)

@@ -178,7 +178,7 @@ class BEVCrossAttention(BaseModule):
                 # the projection itself writes (cams, heads, l, d) (selfocc_linear_fwd_heads; under autograd _TallLinearHeads)
                 v_hm = bricks.value_proj_head_major(da.value_proj.weight, da.value_proj.bias, vin, l, heads)
             if v_hm is not None:
-                v, hm = v_hm[0], True
+                v, hm = v_hm.view(v_hm.shape[1:]), True      # G = 1: a view, not a select
             else:
                 v = da.value_proj(vin.view(num_cams, l, self.embed_dims)).view(num_cams, l, heads, -1)
                 if hm:
