@@ -119,3 +119,32 @@ def test_cached_positional_encodings_follow_the_parameters(hip):
         del enc._pos_cache
         d = enc(lifter(feats)['representation'], ms_img_feats=feats, metas=metas)['representation']
         assert all(torch.equal(x, y) for x, y in zip(c, d))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_training_step_under_autocast(hip, dtype):
+    """the reference's `amp` switch (train.py wraps the forward in torch.autocast): the HIP ops compute in float32 under it
+    (custom_fwd casts), the torch ops around them in the autocast dtype — one whole training step runs, every gradient is
+    finite, and the loss stays close to the float32 step's"""
+    import numpy as np
+    import test_sync_free_gpu as S
+
+    def step(amp):
+        torch.manual_seed(0); np.random.seed(0)
+        th, lifter, enc, head, loss_fn = S._stages(train=True)
+        for m in (lifter, enc, head):
+            for mod in m.modules():
+                if isinstance(mod, nn.Dropout):
+                    mod.p = 0.0                                       # same arithmetic in both runs
+        metas, feats, imgs = S._frame(th, 0)
+        with torch.autocast("cuda", dtype=dtype, enabled=amp):
+            rep = enc(lifter(feats)['representation'], ms_img_feats=feats, metas=metas)['representation']
+            out = head(rep, metas, global_iter=7)
+            total, parts = loss_fn(dict(out, metas=metas, **imgs))
+        total.backward()
+        params = [p for m in (lifter, enc, head) for p in m.parameters()]
+        assert torch.isfinite(total).all() and all(p.grad is None or torch.isfinite(p.grad).all() for p in params)
+        assert sum(p.grad is not None for p in params) > 20
+        return float(total.detach())
+    ref, amp = step(False), step(True)
+    assert abs(amp - ref) <= 0.05 * abs(ref) + 1e-3, (amp, ref)
