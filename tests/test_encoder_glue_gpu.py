@@ -148,3 +148,25 @@ def test_training_step_under_autocast(hip, dtype):
         return float(total.detach())
     ref, amp = step(False), step(True)
     assert abs(amp - ref) <= 0.05 * abs(ref) + 1e-3, (amp, ref)
+
+
+def test_encoder_batch_of_two_runs_both_modes(hip):
+    """batch size 2 (the reference trains with 1 per GPU; its masks use batch element 0): the camera-loop kernels step aside
+    for the re-batch path, the merged value projection / kept-concatenated planes / flatten kernel take a batch — eval and a
+    training step run, finite, and element 0 of an identical pair equals element 1"""
+    import copy
+    import test_sync_free_gpu as S
+    th, lifter, enc, head, _ = S._stages(train=False)
+    metas, feats, _ = S._frame(th, 0)
+    metas2 = [metas[0], copy.deepcopy(metas[0])]
+    feats2 = [f.repeat(2, 1, 1, 1, 1) for f in feats]
+    with torch.no_grad():
+        rep = enc(lifter(feats2)['representation'], ms_img_feats=feats2, metas=metas2)['representation']
+    assert all(r.shape[0] == 2 and torch.isfinite(r).all() for r in rep)
+    assert all(torch.allclose(r[0], r[1], rtol=1e-5, atol=1e-5) for r in rep)
+    for m in (lifter, enc):
+        m.train()
+    rep = enc(lifter(feats2)['representation'], ms_img_feats=feats2, metas=metas2)['representation']
+    sum(r.square().mean() for r in rep).backward()
+    grads = [p.grad for m in (lifter, enc) for p in m.parameters() if p.grad is not None]
+    assert len(grads) > 20 and all(torch.isfinite(g).all() for g in grads)
