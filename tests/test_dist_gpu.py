@@ -126,7 +126,10 @@ def test_bench_two_ranks_on_one_gpu(shard):
     import json, os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, SELFOCC_BENCH_SHARE_GPU="1", MASTER_ADDR="127.0.0.1")
-    port = 29500 + (os.getpid() % 400) + (7 if shard == "rays" else 0)
+    import socket
+    with socket.socket() as sk:                                 # a port nobody listens on right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--preheat", "2", "--shard", shard, "--no-cpu-baseline", "--no-extras", "--no-hotpath"]
