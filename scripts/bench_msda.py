@@ -51,10 +51,17 @@ def time_bwd(make_out, g, n=10):
     return tb / n
 
 
+L1_PEAK = 256 * 64 * 2.4          # GB/s: 256 CUs x 64 bytes / clk of vector L1 at 2.4 GHz
+
+
 def rec(kernel, shape, alg_bytes, ms, points):
     gbps = alg_bytes / ms / 1e6
+    # the texture path: a bilinear sample is 4 corners x 64 bytes of float32 channels through the CU's vector L1, whatever the
+    # caches behind it do (an upper bound on the gathered bytes: samples outside the map and invisible pairs gather nothing)
+    l1 = points * 256.0 / ms / 1e6
     return dict(kernel=kernel, shape=shape, alg_MB=round(alg_bytes / 1e6, 1), ms=round(ms, 4), GBps=round(gbps, 1),
-                frac_of_8TBps=round(gbps / PEAK, 4), Gpoints_per_s=round(points / ms / 1e6, 2))
+                frac_of_8TBps=round(gbps / PEAK, 4), Gpoints_per_s=round(points / ms / 1e6, 2),
+                l1_gather_GBps=round(l1, 0), frac_of_l1_39TBps=round(l1 / L1_PEAK, 3))
 
 
 def query_linears(nq, H, L, P):
@@ -185,4 +192,7 @@ for name, (bs, nq, shapes, P) in CASES.items():
 
 print(json.dumps({"peak_GBps": PEAK, "bound": "hbm",
                   "definition": "algorithmic bytes (SURVEY 8d: inputs once + outputs once) / HIP-event time per call",
+                  "l1_definition": "second view, the bound these gather kernels actually sit under: points x 4 corners x 64 B through the "
+                                   "vector L1 (64 B / clk / CU x 256 CUs x 2.4 GHz = 39.3 TB/s) / the same time; forward rows only read "
+                                   "the corners once, backward rows read them once and scatter them once",
                   "kernels": rows}), flush=True)
