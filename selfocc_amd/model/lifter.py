@@ -18,7 +18,18 @@ class TPVQueryLifter(BaseModule):
 
     def forward(self, ms_img_feats, *args, **kwargs):
         bs = ms_img_feats[0].shape[0]
-        return {'representation': [p.repeat(bs, 1, 1) for p in (self.tpv_hw, self.tpv_zh, self.tpv_wz)]}
+        params = (self.tpv_hw, self.tpv_zh, self.tpv_wz)
+        if bs == 1 and not torch.is_grad_enabled() and params[0].is_cuda:
+            # inference: the planes as views of ONE concatenated tensor (kept until a parameter changes), the form the
+            # encoder's first step wants (tpvformer._Planes): no per-frame batch copies, no concatenating copy
+            from .encoder.tpvformer import _as_planes
+            key = tuple((None if p.is_inference() else p._version, p.data_ptr()) for p in params)
+            hit = getattr(self, '_cat_cache', None)
+            if hit is None or hit[0] != key:
+                hit = self._cat_cache = (key, torch.cat([p.detach() for p in params], 1))
+            return {'representation': _as_planes(hit[1], [p.shape[1] for p in params])}
+        # read-only downstream: an expanded view instead of the reference's .repeat (a copy, and a reduction in its backward)
+        return {'representation': [p.expand(bs, -1, -1) for p in params]}
 
 
 @MODELS.register_module()
@@ -30,4 +41,4 @@ class BEVQueryLifter(BaseModule):
 
     def forward(self, ms_img_feats, *args, **kwargs):
         bs = ms_img_feats[0].shape[0]
-        return {'representation': self.bev.to(ms_img_feats[0].dtype).repeat(bs, 1, 1)}
+        return {'representation': self.bev.to(ms_img_feats[0].dtype).expand(bs, -1, -1)}
