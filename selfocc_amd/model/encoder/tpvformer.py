@@ -474,7 +474,7 @@ class TPVFormerEncoder(_EncoderBase):
         wz3 = torch.cat([torch.linspace(0, H - 1, Ph).reshape(1, 1, -1, 1).expand(W, Z, -1, -1),
                          wz_grid[..., [1, 2]].unsqueeze(2).expand(-1, -1, Ph, -1)], -1)
         for name, g in (('ref_3d_hw', hw3), ('ref_3d_zh', zh3), ('ref_3d_wz', wz3)):
-            self.register_buffer(name, g2m(g).flatten(0, 1).transpose(0, 1), False)
+            self.register_buffer(name, g2m(g).flatten(0, 1).transpose(0, 1).contiguous(), False)   # (D, Q, 3) as point_sampling reads it
         self.register_buffer('cross_view_ref_points', get_cross_view_ref_points(H, W, Z, num_points_self), False)
 
     def forward_layers(self, tpv_query, key, value, tpv_pos=None, spatial_shapes=None, level_start_index=None,
@@ -526,7 +526,7 @@ class BEVFormerEncoder(_EncoderBase):
         self.num_points_cross, self.num_points_self = num_points_cross, num_points_self
         g3 = torch.cat([bev_grid.unsqueeze(2).expand(-1, -1, num_points_cross, -1),
                         torch.linspace(0, Z - 1, num_points_cross).reshape(1, 1, -1, 1).expand(H, W, -1, -1)], -1)
-        self.register_buffer('ref_3d', self.mapping.grid2meter(g3).flatten(0, 1).transpose(0, 1), False)
+        self.register_buffer('ref_3d', self.mapping.grid2meter(g3).flatten(0, 1).transpose(0, 1).contiguous(), False)
         normed = bev_grid.clone()
         normed[..., 0] = normed[..., 0] / (H - 1)
         normed[..., 1] = normed[..., 1] / (W - 1)
@@ -535,8 +535,8 @@ class BEVFormerEncoder(_EncoderBase):
     def forward_layers(self, bev_query, key, value, bev_pos=None, spatial_shapes=None, level_start_index=None,
                        img_metas=None, **kwargs):
         bs = bev_query.shape[0]
-        cam, mask = point_sampling(self.ref_3d.unsqueeze(0).repeat(bs, 1, 1, 1), img_metas)
-        ref_2d = self.ref_2d.unsqueeze(0).repeat(bs, 1, 1, 1).reshape(bs, -1, 1, 2)
+        cam, mask = point_sampling(self.ref_3d.unsqueeze(0).expand(bs, -1, -1, -1), img_metas)   # read-only
+        ref_2d = self.ref_2d.unsqueeze(0).expand(bs, -1, -1, -1).reshape(bs, -1, 1, 2)
         plan = None   # see TPVFormerEncoder.forward_layers
         for layer in self.layers:
             bev_query = layer(bev_query, key, value, bev_pos=bev_pos, ref_2d=ref_2d, spatial_shapes=spatial_shapes,
