@@ -1,14 +1,20 @@
 """dev: which ops launch the non-HIP-library kernels (copies, fills, RNG, cat, elementwise) of one depth-eval frame?"""
 import sys, os, re, collections
 here = os.path.dirname(os.path.abspath(__file__))
-src = open(os.path.join(here, 'bench_hotpath_eval.py')).read().split("def ev():")[0]
-g = {'__name__': 'bench', '__file__': os.path.join(here, 'bench_hotpath_eval.py')}
-exec(compile(src, 'bench_hotpath_eval.py', 'exec'), g)
+OCC = len(sys.argv) > 1 and sys.argv[1] == 'occ'          # `prof_eval_glue.py occ`: the occupancy-evaluation frame
+name = 'bench_hotpath_occ.py' if OCC else 'bench_hotpath_eval.py'
+src = open(os.path.join(here, name)).read().split("def ev():")[0]
+g = {'__name__': 'bench', '__file__': os.path.join(here, name)}
+sys.argv = sys.argv[:1]
+exec(compile(src, name, 'exec'), g)
 import torch
 from torch.profiler import profile, ProfilerActivity
 enc, lifter, head, feats, metas = g['encoder'], g['lifter'], g['head'], g['feats'], g['metas']
 def frame():
     rep = enc(lifter(feats)['representation'], ms_img_feats=feats, metas=metas)['representation']
+    if OCC:
+        res = head.forward_occ(rep, metas, aabb=g['pcr'], resolution=0.4)
+        return g['occ_resample'](res['sdf'], g['g'], 0.0, logits=res['logits'], lut=g['OPENSEED2NUSCENES'], crop=(6, 6, 6, 6, 0, 4))
     head.prepare(rep, metas)
     return head.render(metas, batch=90000)
 with torch.no_grad():

@@ -240,6 +240,17 @@ class SDFField(BaseModule):
             cols.append(q['logits'])
         return torch.cat(cols, -1)
 
+    def query_sdf_logits_argmax(self, xyz):
+        """Inference form of ``forward_geonetwork`` + ``argmax`` for the dense lattice of ``forward_occ``: sdf (n), semantic
+        logits (n, n_sem) and their arg-max (n, int64) from ONE selfocc_field_query launch — no (n, 1 + color_dims)
+        concatenation, no torch.argmax over its strided slice.  None when the volume is differentiable / has no semantics."""
+        v = self.volume
+        if self._differentiable() or v.n_sem == 0 or v.feat is None:
+            return None
+        vol = SDFVolume(v.mapping, v.sdf.detach(), v.feat.detach(), v.n_rgb, v.n_sem)
+        q = field_query(vol, xyz.reshape(-1, 3), want_sdf=True, want_logits=True, want_argmax=True)
+        return q['sdf'], q['logits'], q['argmax'].long()
+
     def forward_sdfnetwork(self, xyz):
         v = self.volume
         if self._differentiable():
@@ -393,6 +404,11 @@ class NeuSHead(BaseModule):
         xyz = uniform_lattice(aabb, resolution, device, shift)
         H, W, D = xyz.shape[:3]
         if self.return_sem:
+            fast = getattr(self.model.field, 'query_sdf_logits_argmax', None)
+            q = fast(xyz) if fast is not None and not torch.is_grad_enabled() else None
+            if q is not None:
+                sdf, logits, am = q
+                return sdf.reshape(H, W, D), am.reshape(H, W, D), logits.reshape(H, W, D, -1), xyz
             h = self.model.field.forward_geonetwork(xyz.reshape(-1, 3))
             sem_logits = h[..., 4:].reshape(H, W, D, -1)
             return h[..., 0].reshape(H, W, D), torch.argmax(sem_logits, dim=-1), sem_logits, xyz

@@ -108,8 +108,15 @@ def field_query_autograd(vol, xyz, want_logits=False):
     return out
 
 
+_LATTICES = {}
+
+
 def uniform_lattice(aabb, resolution, device, shift=False):
-    """xyz lattice of NeuSHead.get_uniform_sdf (neus_head.py:266-281): (H, W, D, 3)."""
+    """xyz lattice of NeuSHead.get_uniform_sdf (neus_head.py:266-281): (H, W, D, 3).  The unshifted lattice is a constant of
+    (aabb, resolution, device): built once (it was three linspace kernels, a stack and a 7.7 MB copy per evaluation frame)."""
+    key = (tuple(float(v) for v in aabb), float(resolution), str(device))
+    if not shift and key in _LATTICES:
+        return _LATTICES[key]
     xs = torch.linspace(aabb[0], aabb[3], int((aabb[3] - aabb[0]) / resolution), device=device)
     ys = torch.linspace(aabb[1], aabb[4], int((aabb[4] - aabb[1]) / resolution), device=device)
     zs = torch.linspace(aabb[2], aabb[5], int((aabb[5] - aabb[2]) / resolution), device=device)
@@ -117,7 +124,10 @@ def uniform_lattice(aabb, resolution, device, shift=False):
     xyz = torch.stack([xs[None, :, None].expand(H, W, D), ys[:, None, None].expand(H, W, D),
                        zs[None, None, :].expand(H, W, D)], dim=-1)
     if shift:
-        xyz = xyz + torch.rand_like(xyz) * resolution
+        return xyz + torch.rand_like(xyz) * resolution
+    if len(_LATTICES) > 8:
+        _LATTICES.clear()
+    _LATTICES[key] = xyz
     return xyz
 
 
