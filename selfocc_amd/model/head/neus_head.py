@@ -346,7 +346,14 @@ class NeuSHead(BaseModule):
         lat = sampler.lattice()
         ny, nx = sampler.ray_resize
         if lat is not None:
-            pix = sampler.pixels(ny, nx, *lat, device)
+            if sampler.ray_sample_mode == 'fixed':      # the same lattice every frame: built once per device
+                key = (ny, nx, lat, str(device))
+                hit = getattr(sampler, '_pix_cache', None)
+                if hit is None or hit[0] != key:
+                    hit = sampler._pix_cache = (key, sampler.pixels(ny, nx, *lat, device))
+                pix = hit[1]
+            else:
+                pix = sampler.pixels(ny, nx, *lat, device)
             rs = RaySet(img2lidar=M[0].contiguous(), nx=nx, ny=ny, sx=float(np.float32(lat[0])), sy=float(np.float32(lat[1])),
                         ox=float(np.float32(lat[2])), oy=float(np.float32(lat[3])))
         else:
