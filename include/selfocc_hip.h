@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SELFOCC_ABI_VERSION 26
+#define SELFOCC_ABI_VERSION 27
 
 int selfocc_abi_version(void);
 const char *selfocc_last_error(void);
@@ -400,6 +400,15 @@ int selfocc_occ_resample(const so_occ_args *args, void *stream);
 int selfocc_iou_counts(const int32_t *pred, const int32_t *target, const uint8_t *mask,
                        int64_t n, const int32_t *class_indices, int32_t n_cls,
                        int32_t empty_label, unsigned long long *counts, void *stream);
+
+/* The eikonal regulariser (/root/reference/loss/eikonal_loss.py:19-22): sum over the n rows of grad (n, 3) float32 of
+ * (||grad_i||_2 - 1)^2 as selfocc_eikonal_partials(n) per-block partial sums (the caller adds them: a fixed order, so the
+ * result is deterministic; the mean is that sum / n), and its gradient g_grad_i = 2 * scale[0] * (||grad_i|| - 1) grad_i /
+ * ||grad_i|| (0 where the norm is 0, as torch's norm backward), `scale` a 1-element DEVICE tensor (upstream gradient / n:
+ * no host read-back).  Returns 0 / SELFOCC_ERR_*. */
+int selfocc_eikonal_partials(int64_t n);
+int selfocc_eikonal_fwd(const float *grad, float *partial, int64_t n, void *stream);
+int selfocc_eikonal_bwd(const float *grad, const float *scale, float *g_grad, int64_t n, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * SSIM term of the photometric losses (class SSIM, loss/reproj_loss_mono_multi_new_combine.py:26-66;

@@ -6,7 +6,7 @@ its exported symbols being callable with these layouts.
 """
 import ctypes as C
 
-ABI_VERSION = 26
+ABI_VERSION = 27
 
 # enums ---------------------------------------------------------------------------
 RAYS_EXPLICIT, RAYS_PIXEL_GRID = 0, 1
@@ -139,6 +139,9 @@ SYMBOLS = {
     "selfocc_linear_dgrad_supported": (C.c_int, [C.c_int64, _i, _i]),
     "selfocc_linear_dgrad_workspace": (C.c_size_t, [_i, _i]),
     "selfocc_linear_dgrad": (C.c_int, [_p] * 3 + [C.c_int64, _i, _i, _p, C.c_int64, _p]),
+    "selfocc_eikonal_partials": (C.c_int, [C.c_int64]),
+    "selfocc_eikonal_fwd": (C.c_int, [_p, _p, C.c_int64, _p]),
+    "selfocc_eikonal_bwd": (C.c_int, [_p, _p, _p, C.c_int64, _p]),
     "selfocc_ssim_fwd": (C.c_int, [_p] * 4 + [_i] * 4 + [_p, _p]),
     "selfocc_ssim_bwd": (C.c_int, [_p] * 4 + [_i] * 4 + [_p, _p, _p, _p]),
     "selfocc_reproj_fwd": (C.c_int, [C.POINTER(SoReprojArgs), _p]),

@@ -98,14 +98,47 @@ class EikonalLoss(BaseLoss):
     @staticmethod
     def eikonal(eik_grad):
         from ..dist import shard_of, global_value_local_grad
-        sq = (eik_grad.norm(2, dim=-1) - 1) ** 2
         shard = shard_of(eik_grad)
+        n_local = eik_grad.numel() // max(eik_grad.shape[-1], 1)
+        if (eik_grad.is_cuda and eik_grad.dtype == torch.float32 and eik_grad.shape[-1] == 3 and n_local > 0
+                and not torch.is_autocast_enabled()):
+            sq_sum = _EikonalSum.apply(eik_grad)           # one HIP pass per direction (csrc/eikonal.hip)
+        else:
+            sq_sum = ((eik_grad.norm(2, dim=-1) - 1) ** 2).sum()
         if shard is None:
-            return sq.mean()
+            return sq_sum / n_local
         # ray-sharded head: this rank's samples only; the mean runs over the samples of ALL ranks
         n_cams = shard.full.img2lidar.shape[0]
-        n_global = sq.numel() // (n_cams * shard.rays_per_cam_local) * n_cams * shard.rays_per_cam_full
-        return global_value_local_grad(sq.sum() / n_global)
+        n_global = n_local // (n_cams * shard.rays_per_cam_local) * n_cams * shard.rays_per_cam_full
+        return global_value_local_grad(sq_sum / n_global)
+
+
+class _EikonalSum(torch.autograd.Function):
+    """sum_i (||g_i||_2 - 1)^2 over the rows of (..., 3) through selfocc_eikonal_fwd / _bwd: torch ran a norm reduction over
+    a dimension of three, sub, pow, sum forward and four more elementwise kernels backward (0.26 ms per iteration on
+    7.4 M samples)."""
+
+    @staticmethod
+    def forward(ctx, g):
+        from .._lib import lib, check, ptr, current_stream
+        g2 = g.reshape(-1, 3).contiguous()
+        n = g2.shape[0]
+        part = torch.empty(int(lib().selfocc_eikonal_partials(n)), device=g.device, dtype=torch.float32)
+        check(lib().selfocc_eikonal_fwd(ptr(g2), ptr(part), n, current_stream(g.device)), "selfocc_eikonal_fwd")
+        ctx.save_for_backward(g2)
+        ctx.shape = g.shape
+        return part.sum()
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, go):
+        from .._lib import lib, check, ptr, current_stream
+        (g2,) = ctx.saved_tensors
+        gg = torch.empty_like(g2)
+        scale = go.reshape(1).float().contiguous()
+        check(lib().selfocc_eikonal_bwd(ptr(g2), ptr(scale), ptr(gg), g2.shape[0], current_stream(g2.device)),
+              "selfocc_eikonal_bwd")
+        return gg.view(ctx.shape)
 
 
 @OPENOCC_LOSS.register_module()

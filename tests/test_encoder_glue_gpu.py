@@ -193,3 +193,23 @@ def test_lifter_views_follow_the_parameters(hip):
     assert lifter.tpv_hw.grad is not None and torch.all(lifter.tpv_hw.grad == 1)
     two = lifter([torch.zeros(2, 2, 8, 2, 2, device=D0)])['representation']
     assert two[0].shape == (2, 20, 8)
+
+
+@pytest.mark.parametrize("n", [7372800 // 16, 1000, 1, 257])
+def test_eikonal_loss_hip_vs_torch_formula(hip, n):
+    """EikonalLoss through selfocc_eikonal_fwd / _bwd == the reference's torch formula (loss/eikonal_loss.py:19-22) under
+    autograd: value and gradient, rows of zero norm included (torch's norm backward gives them a zero gradient)"""
+    from selfocc_amd.loss.simple import EikonalLoss
+    g = torch.Generator().manual_seed(n)
+    x = (torch.randn(n, 3, generator=g) * 0.7 + 0.3).to(D0)
+    x[0] = 0.0
+    a = x.clone().requires_grad_(True)
+    la = EikonalLoss.eikonal(a)
+    (la * 0.37).backward()
+    b = x.clone().requires_grad_(True)
+    lb = ((b.norm(2, dim=-1) - 1) ** 2).mean()
+    (lb * 0.37).backward()
+    assert torch.allclose(la, lb, rtol=2e-6, atol=1e-8)
+    assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-7 / n) and torch.all(a.grad[0] == 0)
+    # deterministic: a fixed order of partial sums
+    assert torch.equal(EikonalLoss.eikonal(x), EikonalLoss.eikonal(x))
