@@ -410,6 +410,15 @@ int selfocc_eikonal_partials(int64_t n);
 int selfocc_eikonal_fwd(const float *grad, float *partial, int64_t n, void *stream);
 int selfocc_eikonal_bwd(const float *grad, const float *scale, float *g_grad, int64_t n, void *stream);
 
+/* Compact second differences of the SDF volume (H, W, D) along h, w, d — NeuSHead's `second_grad`, the input of
+ * SecondGradLoss (/root/reference/loss/second_grad_loss.py:6-19; this repo's declared compact form):
+ * out = concat over the axes of ((s[2:] - 2 s[1:-1]) + s[:-2]).flatten(), selfocc_second_diff_size(H, W, D) floats (0: bad
+ * shape), bit-identical to the torch expression; backward: g_sdf (H, W, D) = the transposed stencil applied to g_out, gather
+ * form (deterministic, overwrites g_sdf).  Returns 0 / SELFOCC_ERR_*. */
+size_t selfocc_second_diff_size(int32_t H, int32_t W, int32_t D);
+int selfocc_second_diff_fwd(const float *sdf, float *out, int32_t H, int32_t W, int32_t D, void *stream);
+int selfocc_second_diff_bwd(const float *g_out, float *g_sdf, int32_t H, int32_t W, int32_t D, void *stream);
+
 /* ------------------------------------------------------------------------------------
  * SSIM term of the photometric losses (class SSIM, loss/reproj_loss_mono_multi_new_combine.py:26-66;
  * also loss/rgb_loss_ms.py): reflection pad 1, 3x3 means, out = clamp((1 - SSIM) / 2, 0, 1), (N, C, H, W).

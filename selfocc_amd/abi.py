@@ -139,6 +139,9 @@ SYMBOLS = {
     "selfocc_linear_dgrad_supported": (C.c_int, [C.c_int64, _i, _i]),
     "selfocc_linear_dgrad_workspace": (C.c_size_t, [_i, _i]),
     "selfocc_linear_dgrad": (C.c_int, [_p] * 3 + [C.c_int64, _i, _i, _p, C.c_int64, _p]),
+    "selfocc_second_diff_size": (C.c_size_t, [_i, _i, _i]),
+    "selfocc_second_diff_fwd": (C.c_int, [_p, _p, _i, _i, _i, _p]),
+    "selfocc_second_diff_bwd": (C.c_int, [_p, _p, _i, _i, _i, _p]),
     "selfocc_eikonal_partials": (C.c_int, [C.c_int64]),
     "selfocc_eikonal_fwd": (C.c_int, [_p, _p, C.c_int64, _p]),
     "selfocc_eikonal_bwd": (C.c_int, [_p, _p, _p, C.c_int64, _p]),

@@ -17,5 +17,7 @@ for s in $SRCS; do
   fi
 done
 for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC _obj/*.o -o "$OUT"
+OBJS=""
+for s in $SRCS; do OBJS="$OBJS _obj/${s%.hip}.o"; done      # only the objects of the sources that exist (a renamed file leaves a stale .o)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o "$OUT"
 echo "built $(readlink -f $OUT)"

@@ -134,6 +134,33 @@ class Img2LiDAR(nn.Module):
         return M[..., :3, 3], direction
 
 
+class _SecondDiff(torch.autograd.Function):
+    """(s[2:] - 2 s[1:-1] + s[:-2]) along the three axes of an (H, W, D) volume, flattened and concatenated: forward one
+    launch (torch: 12 elementwise kernels + a cat), backward one gather launch (torch: 9 zero fills, 9 strided copies and 9
+    accumulations of the full volume)."""
+
+    @staticmethod
+    def forward(ctx, s):
+        from ..._lib import lib, check, ptr, current_stream
+        s = s.contiguous()
+        H, W, D = s.shape
+        n = int(lib().selfocc_second_diff_size(H, W, D))
+        out = torch.empty(max(n, 0), device=s.device, dtype=torch.float32)
+        check(lib().selfocc_second_diff_fwd(ptr(s), ptr(out), H, W, D, current_stream(s.device)), "selfocc_second_diff_fwd")
+        ctx.shape = (H, W, D)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        from ..._lib import lib, check, ptr, current_stream
+        H, W, D = ctx.shape
+        g = g.contiguous().float()
+        gs = torch.empty(H, W, D, device=g.device, dtype=torch.float32)
+        check(lib().selfocc_second_diff_bwd(ptr(g), ptr(gs), H, W, D, current_stream(g.device)), "selfocc_second_diff_bwd")
+        return gs
+
+
 class SDFField(BaseModule):
     """Tri-plane / BEV -> dense SDF + colour + semantic volume, written directly in the
     layout the kernels read.  In-repo analogue: BEVNeRF (nerfacc_head/bev_nerf.py:8-95):
@@ -260,6 +287,8 @@ class SDFField(BaseModule):
     def second_grad(self):
         """Compact second differences of the SDF volume along h, w, d (declared restatement)."""
         s = self.volume.sdf
+        if s.is_cuda and s.dtype == torch.float32 and s.dim() == 3 and not torch.is_autocast_enabled():
+            return _SecondDiff.apply(s)          # one HIP pass per direction (csrc/losses.hip), same bits as the torch form
         return torch.cat([(s[2:] - 2 * s[1:-1] + s[:-2]).flatten(), (s[:, 2:] - 2 * s[:, 1:-1] + s[:, :-2]).flatten(),
                           (s[:, :, 2:] - 2 * s[:, :, 1:-1] + s[:, :, :-2]).flatten()])
 

@@ -213,3 +213,23 @@ def test_eikonal_loss_hip_vs_torch_formula(hip, n):
     assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-7 / n) and torch.all(a.grad[0] == 0)
     # deterministic: a fixed order of partial sums
     assert torch.equal(EikonalLoss.eikonal(x), EikonalLoss.eikonal(x))
+
+
+@pytest.mark.parametrize("shape", [(257, 257, 25), (9, 7, 5), (3, 3, 3), (2, 5, 1), (1, 1, 1)])
+def test_second_differences_hip_vs_torch_expression(hip, shape):
+    """NeuSHead's `second_grad` through selfocc_second_diff_fwd / _bwd == the torch expression it replaces: forward bit for
+    bit, backward (gather form) to float rounding of the accumulation order; axes shorter than 3 contribute nothing"""
+    from selfocc_amd.model.head.neus_head import _SecondDiff
+    g = torch.Generator().manual_seed(sum(shape))
+    s0 = torch.randn(*shape, generator=g).to(D0)
+
+    def torch_form(s):
+        return torch.cat([(s[2:] - 2 * s[1:-1] + s[:-2]).flatten(), (s[:, 2:] - 2 * s[:, 1:-1] + s[:, :-2]).flatten(),
+                          (s[:, :, 2:] - 2 * s[:, :, 1:-1] + s[:, :, :-2]).flatten()])
+    a, b = s0.clone().requires_grad_(True), s0.clone().requires_grad_(True)
+    ya, yb = _SecondDiff.apply(a), torch_form(b)
+    assert ya.shape == yb.shape and torch.equal(ya, yb)
+    if ya.numel():
+        go = torch.randn(ya.shape, generator=g).to(D0)
+        ya.backward(go); yb.backward(go)
+        assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-5)     # <= 9 taps of magnitude ~10 summed in another order
