@@ -442,7 +442,8 @@ __global__ __launch_bounds__(256) void linear_dgrad_split_kernel(const float *w,
 
 struct LinearDgradArgs {
     const float *dy;         // (T, N)
-    const __bf16 *planes;    // [3][K][Npad], Npad = 96 nchunks
+    const __bf16 *planes;    // [3][K][Npad], Npad = 96 nchunks; NULL (one chunk only): the kernel splits W itself
+    const float *w;          // (N, K) as stored: read when planes == NULL
     float *dx;               // (T, K)
     long long T;
     int N, K, Npad, groups;
@@ -498,6 +499,24 @@ __global__ __launch_bounds__(256) void linear_dgrad_b3_kernel(LinearDgradArgs a)
         const int c = (int)(it - pass * nchunks);
         if (nchunks > 1 || it == 0) {
             __syncthreads();                         // the previous chunk's B reads are done
+            if (a.planes == nullptr) {
+                // one chunk (N <= 96): no pre-split planes — transpose and split W here, once per (persistent) block:
+                // thread (column r, run k8) reads W[8 k8 + j][n0 + r] (coalesced along r)
+                for (int idx = threadIdx.x; idx < NCOL * (KC / 8); idx += THREADS) {
+                    const int k8 = idx / NCOL, r = idx - k8 * NCOL;
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int kk = 8 * k8 + j;
+                        v[j] = kk < a.N ? a.w[(size_t)kk * a.K + n0 + r] : 0.0f;
+                    }
+                    bf16x8 w1, w2, w3;
+                    so_split3(v, w1, w2, w3);
+                    *(bf16x8 *)(wb + (size_t)r * KPB + 8 * k8) = w1;
+                    *(bf16x8 *)(wb + (size_t)(NCOL + r) * KPB + 8 * k8) = w2;
+                    *(bf16x8 *)(wb + (size_t)(2 * NCOL + r) * KPB + 8 * k8) = w3;
+                }
+            } else
             // the chunk's planes: 3 x 96 x 12 16-byte runs, straight copies (L2 hits: every block of the chip reads the same)
 #pragma unroll 2
             for (int j0 = 0; j0 < NST; j0 += 7) {
@@ -758,10 +777,11 @@ extern "C" int selfocc_linear_dgrad(const float *dy, const float *w, float *dx, 
     SO_REQUIRE(((uintptr_t)workspace & 15) == 0, "linear_dgrad: workspace must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     const int Npad = (N + 95) / 96 * 96;
-    hipLaunchKernelGGL(linear_dgrad_split_kernel, dim3((unsigned)std::min(256, (K * (Npad / 8) + 255) / 256)), dim3(256), 0, st, w,
-                       (__bf16 *)workspace, N, K, Npad);
     LinearDgradArgs a;
-    a.dy = dy; a.planes = (const __bf16 *)workspace; a.dx = dx; a.T = T; a.N = N; a.K = K; a.Npad = Npad;
+    a.dy = dy; a.planes = (const __bf16 *)workspace; a.w = w; a.dx = dx; a.T = T; a.N = N; a.K = K; a.Npad = Npad;
+    if (Npad == 96) a.planes = nullptr;        // one chunk: the main kernel splits W while it stages it (one launch less)
+    else hipLaunchKernelGGL(linear_dgrad_split_kernel, dim3((unsigned)std::min(256, (K * (Npad / 8) + 255) / 256)), dim3(256), 0,
+                            st, w, (__bf16 *)workspace, N, K, Npad);
     const int ncb = K / 96;
     const long long nwt = (T + 31) / 32;
     static const int percu = getenv("SELFOCC_DGRAD_PERCU") ? atoi(getenv("SELFOCC_DGRAD_PERCU")) : 2;      // dev A/B
