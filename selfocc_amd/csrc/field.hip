@@ -417,7 +417,8 @@ struct FieldBwdArgs {
     float *g_hw, *g_zh, *g_wz;      // zero-initialised, accumulated
     float *g_w1, *g_b1, *g_w2, *g_b2;
     long long M;
-    int n_tiles;
+    int n_tiles;            // PH * PW * PD patches of 4 x 4 x 2 voxels
+    int PW, PD;
 };
 
 constexpr int kFB_C = 96, kFB_KS = 48, kFB_LD = 97, kFB_TS = 100, kFB_WAVES = 4;
@@ -462,14 +463,24 @@ __global__ __launch_bounds__(kFB_WAVES * 64) void field_volume_bwd_kernel(FieldB
     for (int ct = 0; ct < 3; ++ct) bias1[ct] = a.b1[ct * 32 + i];
 
     for (int tile = blockIdx.x * kFB_WAVES + wave; tile < a.n_tiles; tile += gridDim.x * kFB_WAVES) {
-        const long long m0 = (long long)tile * 32;
+        // a tile = a 4 (h) x 4 (w) x 2 (d) patch of voxels, row r of the tile = voxel (r >> 3, (r >> 1) & 3, r & 1) of the patch:
+        // every plane row (h, w) / (d, h) / (w, d) is then shared by 2 / 4 / 4 rows of the tile whose C-layout registers sit
+        // in one lane (or its partner half), and the scatter below adds them up before it issues an atomic — 32 plane-row
+        // atomics per tile instead of 66 with the 32 consecutive voxels of round 2 (1.33 GB of fabric writes per launch,
+        // profiles/r3_k_train_bwd_pmc.txt)
+        const int pd = tile % a.PD, tq = tile / a.PD;
+        const int pw = tq % a.PW, ph = tq / a.PW;
+        const int h_b = 4 * ph, w_b = 4 * pw, d_b = 2 * pd;
+        auto row_voxel = [&](int r, bool &live) {                // linear index (h W + w) D + d of row r (clamped when dead)
+            const int hh = h_b + (r >> 3), ww = w_b + ((r >> 1) & 3), dd = d_b + (r & 1);
+            live = (hh < a.H) & (ww < a.W) & (dd < a.D);
+            return ((long long)min(hh, a.H - 1) * a.W + min(ww, a.W - 1)) * a.D + min(dd, a.D - 1);
+        };
         // ---- S1: a = Softplus(x), A layout (row i, columns half * 48 ..) -> registers and T1 ---------------
-        const long long m = m0 + i;
-        const bool mlive = m < a.M;
-        const long long mc = mlive ? m : a.M - 1;
-        const int d = (int)(mc % a.D);
-        const int hwi = (int)(mc / a.D);
-        const int w = hwi % a.W, h = hwi / a.W;
+        bool mlive;
+        const long long m = row_voxel(i, mlive);
+        const int h = min(h_b + (i >> 3), a.H - 1), w = min(w_b + ((i >> 1) & 3), a.W - 1), d = min(d_b + (i & 1), a.D - 1);
+        const int hwi = h * a.W + w;
         float av[KS];
         {
             const float4 *p0 = (const float4 *)(a.hw + (size_t)hwi * C + half * KS);
@@ -551,9 +562,10 @@ __global__ __launch_bounds__(kFB_WAVES * 64) void field_volume_bwd_kernel(FieldB
         // ---- S6: dW2 += dOut^T z : rows o, columns n (3 tiles), K = the 32 rows of the tile ----------------
 #pragma unroll
         for (int ms = 0; ms < 16; ++ms) {
-            const long long mr = m0 + 2 * ms + half;               // A' operand: dOut[mr][o = i]
+            bool rlive;
+            const long long mr = row_voxel(2 * ms + half, rlive);  // A' operand: dOut[mr][o = i]
             float g = 0.0f;
-            if (mr < a.M && i < a.out_dim) {
+            if (rlive && i < a.out_dim) {
                 if (i == 0) g = a.g_sdf ? a.g_sdf[mr] : 0.0f;
                 else g = a.g_feat ? a.g_feat[(size_t)mr * a.feat_stride + (i - 1)] : 0.0f;
             }
@@ -618,40 +630,39 @@ __global__ __launch_bounds__(kFB_WAVES * 64) void field_volume_bwd_kernel(FieldB
         }
         __builtin_amdgcn_sched_barrier(0);
         // ---- S10 / S11: dX = dA sigmoid(x) (C layout) -> plane gradients -----------------------------------
-        const int hwi0 = (int)(m0 / a.D);
-        const int d0 = (int)(m0 - (long long)hwi0 * a.D);
-        const int w0 = hwi0 % a.W, h0 = hwi0 / a.W;
-        // host guarantees D >= 11 and W >= 4: d0 + r < 4 D (no divisions), at most one wrap of w per tile
+        // C-layout register v of lane (i, half) = tile row r = (v & 3) + 8 (v >> 2) + 4 half = patch voxel
+        //   dd = v & 1,   ww = 2 half + ((v >> 1) & 1),   hh = v >> 2
 #pragma unroll
         for (int ct = 0; ct < 3; ++ct) {
             const int k = ct * 32 + i;
-            float seg[3] = {0.0f, 0.0f, 0.0f};                      // sums over the rows of (h, w) column hwi0 + 0 / 1 / 2
+            float dx[16];
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int r = so_crow(v, half);
-                if (m0 + r >= a.M) continue;
+                const bool live = (h_b + (v >> 2) < a.H) & (w_b + 2 * half + ((v >> 1) & 1) < a.W) & (d_b + (v & 1) < a.D);
                 const float ar = T1[r * TS + k];
-                const float dx = acc[ct][v] * (1.0f - __expf(-ar));
-                const int t = d0 + r;
-                const int sgi = (t >= a.D) + (t >= 2 * a.D) + (t >= 3 * a.D);
-                const int dr = t - sgi * a.D;
-                int wr = w0 + sgi, hr = h0;
-                if (wr >= a.W) { wr -= a.W; hr += 1; }
-                unsafeAtomicAdd(a.g_zh + ((size_t)dr * a.H + hr) * C + k, dx);
-                unsafeAtomicAdd(a.g_wz + ((size_t)wr * a.D + dr) * C + k, dx);
-                if (sgi < 3) {
-                    seg[0] += sgi == 0 ? dx : 0.0f;
-                    seg[1] += sgi == 1 ? dx : 0.0f;
-                    seg[2] += sgi == 2 ? dx : 0.0f;
-                } else {
-                    unsafeAtomicAdd(a.g_hw + (size_t)(hwi0 + sgi) * C + k, dx);   // 4th+ column of the tile
-                }
+                dx[v] = live ? acc[ct][v] * (1.0f - __expf(-ar)) : 0.0f;
             }
+            // g_hw[h][w] += sum over d: registers v, v ^ 1 (8 rows per lane, the halves hold different w)
 #pragma unroll
-            for (int sg = 0; sg < 3; ++sg) {
-                const float tot = seg[sg] + __shfl_xor(seg[sg], 32, 64);
-                if (half == 0 && tot != 0.0f && (long long)(hwi0 + sg) * a.D < a.M)
-                    unsafeAtomicAdd(a.g_hw + (size_t)(hwi0 + sg) * C + k, tot);
+            for (int q = 0; q < 8; ++q) {
+                const int hh = h_b + (q >> 1), ww = w_b + 2 * half + (q & 1);
+                if (hh < a.H && ww < a.W) unsafeAtomicAdd(a.g_hw + ((size_t)hh * a.W + ww) * C + k, dx[2 * q] + dx[2 * q + 1]);
+            }
+            // g_wz[w][d] += sum over h: registers v, v + 4, v + 8, v + 12 (4 rows per lane)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ww = w_b + 2 * half + (q >> 1), dd = d_b + (q & 1);
+                if (ww < a.W && dd < a.D)
+                    unsafeAtomicAdd(a.g_wz + ((size_t)ww * a.D + dd) * C + k, (dx[q] + dx[q + 4]) + (dx[q + 8] + dx[q + 12]));
+            }
+            // g_zh[d][h] += sum over w: registers v, v ^ 2 and the partner half; half 0 issues d = d_b, half 1 d = d_b + 1
+#pragma unroll
+            for (int hq = 0; hq < 4; ++hq) {
+                const float s0 = dx[4 * hq] + dx[4 * hq + 2], s1 = dx[4 * hq + 1] + dx[4 * hq + 3];     // dd = 0 / 1, this half's two w
+                const float t0 = s0 + __shfl_xor(s0, 32, 64), t1 = s1 + __shfl_xor(s1, 32, 64);
+                const int hh = h_b + hq, dd = d_b + half;
+                if (hh < a.H && dd < a.D) unsafeAtomicAdd(a.g_zh + ((size_t)dd * a.H + hh) * C + k, half ? t1 : t0);
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -752,7 +763,6 @@ extern "C" int selfocc_field_volume_bwd(const float *hw, const float *zh, const 
                                         float *g_b_hidden, float *g_w_out, float *g_b_out, void *stream) {
     SO_REQUIRE(H >= 1 && W >= 1 && D >= 1, "field_volume_bwd: bad volume size (%d, %d, %d)", H, W, D);
     SO_REQUIRE(C == 96, "field_volume_bwd: embed_dims must be 96 (got %d); use the autograd path", C);
-    SO_REQUIRE(D >= 11 && W >= 4, "field_volume_bwd: needs D >= 11 and W >= 4 (got D = %d, W = %d); use the autograd path", D, W);
     SO_REQUIRE(out_dim >= 1 && out_dim <= 32, "field_volume_bwd: 1 + color_dims must be <= 32 (got %d)", out_dim);
     SO_REQUIRE(hw && zh && wz && w_hidden && b_hidden && w_out, "field_volume_bwd: NULL input pointer");
     SO_REQUIRE(g_hw && g_zh && g_wz && g_w_hidden && g_b_hidden && g_w_out && g_b_out,
@@ -761,8 +771,10 @@ extern "C" int selfocc_field_volume_bwd(const float *hw, const float *zh, const 
                feat_stride, out_dim - 1);
     const long long M = (long long)H * W * D;
     SO_REQUIRE(M < (1LL << 31) * 32, "field_volume_bwd: volume too large");
+    const long long PH = (H + 3) / 4, PW = (W + 3) / 4, PD = (D + 1) / 2;
+    SO_REQUIRE(PH * PW * PD < (1LL << 31), "field_volume_bwd: volume too large");
     FieldBwdArgs a{hw, zh, wz, H, W, D, w_hidden, b_hidden, w_out, out_dim, g_sdf, g_feat, feat_stride,
-                   g_hw, g_zh, g_wz, g_w_hidden, g_b_hidden, g_w_out, g_b_out, M, (int)((M + 31) / 32)};
+                   g_hw, g_zh, g_wz, g_w_hidden, g_b_hidden, g_w_out, g_b_out, M, (int)(PH * PW * PD), (int)PW, (int)PD};
     const size_t shm = ((size_t)kFB_C * kFB_LD + 32 * kFB_LD + (size_t)kFB_WAVES * 2 * 32 * kFB_TS) * sizeof(float);
     // per launch: the attribute is per device (a process may drive several GPUs)
     (void)hipFuncSetAttribute((const void *)field_volume_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -47,9 +47,7 @@ def field_volume(hw, zh, wz, size_hwd, linears, feat_stride=0, feat_dtype=torch.
 
 def field_volume_train_supported(embed_dims, n_linear, out_dim, feat_stride, feat_dtype, size_hwd=None):
     ok = embed_dims == 96 and n_linear == 2 and 1 <= out_dim <= 32 and feat_stride <= 31 and feat_dtype == torch.float32
-    if size_hwd is not None:          # the backward's division-free row walk
-        ok = ok and size_hwd[2] >= 11 and size_hwd[1] >= 4
-    return ok
+    return ok          # any (H, W, D): the backward walks 4 x 4 x 2 voxel patches (ragged ones are masked)
 
 
 class FieldVolumeFunction(torch.autograd.Function):

@@ -106,7 +106,8 @@ def test_field_volume_rejects_bad_config(hip):
         field_volume(torch.zeros(4, 96), torch.zeros(4, 96), torch.zeros(4, 96), (2, 2, 2), [nn.Linear(96, 1)], 0)
 
 
-@pytest.mark.parametrize("H,W,D,color,F", [(9, 7, 25, 24, 24), (5, 6, 31, 0, 0), (4, 5, 11, 3, 4), (3, 70, 16, 24, 24), (2, 4, 40, 1, 4)])
+@pytest.mark.parametrize("H,W,D,color,F", [(9, 7, 25, 24, 24), (5, 6, 31, 0, 0), (4, 5, 11, 3, 4), (3, 70, 16, 24, 24), (2, 4, 40, 1, 4),
+                                          (8, 8, 2, 3, 4), (1, 1, 1, 0, 0), (5, 3, 3, 24, 24)])     # whole / ragged 4 x 4 x 2 patches
 def test_field_volume_backward_vs_autograd(hip, H, W, D, color, F):
     """FieldVolumeFunction (fused forward + fused backward) vs torch autograd of the same formula in float64:
     gradients of the three planes, both weights and both biases."""
