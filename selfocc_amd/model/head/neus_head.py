@@ -129,8 +129,12 @@ class Img2LiDAR(nn.Module):
 
     def forward(self, metas, rays):
         M = self.matrices(metas, rays.device)
-        pad = torch.cat([rays.float(), torch.ones_like(rays[..., :1])], -1).reshape(1, 1, -1, 3)
-        direction = torch.matmul(M[..., :3, :3].unsqueeze(2), pad.unsqueeze(-1)).squeeze(-1)
+        # M[:3, :3] @ (u, v, 1) per (camera, ray).  The reference writes it as a broadcast torch.matmul (nerfacc_head/img2lidar.py:65-69); as a
+        # batched GEMM of 28 800 3 x 3 matrices the vendor library took 0.41 ms per training iteration — three broadcast
+        # multiply-adds in the same association ((m0 u + m1 v) + m2) take ~15 us
+        uv = rays.float().reshape(1, 1, -1, 2)
+        R = M[..., None, :3, :3]                                    # (B, N, 1, 3, 3)
+        direction = (R[..., 0] * uv[..., 0:1] + R[..., 1] * uv[..., 1:2]) + R[..., 2]
         return M[..., :3, 3], direction
 
 
