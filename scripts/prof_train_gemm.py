@@ -11,10 +11,16 @@ g['run'](2,False)
 with profile(activities=[ProfilerActivity.CPU,ProfilerActivity.CUDA],record_shapes=True) as prof:
     g['run'](1,False)
 torch.cuda.synchronize()
+agg = collections.defaultdict(lambda: [0, 0.0])
 for e in prof.events():
-    if e.device_type.name!='CPU' or not e.kernels: continue
+    if e.device_type.name != 'CPU' or not e.kernels: continue
     for k in e.kernels:
-        if k.name.startswith('Cijk_'):
-            par=[];p=e.cpu_parent
-            while p is not None and len(par)<4: par.append(p.name[:40]); p=p.cpu_parent
-            print(f"{k.duration:8.1f} us {k.name[:60]} | {e.name} {[tuple(x) for x in (e.input_shapes or []) if x]} <- {' <- '.join(par)}")
+        ours = '(anonymous namespace)::' in k.name and 'at::native' not in k.name
+        if ours: continue
+        par = []; p = e.cpu_parent
+        while p is not None and len(par) < 3: par.append(p.name[:36]); p = p.cpu_parent
+        key = (k.name[:44], e.name[:30], str([tuple(x) for x in (e.input_shapes or []) if x])[:70] + ' <- ' + ' <- '.join(par))
+        agg[key][0] += 1; agg[key][1] += k.duration
+print(f"non-selfocc kernels: {sum(v[1] for v in agg.values())/1e3:.2f} ms per iteration")
+for (kn, op, site), (n, us) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(os.environ.get('TOPN', 40))]:
+    print(f"{us/1e3:7.3f} ms {n:4d} x {kn:44s} {op:30s} {site[:150]}")
