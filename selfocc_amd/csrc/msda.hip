@@ -539,6 +539,32 @@ SO_DEVFN void so_bwd_team_step_g(const VT *__restrict__ value, const float4 &go,
 // softmax, off / normalizer, + ref and their three backward kernels, and the 100-400 MB loc / weight
 // tensors with their gradients.
 // ---------------------------------------------------------------------------------------
+// plan of the counting sort that follows the point kernels (see msda_bin_kernel below); the training point kernels count
+// their own hits with it
+constexpr int kMaxBands = 1024;            // bands per level (host falls back to the atomic kernel beyond)
+constexpr int kBinKeysPerBlock = 256 * 32;
+
+// n / d for any 32-bit n without a division (Granlund & Montgomery round-up method; host computes m, l from d)
+struct SoFastDiv {
+    unsigned m;
+    int l;
+};
+SO_DEVFN int so_fastdiv(int n, SoFastDiv f) {
+    if (f.l == 0) return n;                      // d == 1
+    const unsigned t = __umulhi(f.m, (unsigned)n);
+    return (int)((t + (((unsigned)n - t) >> 1)) >> (f.l - 1));
+}
+
+struct MsdaBinPlan {
+    float inv_rows[8];   // 1 / rows[l] (host-computed: the bin kernels and the counting point kernels classify with the same float)
+    int rows[8];      // rows per band of level l
+    int bands[8];     // bands of level l
+    int band0[9];     // first band of level l within a (batch, head)
+    int nbands;       // bands per (batch, head)
+    int seg;          // list entries per band-kernel block
+    SoFastDiv divP;   // key index -> query
+};
+
 template <int D, int LOGG, typename VT>
 __global__ __launch_bounds__(256) void msda_fused_bwd_point_kernel(const VT *__restrict__ value,
                                                                    const int32_t *__restrict__ shapes,
@@ -674,14 +700,23 @@ __global__ __launch_bounds__(256) void msda_cross_bwd_point_kernel(const VT *__r
                                                                    const float *__restrict__ g_out,
                                                                    float *__restrict__ g_off, float *__restrict__ g_logits,
                                                                    int16_t *__restrict__ keys, float4 *__restrict__ recs,
-                                                                   int cams, MsdaDims dm) {
+                                                                   int cams, MsdaDims dm, int32_t *__restrict__ bin_cnt,
+                                                                   MsdaBinPlan plan) {
     constexpr int G = 1 << LOGG;
     constexpr int QL = D / 4;
     constexpr int MAXR = so_maxr(LOGG);
     const int LP = dm.L * dm.P;
     const int groups_per_block = 256 / G;
     const int n_groups = dm.nq * dm.heads;
-    const int gid = (int)so_xcd_block() * groups_per_block + (threadIdx.x / G);
+    // bin_cnt != NULL: the kernel also does the counting pass of the sort (msda_bin_kernel<false>): an LDS histogram over
+    // (head of the block: at most two, camera, band, class), flushed once per block — the keys are in registers here
+    extern __shared__ int hist_s[];                              // [2 heads][cams][nbands][2]
+    const int blk0 = (int)so_xcd_block() * groups_per_block;
+    const int h_first = min(blk0, n_groups - 1) / dm.nq;
+    const int nh = bin_cnt != nullptr ? 2 * cams * plan.nbands * 2 : 0;
+    for (int e = threadIdx.x; e < nh; e += 256) hist_s[e] = 0;
+    if (bin_cnt != nullptr) __syncthreads();
+    const int gid = blk0 + (threadIdx.x / G);
     const int gl = threadIdx.x & (G - 1);
     const bool live = gid < n_groups;
     const int gq0 = live ? gid : 0;                            // head-outer order, see so_split_group_head_outer
@@ -788,7 +823,34 @@ __global__ __launch_bounds__(256) void msda_cross_bwd_point_kernel(const VT *__r
                 keys[ki] = (int16_t)bl.h_low;
                 recs[ki] = make_float4(bl.lh, bl.lw, aw / cnt,
                                        __int_as_float((int)(((unsigned)bl.h_low << 16) | ((unsigned)bl.w_low & 0xffffu))));
+                if (bin_cnt != nullptr) {      // the classification of msda_bin_kernel, on the key in the register
+                    int band0 = 0;
+                    float inv_rows = plan.inv_rows[0];
+                    for (int k = 1; k < 8; ++k)
+                        if (k == l) { band0 = plan.band0[k]; inv_rows = plan.inv_rows[k]; }
+                    const int key = bl.h_low;
+                    const bool va = key >= 0 && key < Hl, vb = key + 1 >= 0 && key + 1 < Hl;
+                    const int ba = (int)(((float)key + 0.5f) * inv_rows), bb = (int)(((float)key + 1.5f) * inv_rows);
+                    int *hb = hist_s + (((h - h_first) * cams + cam) * plan.nbands + band0) * 2;
+                    if (va && vb && ba == bb) {
+                        atomicAdd(hb + 2 * ba, 1);
+                    } else {
+                        if (va) atomicAdd(hb + 2 * ba + 1, 1);
+                        if (vb) atomicAdd(hb + 2 * bb + 1, 1);
+                    }
+                }
             }
+        }
+    }
+    if (bin_cnt != nullptr) {
+        __syncthreads();
+        for (int e = threadIdx.x; e < nh; e += 256) {
+            const int c = hist_s[e];
+            if (c == 0) continue;
+            const int per_head = cams * plan.nbands * 2;
+            const int hr = e / per_head, rem = e - hr * per_head;
+            const int cam = rem / (plan.nbands * 2), bc = rem - cam * (plan.nbands * 2);
+            atomicAdd(bin_cnt + ((size_t)(cam * dm.heads + h_first + hr) * plan.nbands) * 2 + bc, c);
         }
     }
     float sum_l = 0.0f;
@@ -827,29 +889,6 @@ constexpr int band_tile_bytes(int threads) { return threads == 512 ? 52 * 1024 :
 // Training iteration (16 calls): 15.6 ms -> 8.1 ms; the band kernel now runs at the ds_add_f64 rate measured by
 // scripts/micro/atomics2.hip (~10.6 clk per 64-lane instruction).
 // ---------------------------------------------------------------------------------------
-constexpr int kMaxBands = 1024;            // bands per level (host falls back to the atomic kernel beyond)
-constexpr int kBinKeysPerBlock = 256 * 32;
-
-// n / d for any 32-bit n without a division (Granlund & Montgomery round-up method; host computes m, l from d)
-struct SoFastDiv {
-    unsigned m;
-    int l;
-};
-SO_DEVFN int so_fastdiv(int n, SoFastDiv f) {
-    if (f.l == 0) return n;                      // d == 1
-    const unsigned t = __umulhi(f.m, (unsigned)n);
-    return (int)((t + (((unsigned)n - t) >> 1)) >> (f.l - 1));
-}
-
-struct MsdaBinPlan {
-    int rows[8];      // rows per band of level l
-    int bands[8];     // bands of level l
-    int band0[9];     // first band of level l within a (batch, head)
-    int nbands;       // bands per (batch, head)
-    int seg;          // list entries per band-kernel block
-    SoFastDiv divP;   // key index -> query
-};
-
 template <bool FILL>
 __global__ __launch_bounds__(256) void msda_bin_kernel(const int16_t *__restrict__ keys, const int32_t *__restrict__ shapes,
                                                        int32_t *__restrict__ cnt, int32_t *__restrict__ cursor,
@@ -863,9 +902,10 @@ __global__ __launch_bounds__(256) void msda_bin_kernel(const int16_t *__restrict
     const int chunk = blockIdx.x - (int)(bhl * bpb);
     const int l = (int)(bhl % dm.L);
     const long long bh = bhl / dm.L;
-    int rows_l = plan.rows[0], bands_l = plan.bands[0], band0 = 0;
+    int bands_l = plan.bands[0], band0 = 0;
+    float inv_rows = plan.inv_rows[0];
     for (int k = 1; k < 8; ++k)
-        if (k == l) { rows_l = plan.rows[k]; bands_l = plan.bands[k]; band0 = plan.band0[k]; }
+        if (k == l) { bands_l = plan.bands[k]; band0 = plan.band0[k]; inv_rows = plan.inv_rows[k]; }
     const int Hl = shapes[2 * l];
     const long long n = (long long)dm.nq * dm.P;                      // keys of one (b, h, l)
     const long long kbase = bhl * n;
@@ -873,8 +913,6 @@ __global__ __launch_bounds__(256) void msda_bin_kernel(const int16_t *__restrict
     const long long win = (kbase & ~3LL) + (long long)chunk * kBinKeysPerBlock;
     const long long lo = max(kbase, win), hi = min(kbase + n, win + kBinKeysPerBlock);
     const long long bucket0 = (bh * plan.nbands + band0) * 2;         // bucket = (band id) * 2 + class
-    const float inv_rows = 1.0f / (float)rows_l;
-
     for (int i = threadIdx.x; i < 2 * bands_l; i += 256) hist[i] = 0;
 
     // every lane loads its keys ONCE (4 consecutive keys = 8 aligned bytes per step, all steps in flight together);
@@ -1375,7 +1413,7 @@ int so_band_setup(const int32_t *host_shapes, int bs, int nq, int heads, int d, 
     bsu.ok = L <= 8;
     bsu.tile_px = 0;
     int nb = 0;
-    for (int l = 0; l < 8; ++l) { bp.rows[l] = 1; bp.bands[l] = 0; bp.band0[l] = 0; }
+    for (int l = 0; l < 8; ++l) { bp.rows[l] = 1; bp.bands[l] = 0; bp.band0[l] = 0; bp.inv_rows[l] = 1.0f; }
     for (int l = 0; l < L && bsu.ok; ++l) {
         const int Hl = host_shapes[2 * l], Wl = host_shapes[2 * l + 1];
         SO_REQUIRE(Hl >= 0 && Wl >= 0 && Hl < 32767 && Wl < 32767, "msda banded: bad level shape (%d, %d)", Hl, Wl);
@@ -1383,6 +1421,7 @@ int so_band_setup(const int32_t *host_shapes, int bs, int nq, int heads, int d, 
         if (Hl == 0 || Wl == 0) continue;
         if (Wl > cap_px) { bsu.ok = false; break; }
         bp.rows[l] = std::min(Hl, cap_px / Wl);
+        bp.inv_rows[l] = 1.0f / (float)bp.rows[l];
         bp.bands[l] = (Hl + bp.rows[l] - 1) / bp.rows[l];
         if (bp.bands[l] > kMaxBands) { bsu.ok = false; break; }
         nb += bp.bands[l];
@@ -1425,7 +1464,7 @@ BandWorkspace so_band_workspace(void *workspace, int bs, int nq, int heads, int 
 // invisible (camera, query) pairs are unwritten and must not be read (needs P >= 4, see msda_bin_kernel)
 int so_band_scatter(const int32_t *shapes, const int32_t *starts, const float *g_out, float *g_value,
                     const BandWorkspace &w, const BandSetup &bsu, MsdaDims dm, int d, const unsigned char *vis,
-                    hipStream_t st) {
+                    hipStream_t st, bool counted = false) {
     const MsdaBinPlan &bp = bsu.bin;
     const int nb = dm.bs * dm.heads * bp.nbands;                 // bands over all (batch, head)
     int32_t *cnt = w.counters, *cursor = cnt + 2 * (size_t)nb, *off = cursor + 2 * (size_t)nb, *item0 = off + 2 * (size_t)nb;
@@ -1434,9 +1473,11 @@ int so_band_scatter(const int32_t *shapes, const int32_t *starts, const float *g
     const long long bin_blocks = (long long)dm.bs * dm.heads * dm.L * bpb;
     const long long max_items = nb + (2 * w.n_pts) / bp.seg;
     SO_REQUIRE(bin_blocks < (1LL << 31) && max_items < (1LL << 31), "msda banded: grid too large");
-    (void)hipMemsetAsync(cnt, 0, (size_t)nb * 4 * sizeof(int32_t), st);     // cnt and cursor
-    hipLaunchKernelGGL(msda_bin_kernel<false>, dim3((unsigned)bin_blocks), dim3(256), 0, st, w.keys, shapes, cnt,
-                       cursor, off, w.list, vis, bpb, dm, bp);
+    if (!counted) {      // counted: the point kernel zeroed-and-filled cnt (and zeroed cursor) already
+        (void)hipMemsetAsync(cnt, 0, (size_t)nb * 4 * sizeof(int32_t), st);     // cnt and cursor
+        hipLaunchKernelGGL(msda_bin_kernel<false>, dim3((unsigned)bin_blocks), dim3(256), 0, st, w.keys, shapes, cnt,
+                           cursor, off, w.list, vis, bpb, dm, bp);
+    }
     hipLaunchKernelGGL(msda_bin_scan_kernel, dim3(1), dim3(1024), 0, st, cnt, off, item0, nb, bp.seg);
     hipLaunchKernelGGL(msda_bin_kernel<true>, dim3((unsigned)bin_blocks), dim3(256), 0, st, w.keys, shapes, cnt,
                        cursor, off, w.list, vis, bpb, dm, bp);
@@ -1550,6 +1591,8 @@ extern "C" int selfocc_msda_fused_bwd(const void *value, const int32_t *shapes, 
     const int gpb = 256 / G;
     const long long blocks = (n_groups + gpb - 1) / gpb;
     SO_REQUIRE(blocks < (1LL << 31), "msda_fused_bwd: grid too large");
+    // (counting the sort's buckets inside this kernel, as selfocc_msda_cross_bwd does, measured slower here: 454 -> 570 us for
+    // 58 us of msda_bin_kernel<false>: 32 groups per block contend for the few buckets of one plane)
 #define SO_LAUNCH_G(DD, LG)                                                                                  \
     if (value_dtype == SO_DTYPE_BF16)                                                                        \
         hipLaunchKernelGGL((msda_fused_bwd_point_kernel<DD, LG, uint16_t>), dim3((unsigned)blocks), dim3(256), 0, st,  \
@@ -1623,15 +1666,25 @@ extern "C" int selfocc_msda_cross_bwd(const void *value, const int32_t *shapes, 
     const int gpb = 256 / G;
     const long long blocks = (n_groups + gpb - 1) / gpb;
     SO_REQUIRE(blocks < (1LL << 31), "msda_cross_bwd: grid too large");
+    // the point kernel does the sort's counting pass itself (an LDS histogram per block, flushed once) when a block's groups
+    // span at most two heads and the histogram fits: saves one pass over the keys (msda_bin_kernel<false>, 0.9 ms per iteration)
+    static const bool count_env = so_env_int("SELFOCC_MSDA_COUNT_IN_POINT", 1) != 0;
+    const size_t hist_need = (size_t)2 * cams * bsu.bin.nbands * 2 * sizeof(int);
+    const bool count_here = count_env && nq >= gpb && hist_need <= 32 * 1024;
+    const size_t hist_bytes = count_here ? hist_need : 0;
+    if (count_here) {
+        const size_t nb_all = (size_t)cams * heads * bsu.bin.nbands;
+        (void)hipMemsetAsync(w.counters, 0, nb_all * 4 * sizeof(int32_t), st);      // cnt and cursor, before the counting kernel
+    }
 #define SO_LAUNCH_G(DD, LG)                                                                                  \
     if (value_dtype == SO_DTYPE_BF16)                                                                        \
-        hipLaunchKernelGGL((msda_cross_bwd_point_kernel<DD, LG, uint16_t>), dim3((unsigned)blocks), dim3(256), 0, st,  \
+        hipLaunchKernelGGL((msda_cross_bwd_point_kernel<DD, LG, uint16_t>), dim3((unsigned)blocks), dim3(256), hist_bytes, st,  \
                            (const uint16_t *)value, shapes, starts, ref, vis, off_raw, logits, g_out, g_off, g_logits, \
-                           w.keys, w.recs, cams, dm);                                                        \
+                           w.keys, w.recs, cams, dm, count_here ? w.counters : nullptr, bsu.bin);            \
     else                                                                                                     \
-        hipLaunchKernelGGL((msda_cross_bwd_point_kernel<DD, LG, float>), dim3((unsigned)blocks), dim3(256), 0, st,     \
+        hipLaunchKernelGGL((msda_cross_bwd_point_kernel<DD, LG, float>), dim3((unsigned)blocks), dim3(256), hist_bytes, st,     \
                            (const float *)value, shapes, starts, ref, vis, off_raw, logits, g_out, g_off, g_logits,    \
-                           w.keys, w.recs, cams, dm)
+                           w.keys, w.recs, cams, dm, count_here ? w.counters : nullptr, bsu.bin)
 #define SO_LAUNCH(DD)                                                                                        \
     switch (logG) {                                                                                          \
         case 0: SO_LAUNCH_G(DD, 0); break;                                                                   \
@@ -1650,5 +1703,5 @@ extern "C" int selfocc_msda_cross_bwd(const void *value, const int32_t *shapes, 
     }
 #undef SO_LAUNCH
 #undef SO_LAUNCH_G
-    return so_band_scatter(shapes, starts, g_out, g_value, w, bsu, dm, d, bin_vis, st);
+    return so_band_scatter(shapes, starts, g_out, g_value, w, bsu, dm, d, bin_vis, st, count_here);
 }
