@@ -690,6 +690,8 @@ __global__ __launch_bounds__(256) void msda_fused_bwd_point_kernel(const VT *__r
 // record's weight already divided by cnt, and the band kernel reads the shared g_out row (go_shared).
 // ---------------------------------------------------------------------------------------
 template <int D, int LOGG, typename VT>
+// (no register cap: with min-waves 4 the compiler holds the kernel at 105 / 101 registers instead of 115 / 111 and the
+// iteration loses 1.3 ms — fewer corner gathers in flight per wave; 5 / 6 waves spill)
 __global__ __launch_bounds__(256) void msda_cross_bwd_point_kernel(const VT *__restrict__ value,
                                                                    const int32_t *__restrict__ shapes,
                                                                    const int32_t *__restrict__ starts,
