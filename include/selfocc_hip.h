@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SELFOCC_ABI_VERSION 27
+#define SELFOCC_ABI_VERSION 28
 
 int selfocc_abi_version(void);
 const char *selfocc_last_error(void);
@@ -173,9 +173,22 @@ typedef struct so_render_bwd_args {
     float *g_sdf_vol;         /* [H][W][D]                                             */
     float *g_feat_vol;        /* [H][W][D][feat_stride] float32                        */
     float *g_inv_s;           /* (1)                                                   */
+    /* Optional scratch for the BRICK-BINNED volume-gradient scatter (round 4).  NULL: every sample adds its
+     * 8 corner rows to g_sdf_vol / g_feat_vol with device-scope float atomics (on MI355X each one is a write
+     * through the fabric: 3.1 GB of them for a 165 MB gradient at the nuscenes_occ training shape).  Given
+     * (>= selfocc_render_bwd_ws_bytes() bytes, 256-B aligned): the ray kernel writes one record per sample
+     * (cell, fractions, d L / d feature row, SDF coefficients) and a brick key (8 x 8 x 8 cells); a counting
+     * sort groups the samples by brick; one workgroup per (brick, <= chunk samples) sums them into a
+     * 9 x 9 x 9-voxel tile in LDS (ds_add_f32) and adds the tile's non-zero rows to the gradient once.
+     * Same sums, different (still unspecified) float addition order.                                       */
+    void *scatter_ws;
+    uint64_t scatter_ws_bytes;
 } so_render_bwd_args;
 
 int selfocc_render_bwd(const so_render_bwd_args *args, void *stream);
+/* bytes of so_render_bwd_args::scatter_ws for this call (0: the shape is outside the binned path's range,
+ * i.e. an axis longer than 1022 grid points; pass NULL then) */
+size_t selfocc_render_bwd_ws_bytes(const so_render_bwd_args *args);
 
 /* ------------------------------------------------------------------------------------
  * Multi-scale deformable attention.  Replaces mmcv==2.0.1

@@ -6,7 +6,7 @@ its exported symbols being callable with these layouts.
 """
 import ctypes as C
 
-ABI_VERSION = 27
+ABI_VERSION = 28
 
 # enums ---------------------------------------------------------------------------
 RAYS_EXPLICIT, RAYS_PIXEL_GRID = 0, 1
@@ -60,6 +60,7 @@ class SoRenderBwdArgs(C.Structure):
         ("g_depth", _p), ("g_acc", _p), ("g_rgb", _p), ("g_sem", _p),
         ("g_weights", _p), ("g_sdf", _p), ("g_grad", _p),
         ("g_sdf_vol", _p), ("g_feat_vol", _p), ("g_inv_s", _p),
+        ("scatter_ws", _p), ("scatter_ws_bytes", C.c_uint64),
     ]
 
 
@@ -105,11 +106,12 @@ SYMBOLS = {
     "selfocc_last_error": (C.c_char_p, []),
     "selfocc_render_fwd": (C.c_int, [C.POINTER(SoRenderArgs), _p]),
     "selfocc_render_bwd": (C.c_int, [C.POINTER(SoRenderBwdArgs), _p]),
+    "selfocc_render_bwd_ws_bytes": (C.c_size_t, [C.POINTER(SoRenderBwdArgs)]),
     "selfocc_msda_fwd": (C.c_int, [_p, _p, _p, _p, _p, _p] + [_i] * 7 + [_p]),
     "selfocc_msda_fused_fwd": (C.c_int, [_p, _p, _p, _p, _i, _p, _p, _p] + [_i] * 9 + [_p]),
     "selfocc_msda_cross_fwd": (C.c_int, [_p] * 8 + [_i] * 10 + [_p]),
     "selfocc_msda_pro_supported": (C.c_int, [_i] * 5),
-    "selfocc_msda_pro_fwd": (C.c_int, [_p] * 12 + [_i] * 12 + [_p]),
+    "selfocc_msda_pro_fwd": (C.c_int, [_p] * 4 + [_i] + [_p] * 7 + [_i] * 12 + [_p]),
     "selfocc_msda_cross_lds_supported": (C.c_int, [_p] + [_i] * 4),
     "selfocc_msda_cross_lds_workspace": (C.c_size_t, [_i] * 4),
     "selfocc_msda_cross_lds_fwd": (C.c_int, [_p] * 9 + [_i] * 7 + [_p, C.c_size_t, _p]),

@@ -15,6 +15,7 @@
 // d L / d alpha_i = T_i (Gw_i - E_i), Gw_i = total derivative of the loss wrt weight i.
 // The volume gradient is a scatter of 8 (+ 8 * n_feat) hardware float atomics per sample.
 #include "so_device.h"
+#include <stdlib.h>
 #include <type_traits>
 
 namespace {
@@ -90,13 +91,100 @@ SO_DEVFN void load_feat(const void *vol, size_t vox, float f[NF > 0 ? NF : 1]) {
     }
 }
 
+// ---- brick-binned scatter (so_render_bwd_args::scatter_ws) -----------------------------------------------
+// The volume is cut into bricks of kBH x kBW x kBD CELLS; the voxels a brick's samples touch are the
+// (kBH + 1)(kBW + 1)(kBD + 1) tile that shares its upper faces with the neighbouring bricks.
+//   rb_count_kernel   one thread per sample: the sample's cell (same code as the ray kernel) -> its brick; counts the
+//                     samples per (brick, shard), one integer atomic per run of consecutive samples with one counter
+//   rb_scan1 / scan2  counts -> slot cursors per (brick, shard) and a list of work items (brick, <= chunk samples)
+//   render_bwd_kernel<.., BIN = true>  takes the slots of its runs (one returning atomic per run, issued early) and
+//                     writes ONE RECORD PER SAMPLE AT ITS SLOT, i.e. in brick order.  A record is RECF floats:
+//                         [0 .. NCH)        d L / d (interpolated feature channel)
+//                         [RECF - 8]        ds                (coefficient of the trilinear weights in d L / d sdf corner)
+//                         [RECF - 7]        packed cell       ((h0 + 1) << 20 | (w0 + 1) << 10 | (d0 + 1), as bits)
+//                         [RECF - 6 .. -4]  fh1, fw1, fd1     (fractions inside the cell)
+//                         [RECF - 3 .. -1]  qx, qy, qz        (coefficients of the weights' axis derivatives)
+//   rb_brick_kernel   one workgroup per item: streams the item's records, sums them into the brick's tile in LDS and
+//                     adds the tile's non-zero rows to the gradient volumes: (items x touched rows) row atomics instead
+//                     of (sample runs x 8).  The tile is DOUBLE: ds_add_f64 issues in ~10 clocks per 64-lane
+//                     instruction on gfx950, ds_add_f32 in ~3 clocks per LANE (measured again here:
+//                     7.7 ms with a float tile).
+constexpr int kBH = 4, kBW = 4, kBD = 8;
+constexpr int kTH = kBH + 1, kTW = kBW + 1, kTD = kBD + 1;
+constexpr int kTileVox = kTH * kTW * kTD;   // 225
+constexpr int kInvsSlots = 1024;
+constexpr int kShards = 8;   // counters per brick (shard = bits 8.. of the sample index): the bricks around the cameras
+                             // are entered by every ray, and same-address atomics serialise at ~12 ns each
+SO_DEVFN int rb_shard(long long sample) { return (int)(sample >> 8) & (kShards - 1); }
+
+template <int NF>
+struct RbRec {
+    static constexpr int NCH = NF == 4 ? 3 : NF;                      // feature channels with a gradient
+    static constexpr int RECF = NF >= 20 ? 32 : (NF >= 4 ? 16 : 8);   // floats per record = lanes per sample
+    static constexpr int RW = NCH + 1;                                 // tile row: features then the sdf column
+};
+
+struct RbBin {
+    float *rec;        // [n_rays * n_samples][RECF], in brick order
+    int *counts;       // [n_bricks][kShards] (zeroed per call, together with invs_part and n_items)
+    float *invs_part;  // [kInvsSlots]     partial sums of d L / d inv_s
+    int *n_items;      // [1]
+    int *cursor;       // [n_bricks][kShards] next free slot
+    int2 *blk_tot;     // [ceil(n_bricks / 1024)] (samples, items) per scan block
+    int4 *items;       // [max_items] {brick, begin, end, -}
+    int nbh, nbw, nbd, chunk;
+    int dbg;           // dev switches (SELFOCC_RB_DBG): 1 = no LDS adds, 2 = no flush
+};
+
+SO_DEVFN int rb_key(const RbBin &b, const so_cell &c, int H, int W, int D) {
+    const int bh = min(max(c.h0, 0), H - 1) / kBH, bw = min(max(c.w0, 0), W - 1) / kBW, bd = min(max(c.d0, 0), D - 1) / kBD;
+    return (bh * b.nbw + bw) * b.nbd + bd;
+}
+
+// entry / exit of the ray in the box collider, and the cell of sample i: ONE definition for the ray kernel and the
+// counting pre-pass (they must agree on every sample's brick)
+SO_DEVFN void ray_bounds(const so_render_args &a, const RayGeomB &g, float &tn, float &tf) {
+    const float fx = 1.0f / (g.dx + 1e-6f), fy = 1.0f / (g.dy + 1e-6f), fz = 1.0f / (g.dz + 1e-6f);
+    const float t1 = (a.aabb[0] - g.ox) * fx, t2 = (a.aabb[3] - g.ox) * fx;
+    const float t3 = (a.aabb[1] - g.oy) * fy, t4 = (a.aabb[4] - g.oy) * fy;
+    const float t5 = (a.aabb[2] - g.oz) * fz, t6 = (a.aabb[5] - g.oz) * fz;
+    tn = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
+    tf = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
+    tn = fmaxf(tn, a.near_plane);
+    tf = fmaxf(tf, tn + 1e-6f);
+}
+
+SO_DEVFN so_cell sample_cell(const so_render_args &a, const RayGeomB &g, float t0, float t1) {
+    float px, py, pz;
+    if (a.sample_pos == SO_SAMPLE_AT_START) {
+        px = g.ox + g.dx * t0; py = g.oy + g.dy * t0; pz = g.oz + g.dz * t0;
+    } else {
+        const float tt = t0 + t1;
+        px = g.ox + (g.dx * tt) / 2.0f; py = g.oy + (g.dy * tt) / 2.0f; pz = g.oz + (g.dz * tt) / 2.0f;
+    }
+    return so_locate(a.map, px, py, pz);
+}
+
+// run of consecutive lanes with one key: returns the run's length at its head lane (0 elsewhere) and the head's lane
+SO_DEVFN int rb_run(int key, int lane, int &head_lane) {
+    const int prev = __shfl_up(key, 1, 64);
+    const bool head = (lane == 0) || (key != prev);
+    const unsigned long long hm = __ballot(head);
+    const unsigned long long upto = hm & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));   // heads at lanes <= mine
+    head_lane = 63 - __clzll((long long)upto);
+    if (!head) return 0;
+    const unsigned long long later = (lane == 63) ? 0ull : (hm >> (lane + 1));
+    return later ? __ffsll((long long)later) : 64 - lane;
+}
+
 // WPR = waves per ray.  WPR == 1: a wave owns a ray and M * 64 samples (4 rays per block).  WPR == 4: the
 // block's four waves share one ray, wave w taking step (j * 4 + w) — at the shipped 256 samples per ray
 // that is M = 1, which cuts the per-sample register state 4x (the M = 4 form needed > 256 VGPRs: one wave
 // per SIMD, latency-bound); scan carries and per-ray sums cross the waves through a few floats of LDS.
-template <int NF, bool BF16, int M, int WPR>
-__global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba) {
+template <int NF, bool BF16, int M, int WPR, bool BIN>
+__global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba, RbBin bin) {
     static_assert(WPR == 1 || WPR == 4, "waves per ray");
+    constexpr int RECF = RbRec<NF>::RECF, NCH = RbRec<NF>::NCH;
     const so_render_args &a = ba.fwd;
     constexpr int NSEM = NF > 4 ? NF - 3 : 0;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -120,23 +208,14 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba) 
         }
     };
     // per-wave transpose buffer of the feature-gradient scatter (phase B); odd record stride
-    __shared__ __attribute__((aligned(16))) float lds_rec[4 * 64 * (NF > 0 ? (NF + 9 + (((NF + 9) & 1) ? 0 : 1)) : 9)];
+    __shared__ __attribute__((aligned(16))) float lds_rec[BIN ? 4 : 4 * 64 * (NF > 0 ? (NF + 9 + (((NF + 9) & 1) ? 0 : 1)) : 9)];
     if (ray >= a.n_rays) return;  // wave-uniform (block-uniform when the waves share a ray)
     const int H = a.map.h.tot_len, W = a.map.w.tot_len, D = a.map.d.tot_len;
     const int S = a.n_samples;
     const RayGeomB g = load_ray(a, ray);
 
     float tn, tf;
-    {
-        const float fx = 1.0f / (g.dx + 1e-6f), fy = 1.0f / (g.dy + 1e-6f), fz = 1.0f / (g.dz + 1e-6f);
-        const float t1 = (a.aabb[0] - g.ox) * fx, t2 = (a.aabb[3] - g.ox) * fx;
-        const float t3 = (a.aabb[1] - g.oy) * fy, t4 = (a.aabb[4] - g.oy) * fy;
-        const float t5 = (a.aabb[2] - g.oz) * fz, t6 = (a.aabb[5] - g.oz) * fz;
-        tn = fmaxf(fmaxf(fminf(t1, t2), fminf(t3, t4)), fminf(t5, t6));
-        tf = fminf(fminf(fmaxf(t1, t2), fmaxf(t3, t4)), fmaxf(t5, t6));
-        tn = fmaxf(tn, a.near_plane);
-        tf = fmaxf(tf, tn + 1e-6f);
-    }
+    ray_bounds(a, g, tn, tf);
 
     // ---- phase A: per-sample forward state -------------------------------------------------
     so_cell cell[M];
@@ -150,14 +229,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba) 
         const float t0 = edge_t(a, ray, ic, tn, tf), t1 = edge_t(a, ray, ic + 1, tn, tf);
         delta[j] = t1 - t0;
         tmid[j] = (t0 + t1) / 2.0f;
-        float px, py, pz;
-        if (a.sample_pos == SO_SAMPLE_AT_START) {
-            px = g.ox + g.dx * t0; py = g.oy + g.dy * t0; pz = g.oz + g.dz * t0;
-        } else {
-            const float tt = t0 + t1;
-            px = g.ox + (g.dx * tt) / 2.0f; py = g.oy + (g.dy * tt) / 2.0f; pz = g.oz + (g.dz * tt) / 2.0f;
-        }
-        cell[j] = so_locate(a.map, px, py, pz);
+        cell[j] = sample_cell(a, g, t0, t1);
         float v[8], wk[8];
         so_gather_sdf(a.sdf_vol, H, W, D, cell[j], v);
         sdfv[j] = so_trilerp_sdf(cell[j], v, wk);
@@ -172,6 +244,19 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba) 
         unclipped[j] = (araw > 0.0f) && (araw < 1.0f);
         alpha[j] = live[j] ? fminf(fmaxf(araw, 0.0f), 1.0f) : 0.0f;
         fj[j] = live[j] ? (1.0f - alpha[j]) + 1e-7f : 1.0f;
+    }
+    // BIN: the slots of this wave's samples in the brick-ordered record array: one returning atomic per run of lanes
+    // with one (brick, shard) counter, issued here so that its latency hides behind phase B's gathers
+    int slot_base[M], slot_head[M];
+    if constexpr (BIN) {
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+            int key = -1;
+            if (live[j]) key = rb_key(bin, cell[j], H, W, D) * kShards + rb_shard((long long)ray * S + ((j * WPR + wstep) * 64 + lane));
+            const int run = rb_run(key, lane, slot_head[j]);
+            slot_base[j] = 0;
+            if (run > 0 && key >= 0) slot_base[j] = atomicAdd(bin.cursor + key, run);
+        }
     }
     // transmittance: exclusive prefix product over the samples in ray order = per step an exclusive scan
     // over the lanes (Hillis-Steele on shuffles) times the product of all earlier steps
@@ -332,7 +417,21 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba) 
                     for (int k = 0; k < NSEM; ++k) df[3 + k] = w[j] * pk[k] * (g_semr[k] - gp);  // softmax backward
                 }
             }
-            if (ba.g_feat_vol) {   // wave-uniform
+            if constexpr (BIN) {
+                const int slot = __shfl(slot_base[j], slot_head[j], 64) + (lane - slot_head[j]);
+                if (live[j]) {   // the feature part of the sample's record, 16 bytes at a time
+                    float4 *dst = (float4 *)(bin.rec + (size_t)slot * RECF);
+#pragma unroll
+                    for (int q = 0; q < (RECF - 8) / 4; ++q) {
+                        float4 t;
+                        t.x = (4 * q < NCH) ? df[(4 * q < NCH) ? 4 * q : 0] : 0.0f;
+                        t.y = (4 * q + 1 < NCH) ? df[(4 * q + 1 < NCH) ? 4 * q + 1 : 0] : 0.0f;
+                        t.z = (4 * q + 2 < NCH) ? df[(4 * q + 2 < NCH) ? 4 * q + 2 : 0] : 0.0f;
+                        t.w = (4 * q + 3 < NCH) ? df[(4 * q + 3 < NCH) ? 4 * q + 3 : 0] : 0.0f;
+                        dst[q] = t;
+                    }
+                }
+            } else if (ba.g_feat_vol) {   // wave-uniform
                 float *mine = rec + lane * REC;
                 mine[0] = __int_as_float((cell[j].h0 * W + cell[j].w0) * D + cell[j].d0);
 #pragma unroll
@@ -423,6 +522,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba) 
     for (int j = M - 1; j >= 0; --j) {
         float dalpha = T[j] * (Gw[j] - Ev[j]);
         float coefs[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        float r_ds = 0.0f, r_qx = 0.0f, r_qy = 0.0f, r_qz = 0.0f;   // BIN: the record's sdf coefficients
         if (live[j]) {
             if (!unclipped[j]) dalpha = 0.0f;
             const float pe = Pc[j] + 1e-5f;
@@ -438,7 +538,10 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba) 
             float dgx = dc * g.dx, dgy = dc * g.dy, dgz = dc * g.dz;
             if (ba.g_sdf) ds += ba.g_sdf[so];
             if (ba.g_grad) { dgx += ba.g_grad[3 * so]; dgy += ba.g_grad[3 * so + 1]; dgz += ba.g_grad[3 * so + 2]; }
-            if (ba.g_sdf_vol) {
+            if (BIN && ba.g_sdf_vol) {
+                r_ds = ds; r_qx = dgx * cell[j].sw; r_qy = dgy * cell[j].sh; r_qz = dgz * cell[j].sd;
+            }
+            if (!BIN && ba.g_sdf_vol) {
                 // sdf = sum_k W_k v_k ; grad_axis = slope_axis * sum_k dW_k/d axis * v_k
                 const so_cell &c = cell[j];
                 const float fd[2] = {c.fd0, c.fd1}, fw[2] = {c.fw0, c.fw1}, fh[2] = {c.fh0, c.fh1};
@@ -456,7 +559,17 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba) 
                 }
             }
         }
-        if (ba.g_sdf_vol) {   // wave-uniform
+        if constexpr (BIN) {
+            const so_cell &c = cell[j];
+            const int slot = __shfl(slot_base[j], slot_head[j], 64) + (lane - slot_head[j]);
+            if (live[j]) {
+                const int pack = ((min(max(c.h0, -1), 1022) + 1) << 20) | ((min(max(c.w0, -1), 1022) + 1) << 10) |
+                                 (min(max(c.d0, -1), 1022) + 1);
+                float4 *dst = (float4 *)(bin.rec + (size_t)slot * RECF + (RECF - 8));
+                dst[0] = make_float4(r_ds, __int_as_float(pack), c.fh1, c.fw1);
+                dst[1] = make_float4(c.fd1, r_qx, r_qy, r_qz);
+            }
+        } else if (ba.g_sdf_vol) {   // wave-uniform
             // Scalar per-lane atomics would be one 64-byte fabric write each (8 per sample: as much traffic as
             // the whole feature scatter).  Instead 8-lane rows (one corner per lane) walk the samples in ray
             // order and add the coefficients of a run of samples inside one voxel before one atomic per corner.
@@ -490,23 +603,267 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba) 
     }
     if (ba.g_inv_s) {
         const float t = wave_sum(dinv_s_l);
-        if (lane == 0) unsafeAtomicAdd(ba.g_inv_s, t);
+        // BIN: kInvsSlots partial sums (rb_brick_kernel's first block adds them up) instead of one atomic per wave on ONE word
+        if (lane == 0) unsafeAtomicAdd(BIN ? bin.invs_part + (blockIdx.x & (kInvsSlots - 1)) : ba.g_inv_s, t);
     }
 }
 
-template <int NF, bool BF16>
-int launch_m(const so_render_bwd_args &ba, hipStream_t st) {
+// ---- the binned scatter's own kernels ---------------------------------------------------------------------
+// one wave per ray (the ray's geometry once per lane, then S / 64 steps of 64 consecutive samples)
+__global__ __launch_bounds__(256) void rb_count_kernel(so_render_args a, RbBin b) {
+    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (ray >= a.n_rays) return;
+    const int S = a.n_samples;
+    const RayGeomB g = load_ray(a, ray);
+    float tn, tf;
+    ray_bounds(a, g, tn, tf);
+    const int H = a.map.h.tot_len, W = a.map.w.tot_len, D = a.map.d.tot_len;
+    for (int s0 = 0; s0 < S; s0 += 64) {
+        const int smp = s0 + lane;
+        int key = -1;
+        if (smp < S) {
+            const so_cell c = sample_cell(a, g, edge_t(a, ray, smp, tn, tf), edge_t(a, ray, smp + 1, tn, tf));
+            key = rb_key(b, c, H, W, D) * kShards + rb_shard((long long)ray * S + smp);
+        }
+        int hl;
+        const int run = rb_run(key, lane, hl);
+        if (run > 0 && key >= 0) atomicAdd(b.counts + key, run);
+    }
+}
+
+// counts -> cursors + items, in two launches of ceil(n_bricks / 1024) blocks: per-block totals, then the scan proper
+__global__ __launch_bounds__(1024) void rb_scan1_kernel(RbBin b) {
+    __shared__ int sc[16], sn[16];
+    const int nb = b.nbh * b.nbw * b.nbd;
+    const int k = blockIdx.x * 1024 + threadIdx.x;
+    int c = 0;
+    if (k < nb) {
+        const int4 *p = (const int4 *)(b.counts + (size_t)k * kShards);
+        const int4 x = p[0], y = p[1];
+        c = ((x.x + x.y) + (x.z + x.w)) + ((y.x + y.y) + (y.z + y.w));
+    }
+    int n = (c + b.chunk - 1) / b.chunk;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { c += __shfl_xor(c, m, 64); n += __shfl_xor(n, m, 64); }
+    if ((threadIdx.x & 63) == 0) { sc[threadIdx.x >> 6] = c; sn[threadIdx.x >> 6] = n; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int cc = 0, nn = 0;
+        for (int w = 0; w < 16; ++w) { cc += sc[w]; nn += sn[w]; }
+        b.blk_tot[blockIdx.x] = make_int2(cc, nn);
+    }
+}
+
+__global__ __launch_bounds__(1024) void rb_scan2_kernel(RbBin b) {
+    __shared__ int sc[1024], sn[1024];
+    static_assert(kShards == 8, "two int4 loads per brick");
+    const int t = threadIdx.x;
+    const int nb = b.nbh * b.nbw * b.nbd;
+    const int k = blockIdx.x * 1024 + t;
+    int cs[kShards];
+    int c = 0;
+    if (k < nb) {
+        const int4 *p = (const int4 *)(b.counts + (size_t)k * kShards);
+        const int4 x = p[0], y = p[1];
+        cs[0] = x.x; cs[1] = x.y; cs[2] = x.z; cs[3] = x.w; cs[4] = y.x; cs[5] = y.y; cs[6] = y.z; cs[7] = y.w;
+#pragma unroll
+        for (int sh = 0; sh < kShards; ++sh) c += cs[sh];
+    }
+    const int n = (c + b.chunk - 1) / b.chunk;
+    int c0 = 0, n0 = 0;   // totals of the earlier blocks
+    for (int q = 0; q < (int)blockIdx.x; ++q) { const int2 v = b.blk_tot[q]; c0 += v.x; n0 += v.y; }
+    sc[t] = c; sn[t] = n;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {   // inclusive Hillis-Steele scans (samples, items)
+        const int oc = t >= d ? sc[t - d] : 0, on = t >= d ? sn[t - d] : 0;
+        __syncthreads();
+        sc[t] += oc; sn[t] += on;
+        __syncthreads();
+    }
+    if (k < nb) {
+        const int coff = c0 + sc[t] - c;
+        int noff = n0 + sn[t] - n;
+        int run = coff;
+        int4 x, y;
+        x.x = run; run += cs[0]; x.y = run; run += cs[1]; x.z = run; run += cs[2]; x.w = run; run += cs[3];
+        y.x = run; run += cs[4]; y.y = run; run += cs[5]; y.z = run; run += cs[6]; y.w = run;
+        int4 *q = (int4 *)(b.cursor + (size_t)k * kShards);   // a brick's shards are consecutive ranges of the sorted order
+        q[0] = x; q[1] = y;
+        for (int o = 0; o < c; o += b.chunk) b.items[noff++] = make_int4(k, coff + o, coff + min(o + b.chunk, c), 0);
+    }
+    if (blockIdx.x == gridDim.x - 1 && t == 1023) b.n_items[0] = n0 + sn[1023];
+}
+
+// One workgroup per item: the item's records (contiguous) summed into the brick's tile in LDS, the tile added to the volumes.
+template <int NF, int NT>
+__global__ __launch_bounds__(NT) void rb_brick_kernel(RbBin b, float *__restrict__ g_sdf_vol, float *__restrict__ g_feat_vol,
+                                                      float *__restrict__ g_inv_s, int H, int W, int D) {
+    constexpr int RECF = RbRec<NF>::RECF, NCH = RbRec<NF>::NCH, RW = RbRec<NF>::RW;
+    constexpr int NG = NT / RECF, U = 4;
+    extern __shared__ double tile[];   // [kTileVox][RW]
+    if (blockIdx.x == 0 && g_inv_s) {   // the ray kernel's partial sums of d L / d inv_s: one atomic per wave of this block
+        float t = 0.0f;
+        for (int k = threadIdx.x; k < kInvsSlots; k += NT) t += b.invs_part[k];
+        t = wave_sum(t);
+        if ((threadIdx.x & 63) == 0) unsafeAtomicAdd(g_inv_s, t);
+    }
+    if ((int)blockIdx.x >= b.n_items[0]) return;
+    const int4 it = b.items[blockIdx.x];
+    const int bd = it.x % b.nbd, bw = (it.x / b.nbd) % b.nbw, bh = it.x / (b.nbd * b.nbw);
+    const int oh = bh * kBH, ow = bw * kBW, od = bd * kBD;
+    for (int k = threadIdx.x; k < kTileVox * RW; k += NT) tile[k] = 0.0;
+    __syncthreads();
+    const int grp = threadIdx.x / RECF, sub = threadIdx.x % RECF;
+    // lanes [0, NCH) of a group: one feature channel each, all 8 corners; lanes [RECF - 8, RECF): ONE corner each of the
+    // sdf column (its coefficient has four terms: spreading the corners over the 8 otherwise idle tail lanes keeps the
+    // per-corner loop of the feature lanes at one multiply)
+    const bool sdf_lane = sub >= RECF - 8;
+    const int mk = sub - (RECF - 8), mkd = mk & 1, mkw = (mk >> 1) & 1, mkh = (mk >> 2) & 1;
+    const int moff = ((mkh * kTW + mkw) * kTD + mkd) * RW + NCH;
+    // consecutive groups take consecutive records: a block step reads NG * RECF * 4 contiguous bytes
+    for (int i0 = it.y; i0 < it.z; i0 += NG * U) {
+        bool ok[U];
+        float v[U];
+        float4 ta[U], tb[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * NG + grp;
+            ok[u] = i < it.z;
+            if (ok[u]) {
+                const float *r = b.rec + (size_t)i * RECF;
+                v[u] = r[sub];
+                ta[u] = *(const float4 *)(r + (RECF - 8));
+                tb[u] = *(const float4 *)(r + (RECF - 4));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (!ok[u] || (b.dbg & 1)) continue;
+            const int pack = __float_as_int(ta[u].y);
+            const int h0 = (pack >> 20) - 1, w0 = ((pack >> 10) & 1023) - 1, d0 = (pack & 1023) - 1;
+            const int lh = h0 - oh, lw = w0 - ow, ld = d0 - od;
+            const float fh[2] = {1.0f - ta[u].z, ta[u].z}, fw[2] = {1.0f - ta[u].w, ta[u].w}, fd[2] = {1.0f - tb[u].x, tb[u].x};
+            // a corner counts when it is inside the volume AND inside this brick's tile (the second never fails: the
+            // counting pass and the ray kernel derive the cell with the same code; it only keeps a mismatch inside the tile)
+            const bool okh[2] = {((unsigned)h0 < (unsigned)H) && ((unsigned)lh < (unsigned)kTH),
+                                 ((unsigned)(h0 + 1) < (unsigned)H) && ((unsigned)(lh + 1) < (unsigned)kTH)};
+            const bool okw[2] = {((unsigned)w0 < (unsigned)W) && ((unsigned)lw < (unsigned)kTW),
+                                 ((unsigned)(w0 + 1) < (unsigned)W) && ((unsigned)(lw + 1) < (unsigned)kTW)};
+            const bool okd[2] = {((unsigned)d0 < (unsigned)D) && ((unsigned)ld < (unsigned)kTD),
+                                 ((unsigned)(d0 + 1) < (unsigned)D) && ((unsigned)(ld + 1) < (unsigned)kTD)};
+            double *t0 = tile + ((lh * kTW + lw) * kTD + ld) * RW;
+            if constexpr (NCH > 0) {
+                if (sub < NCH) {
+                    const float fdfw[2][2] = {{fd[0] * fw[0], fd[0] * fw[1]}, {fd[1] * fw[0], fd[1] * fw[1]}};
+#pragma unroll
+                    for (int kk = 0; kk < 8; ++kk) {
+                        const int kd = kk & 1, kw = (kk >> 1) & 1, kh = kk >> 2;
+                        const float val = (fdfw[kd][kw] * fh[kh]) * v[u];
+                        if (okd[kd] && okw[kw] && okh[kh] && val != 0.0f)
+                            __hip_atomic_fetch_add(t0 + ((kh * kTW + kw) * kTD + kd) * RW + sub, (double)val, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
+                }
+            }
+            if (sdf_lane) {
+                // d L / d sdf corner = ds W_k + qz dW_k/dd + qx dW_k/dw + qy dW_k/dh
+                const float fds = fd[mkd], fws = fw[mkw], fhs = fh[mkh];
+                const float Wk = (fds * fws) * fhs;
+                const float dWd = (mkd ? 1.0f : -1.0f) * (fws * fhs);
+                const float dWw = (mkw ? 1.0f : -1.0f) * (fds * fhs);
+                const float dWh = (mkh ? 1.0f : -1.0f) * (fds * fws);
+                const float val = fmaf(Wk, ta[u].x, fmaf(dWd, tb[u].w, fmaf(dWw, tb[u].y, dWh * tb[u].z)));
+                if (okd[mkd] && okw[mkw] && okh[mkh] && val != 0.0f)
+                    __hip_atomic_fetch_add(t0 + moff, (double)val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    }
+    __syncthreads();
+    if (b.dbg & 2) return;
+    // flush.  Feature rows: RECF lanes per voxel row, consecutive groups = consecutive d (contiguous rows in HBM).
+    if constexpr (NCH > 0) {
+        if (g_feat_vol) {
+            for (int r = grp; r < kTileVox; r += NG) {
+                const int rd = r % kTD, rw = (r / kTD) % kTW, rh = r / (kTD * kTW);
+                const int h = oh + rh, w = ow + rw, d = od + rd;
+                if (h < H && w < W && d < D && sub < NCH) {
+                    const float val = (float)tile[r * RW + sub];
+                    if (val != 0.0f) unsafeAtomicAdd(g_feat_vol + ((size_t)(h * W + w) * D + d) * NF + sub, val);
+                }
+            }
+        }
+    }
+    if (g_sdf_vol) {   // the sdf column: consecutive lanes = consecutive d
+        for (int r = threadIdx.x; r < kTileVox; r += NT) {
+            const int rd = r % kTD, rw = (r / kTD) % kTW, rh = r / (kTD * kTW);
+            const int h = oh + rh, w = ow + rw, d = od + rd;
+            if (h < H && w < W && d < D) {
+                const float val = (float)tile[r * RW + NCH];
+                if (val != 0.0f) unsafeAtomicAdd(g_sdf_vol + (size_t)(h * W + w) * D + d, val);
+            }
+        }
+    }
+}
+
+inline size_t rb_align(size_t x) { return (x + 255) & ~(size_t)255; }
+
+inline size_t rb_bricks(const so_render_args &a, RbBin *b) {
+    const int H = a.map.h.tot_len, W = a.map.w.tot_len, D = a.map.d.tot_len;
+    const int nbh = (H + kBH - 1) / kBH, nbw = (W + kBW - 1) / kBW, nbd = (D + kBD - 1) / kBD;
+    if (b) { b->nbh = nbh; b->nbw = nbw; b->nbd = nbd; }
+    return (size_t)nbh * nbw * nbd;
+}
+
+// workspace carve-up; returns the total size (base may be NULL to size only)
+template <int NF>
+size_t rb_layout(const so_render_args &a, int chunk, char *base, RbBin *out, int *max_items) {
+    RbBin b;
+    const size_t nb = rb_bricks(a, &b);
+    b.chunk = chunk;
+    b.dbg = 0;
+    const size_t total = (size_t)a.n_rays * a.n_samples;
+    const size_t mi = (total + chunk - 1) / chunk + nb;
+    size_t off = 0;
+    b.counts = (int *)(base + off); off += nb * kShards * 4;
+    b.invs_part = (float *)(base + off); off += kInvsSlots * 4;
+    b.n_items = (int *)(base + off); off += 4;       // [0, here) is cleared per call (rb_zeroed_bytes)
+    off = rb_align(off);
+    b.cursor = (int *)(base + off); off = rb_align(off + nb * kShards * 4);
+    b.blk_tot = (int2 *)(base + off); off = rb_align(off + ((nb + 1023) / 1024) * 8);
+    b.items = (int4 *)(base + off); off = rb_align(off + mi * 16);
+    b.rec = (float *)(base + off); off = rb_align(off + total * RbRec<NF>::RECF * 4);
+    if (out) *out = b;
+    if (max_items) *max_items = (int)mi;
+    return off;
+}
+
+inline size_t rb_zeroed_bytes(const so_render_args &a) { return rb_bricks(a, nullptr) * kShards * 4 + kInvsSlots * 4 + 4; }
+
+inline int rb_env_int(const char *name, int dflt) {
+    const char *e = getenv(name);
+    return (e && *e) ? atoi(e) : dflt;
+}
+inline int rb_chunk() { static const int c = max(256, rb_env_int("SELFOCC_RB_CHUNK", 4096)); return c; }
+inline int rb_threads() { static const int t = rb_env_int("SELFOCC_RB_THREADS", 512); return t; }
+
+inline bool rb_in_range(const so_render_args &a) {
+    return a.map.h.tot_len <= 1022 && a.map.w.tot_len <= 1022 && a.map.d.tot_len <= 1022 &&
+           (size_t)a.n_rays * a.n_samples < ((size_t)1 << 31);
+}
+
+template <int NF, bool BF16, bool BIN>
+int launch_ray(const so_render_bwd_args &ba, const RbBin &bin, hipStream_t st) {
     const int S = ba.fwd.n_samples;
     const int m = (S + 63) / 64;
     if (m >= 3) {   // four waves per ray: M = ceil(m / 4) steps per wave
         const int blocks = ba.fwd.n_rays;
-#define SO_L(MM) hipLaunchKernelGGL((render_bwd_kernel<NF, BF16, MM, 4>), dim3(blocks), dim3(256), 0, st, ba)
+#define SO_L(MM) hipLaunchKernelGGL((render_bwd_kernel<NF, BF16, MM, 4, BIN>), dim3(blocks), dim3(256), 0, st, ba, bin)
         if (m <= 4) SO_L(1);
         else SO_L(2);
 #undef SO_L
     } else {
         const int blocks = (ba.fwd.n_rays + 3) / 4;
-#define SO_L(MM) hipLaunchKernelGGL((render_bwd_kernel<NF, BF16, MM, 1>), dim3(blocks), dim3(256), 0, st, ba)
+#define SO_L(MM) hipLaunchKernelGGL((render_bwd_kernel<NF, BF16, MM, 1, BIN>), dim3(blocks), dim3(256), 0, st, ba, bin)
         if (m <= 1) SO_L(1);
         else SO_L(2);
 #undef SO_L
@@ -514,9 +871,60 @@ int launch_m(const so_render_bwd_args &ba, hipStream_t st) {
     return so_launch_status();
 }
 
+template <int NF, bool BF16>
+int launch_m(const so_render_bwd_args &ba, hipStream_t st) {
+    const so_render_args &a = ba.fwd;
+    const bool binned = ba.scatter_ws != nullptr && rb_in_range(a) && (ba.g_sdf_vol || ba.g_feat_vol);
+    if (!binned) return launch_ray<NF, BF16, false>(ba, RbBin{}, st);
+    RbBin bin;
+    int max_items = 0;
+    const size_t need = rb_layout<NF>(a, rb_chunk(), (char *)ba.scatter_ws, &bin, &max_items);
+    bin.dbg = rb_env_int("SELFOCC_RB_DBG", 0);
+    SO_REQUIRE(ba.scatter_ws_bytes >= need, "render_bwd: scatter_ws holds %llu bytes, selfocc_render_bwd_ws_bytes() asks for %llu",
+               (unsigned long long)ba.scatter_ws_bytes, (unsigned long long)need);
+    SO_REQUIRE(((uintptr_t)ba.scatter_ws & 255) == 0, "render_bwd: scatter_ws must be 256-byte aligned");
+    hipError_t e = hipMemsetAsync(ba.scatter_ws, 0, rb_zeroed_bytes(a), st);
+    SO_REQUIRE(e == hipSuccess, "render_bwd: hipMemsetAsync failed: %s", hipGetErrorString(e));
+    const unsigned sblocks = (unsigned)((rb_bricks(a, nullptr) + 1023) / 1024);
+    hipLaunchKernelGGL(rb_count_kernel, dim3((unsigned)((a.n_rays + 3) / 4)), dim3(256), 0, st, a, bin);
+    hipLaunchKernelGGL(rb_scan1_kernel, dim3(sblocks), dim3(1024), 0, st, bin);
+    hipLaunchKernelGGL(rb_scan2_kernel, dim3(sblocks), dim3(1024), 0, st, bin);
+    if (int rc = launch_ray<NF, BF16, true>(ba, bin, st)) return rc;
+    const int H = a.map.h.tot_len, W = a.map.w.tot_len, D = a.map.d.tot_len;
+    const size_t lds = (size_t)kTileVox * RbRec<NF>::RW * 8;
+    const int nt = rb_threads();
+#define SO_B(NT)                                                                                                          \
+    do {                                                                                                                  \
+        static const hipError_t attr = hipFuncSetAttribute((const void *)rb_brick_kernel<NF, NT>,                         \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
+        (void)attr;                                                                                                       \
+        hipLaunchKernelGGL((rb_brick_kernel<NF, NT>), dim3(max_items), dim3(NT), lds, st, bin, ba.g_sdf_vol,              \
+                           ba.g_feat_vol, ba.g_inv_s, H, W, D);                                                           \
+    } while (0)
+    if (nt >= 1024) SO_B(1024);
+    else if (nt >= 512) SO_B(512);
+    else SO_B(256);
+#undef SO_B
+    return so_launch_status();
+}
+
 }  // namespace
 
 int so_validate_render(const so_render_args &a);
+
+extern "C" size_t selfocc_render_bwd_ws_bytes(const so_render_bwd_args *args) {
+    if (!args) return 0;
+    const so_render_args &a = args->fwd;
+    if (!rb_in_range(a) || a.n_rays <= 0 || a.n_samples <= 0) return 0;
+    switch (a.n_rgb + a.n_sem == 3 ? 4 : a.n_rgb + a.n_sem) {
+        case 0: return rb_layout<0>(a, rb_chunk(), nullptr, nullptr, nullptr);
+        case 4: return rb_layout<4>(a, rb_chunk(), nullptr, nullptr, nullptr);
+        case 8: return rb_layout<8>(a, rb_chunk(), nullptr, nullptr, nullptr);
+        case 20: return rb_layout<20>(a, rb_chunk(), nullptr, nullptr, nullptr);
+        case 24: return rb_layout<24>(a, rb_chunk(), nullptr, nullptr, nullptr);
+        default: return 0;
+    }
+}
 
 extern "C" int selfocc_render_bwd(const so_render_bwd_args *args, void *stream) {
     SO_REQUIRE(args != nullptr, "args is NULL");

@@ -5,6 +5,7 @@ replaces what the reference obtains from the sdfstudio fork's
 ``NeuSCustomModel.__call__(RayBundle)`` (model/head/neus_head/neus_head.py:353,394,531).
 Tensors are only device-memory handles here: the arithmetic is in csrc/render_*.hip.
 """
+import os
 from dataclasses import dataclass, field
 from typing import Optional
 
@@ -119,6 +120,9 @@ class RenderConfig:
     face_safe: bool = True            # fast path: canonical cell selection within a few ulp of a voxel face (~6 % slower)
     ahead: bool = True                # SDF-only per-ray launches with brick + skip: code-ahead skip marcher (A/B)
     ray_per_lane: bool = False        # per-sample launches through the ray-per-lane kernels (A/B; default: sample-parallel)
+    bwd_scatter: str = 'auto'         # backward: 'binned' = brick-binned LDS scatter of the volume gradients (needs a scratch
+                                      # of ~(record + 8) bytes per sample), 'atomic' = per-sample row atomics, 'auto' = binned
+                                      # from 2^18 samples per launch (SELFOCC_RB_SCATTER overrides 'auto')
 
 
 def _c(t, dtype=torch.float32):
@@ -234,6 +238,19 @@ def _brick_workspace(sdf):
     return ws
 
 
+_SCATTER_WS = {}
+
+
+def _scatter_workspace(device, nbytes):
+    """Grow-only scratch of the binned backward scatter per (device, stream): used inside one selfocc_render_bwd
+    call only (stream-ordered), so consecutive calls on a stream share it."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _SCATTER_WS.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = _SCATTER_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
+    return ws
+
+
 class _RenderFunction(torch.autograd.Function):
     """Differentiable wrt the SDF volume, the feature volume and inv_s (a 0-dim / 1-elem
     tensor).  Ray geometry carries no gradient — the reference's rays come from constant
@@ -294,6 +311,15 @@ class _RenderFunction(torch.autograd.Function):
             ba.g_feat_vol = ptr(g_feat)
         g_inv_s = torch.zeros(1, device=vol.sdf.device)
         ba.g_inv_s = ptr(g_inv_s)
+        mode = cfg.bwd_scatter if cfg.bwd_scatter != 'auto' else os.environ.get('SELFOCC_RB_SCATTER', 'auto')
+        if mode == 'binned' or (mode == 'auto' and rays.n_rays * cfg.n_samples >= (1 << 18)):
+            need = int(lib().selfocc_render_bwd_ws_bytes(ba))
+            if need > 0:
+                ws = _scatter_workspace(vol.sdf.device, need)
+                ba.scatter_ws, ba.scatter_ws_bytes = ptr(ws), ws.numel()
+                hold.append(ws)
+            elif mode == 'binned':
+                raise RuntimeError("bwd_scatter='binned': the volume / launch is outside the binned scatter's range")
         check(lib().selfocc_render_bwd(ba, current_stream(vol.sdf.device)), "selfocc_render_bwd")
         if g_feat is not None and vol.feat.dtype != torch.float32:
             g_feat = g_feat.to(vol.feat.dtype)

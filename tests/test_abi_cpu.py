@@ -27,6 +27,7 @@ def test_struct_layouts_match_header(tmp_path):
     fields = [("so_axis", "tot_len", abi.SoAxis), ("so_mapping", "d", abi.SoMapping),
               ("so_render_args", "grad", abi.SoRenderArgs), ("so_render_args", "sdf_brick", abi.SoRenderArgs), ("so_render_args", "inv_s", abi.SoRenderArgs),
               ("so_render_args", "t_rand", abi.SoRenderArgs), ("so_render_bwd_args", "g_inv_s", abi.SoRenderBwdArgs),
+              ("so_render_bwd_args", "scatter_ws_bytes", abi.SoRenderBwdArgs),
               ("so_query_args", "sem_argmax", abi.SoQueryArgs), ("so_occ_args", "sem", abi.SoOccArgs),
               ("so_occ_args", "thresh", abi.SoOccArgs), ("so_reproj_args", "wnorm", abi.SoReprojArgs),
               ("so_reproj_args", "img_h", abi.SoReprojArgs)]
@@ -72,3 +73,20 @@ def test_banded_support_query_is_pure_host_logic():
     n = 6 * 22016 * 6 * 4 * 8
     ws = l.selfocc_msda_bwd_banded_workspace(6, 22016, 6, 4, 8)
     assert ws >= 18 * n and ws % 16 == 0
+
+
+def test_render_bwd_scatter_workspace_size_is_pure_host_logic():
+    """selfocc_render_bwd_ws_bytes: one record per sample + counters / cursors / the item list of the brick-binned scatter."""
+    from selfocc_amd._lib import lib
+    l = lib()
+    ba = abi.SoRenderBwdArgs()
+    for ax, n in ((ba.fwd.map.h, 257), (ba.fwd.map.w, 257), (ba.fwd.map.d, 25)):
+        ax.tot_len = n
+    ba.fwd.n_rays, ba.fwd.n_samples, ba.fwd.n_rgb, ba.fwd.n_sem = 28800, 256, 3, 21
+    total = 28800 * 256
+    ws = l.selfocc_render_bwd_ws_bytes(ba)
+    assert total * 128 <= ws <= total * 128 + (4 << 20) and ws % 256 == 0     # 24 channels: 128-byte records + counters / items
+    ba.fwd.n_rgb, ba.fwd.n_sem = 0, 0
+    assert total * 32 <= l.selfocc_render_bwd_ws_bytes(ba) <= total * 32 + (4 << 20)   # SDF only: 32-byte records
+    ba.fwd.map.h.tot_len = 2000                                     # cell coordinates are packed in 10 bits per axis
+    assert l.selfocc_render_bwd_ws_bytes(ba) == 0

@@ -15,15 +15,17 @@ def _rel_l2(a, b):
     return ((a - b).norm() / (b.norm() + 1e-30)).item()
 
 
+@pytest.mark.parametrize("scatter", ["atomic", "binned"])
 @pytest.mark.parametrize("n_rgb,n_sem,jitter,sample_pos,S", [
     (0, 0, abi.JITTER_NONE, 0, 32), (3, 0, abi.JITTER_SINGLE, 1, 32), (3, 5, abi.JITTER_PER_BIN, 0, 32),
-    (3, 21, abi.JITTER_NONE, 0, 100), (3, 0, abi.JITTER_NONE, 0, 256)])
-def test_render_backward_vs_float64_autograd(hip, n_rgb, n_sem, jitter, sample_pos, S):
+    (3, 21, abi.JITTER_NONE, 0, 100), (3, 0, abi.JITTER_NONE, 0, 256), (3, 17, abi.JITTER_SINGLE, 0, 300)])
+def test_render_backward_vs_float64_autograd(hip, n_rgb, n_sem, jitter, sample_pos, S, scatter):
     vol = sy.make_volume("cfg1", n_rgb=n_rgb, n_sem=n_sem, seed=11, noise=0.02)
     ex = sy.explicit_rays(sy.make_rays("cfg1", seed=11))
     cfg = sy.make_render_config("cfg1", inv_s=12.0, sample_pos=sample_pos, jitter_mode=jitter,
                                 bkgd_mode=abi.BKGD_PER_RAY if n_rgb else abi.BKGD_NONE)
     cfg.n_samples = S
+    cfg.bwd_scatter = scatter     # per-sample row atomics / the brick-binned LDS scatter (same sums)
     N = ex.n_rays
     g = torch.Generator().manual_seed(3)
     t_rand = None if jitter == abi.JITTER_NONE else torch.rand(*((N,) if jitter == abi.JITTER_SINGLE else (N, S + 1)), generator=g)
@@ -88,3 +90,36 @@ def test_render_backward_zero_upstream(hip):
                                sy.make_render_config("cfg1"))
     (out['depth'].sum() * 0.0).backward()
     assert sdf_p.grad.abs().max() == 0 and inv_s.grad.abs().max() == 0
+
+
+@pytest.mark.parametrize("n_rgb,n_sem", [(0, 0), (3, 21)])
+def test_render_backward_binned_vs_atomic_at_training_shape(hip, n_rgb, n_sem):
+    """The shipped nuscenes_occ training launch (257 x 257 x 25 volume, 6 x 48 x 100 rays x 256 samples): the
+    brick-binned scatter and the per-sample atomics produce the same volume gradients (float addition order aside);
+    bricks at every face / corner of the volume, several work items per brick around the cameras."""
+    rays = sy.make_rays("cfg5")
+    rg = RaySet(img2lidar=rays.img2lidar.to(D0), nx=rays.nx, ny=rays.ny, sx=rays.sx, sy=rays.sy)
+    vol = sy.make_volume("cfg5", n_rgb=n_rgb, n_sem=n_sem).to(D0)
+    res = {}
+    for mode in ("atomic", "binned"):
+        cfg = sy.make_render_config("cfg5")
+        cfg.bwd_scatter = mode
+        inv_s = torch.tensor([float(cfg.inv_s)], device=D0, requires_grad=True)
+        sdf = vol.sdf.detach().clone().requires_grad_(True)
+        feat = None if vol.feat is None else vol.feat.detach().clone().requires_grad_(True)
+        out = render_rays_autograd(SDFVolume(vol.mapping, sdf, feat, n_rgb, n_sem), inv_s, rg, cfg)
+        loss = out['depth'].mean() + out['sdf'].abs().mean() * 0.1 + (out['grad'].norm(dim=-1) - 1).square().mean() * 0.1 + \
+            (out['weights'] * torch.linspace(0, 1, out['weights'].shape[-1], device=D0)).sum(-1).mean()
+        if n_rgb:
+            loss = loss + out['rgb'].mean() + out['sem'].square().mean()
+        loss.backward()
+        res[mode] = (sdf.grad, None if feat is None else feat.grad, inv_s.grad)
+    a, b = res["atomic"], res["binned"]
+    assert a[0].abs().max() > 0
+    assert _rel_l2(b[0].double(), a[0].double()) < 1e-5
+    assert (b[0] - a[0]).abs().max() <= 1e-4 * a[0].abs().max()
+    if n_rgb:
+        assert a[1].abs().max() > 0
+        assert _rel_l2(b[1].double(), a[1].double()) < 1e-5
+        assert (b[1] - a[1]).abs().max() <= 1e-4 * a[1].abs().max()
+    assert abs(b[2].item() - a[2].item()) <= 1e-3 * abs(a[2].item()) + 1e-6
