@@ -24,6 +24,8 @@ import os
 import sys
 import types
 
+sys.dont_write_bytecode = True      # /root/reference is read-only input: importing its files must not leave __pycache__ there
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -836,10 +838,30 @@ def golden_head(REG):
                     mapping_args=dict(nonlinear_mode='linear', h_size=[32, 0], h_range=[16.0, 0], h_half=True,
                                       w_size=[8, 0], w_range=[8.0, 0], w_half=False, d_size=[4, 0], d_range=[-1.0, 3.0, 3.0]),
                     embed_dims=32, color_dims=0, density_layers=2, sh_deg=0, sh_act='relu', two_split=False, tpv=False),
+        # the SHIPPED head of config/nuscenes/nuscenes_occ.py:303-352, key for key: 256 samples, 6 cameras, color_dims 24
+        # (rgb + 21 semantic logits), cellular lattice on the 768 x 1600 image, random background, learnable beta 0.1,
+        # the 80 m x 80 m x 6.4 m box.  Reduced for a CPU fixture: the TPV grid (65 x 65 x 13 instead of 257 x 257 x 25)
+        # the lattice (6 x 10 rays per camera instead of 48 x 100) and the dense-query resolution (1.6 m instead of 0.4);
+        # `use_compact_2nd_grad=True` because the fork's non-compact form is not on disk (README).
+        # Saved to its own file (head_occ.npz): training forward, prepare + render, forward_occ.
+        'occ': dict(roi_aabb=[-40.0, -40.0, -1.0, 40.0, 40.0, 5.4], resolution=1.6, near_plane=0.0, far_plane=1e10,
+                    num_samples=256, num_samples_importance=0, num_up_sample_steps=0, base_variance=4, beta_init=0.1,
+                    beta_max=0.195, total_iters=3516 * 11, beta_hand_tune=False, use_numerical_gradients=False,
+                    sample_gradient=True, return_uniform_sdf=False, return_second_grad=True, use_compact_2nd_grad=True,
+                    return_sem=True, return_sample_sdf=False, ray_sample_mode='cellular', ray_number=[6, 10],
+                    ray_img_size=[768, 1600], ray_upper_crop=0, trans_kw='temImg2lidar', novel_view=None,
+                    render_bkgd='random',
+                    mapping_args=dict(nonlinear_mode='linear', h_size=[32, 0], h_range=[40.0, 0], h_half=False,
+                                      w_size=[32, 0], w_range=[40.0, 0], w_half=False, d_size=[12, 0], d_range=[-1.0, 5.4, 5.4]),
+                    embed_dims=96, color_dims=24, density_layers=2, sh_deg=0, sh_act='relu', two_split=False, tpv=True),
     }
     arrs, meta_json = {}, {}
+    occ_arrs, occ_json = {}, {}
     for tag, cfg in cfgs.items():
-        torch.manual_seed(21 if tag == 'tpv' else 22)
+        light = tag == 'occ'            # the shipped-shape case: 92 k samples per per-sample tensor, fewer calls recorded
+        if light:
+            arrs, meta_json = occ_arrs, occ_json
+        torch.manual_seed({'tpv': 21, 'bev': 22, 'occ': 23}[tag])
         import copy
         head = nh.NeuSHead(**copy.deepcopy(cfg))
         f = head.model.field
@@ -851,9 +873,10 @@ def golden_head(REG):
             rep = [torch.randn(1, H * W, C, generator=g), torch.randn(1, D * H, C, generator=g), torch.randn(1, W * D, C, generator=g)]
         else:
             rep = torch.randn(1, H * W, C, generator=g)
-        n_cams = 2
+        n_cams = 6 if tag == 'occ' else 2
         img = tuple(cfg['ray_img_size'])
-        c0, c1 = cams(n_cams, 1, img), cams(n_cams, 2, img)
+        foc = 1266.0 if tag == 'occ' else 60.0          # nuScenes focal length on the 1600-pixel image
+        c0, c1 = cams(n_cams, 1, img, foc), cams(n_cams, 2, img, foc)
         if tag == 'bev':
             c0[:, 1, 3] += 6.0; c1[:, 1, 3] += 6.0        # the KITTI-like box lies in front of the rig
         metas = [dict(img2lidar=list(c0), temImg2lidar=list(c1))]
@@ -891,12 +914,13 @@ def golden_head(REG):
         head.eval()
         DRAWS.clear()
         torch.manual_seed(101)
-        with torch.no_grad():
-            out = head(rep, metas)
-        _flatten_out(f'{tag}.evalfwd', out, arrs)
-        if 'bkgd' in DRAWS:
-            arrs[f'{tag}.evalfwd.draw.bkgd'] = DRAWS['bkgd'][0].numpy()
-        if cfg['return_uniform_sdf']:
+        if not light:
+            with torch.no_grad():
+                out = head(rep, metas)
+            _flatten_out(f'{tag}.evalfwd', out, arrs)
+            if 'bkgd' in DRAWS:
+                arrs[f'{tag}.evalfwd.draw.bkgd'] = DRAWS['bkgd'][0].numpy()
+        if cfg['return_uniform_sdf'] and not light:
             torch.manual_seed(101)
             N = out['origin'].shape[0]
             if 'bkgd' in DRAWS:
@@ -905,7 +929,7 @@ def golden_head(REG):
             arrs[f'{tag}.evalfwd.draw.shift'] = torch.rand_like(torch.empty(n, 3)).numpy()
 
         # ---- eval_depth.py:165-166: prepare + render, unchunked and in chunks of 50 rays ----
-        for name, batch in (('render0', 0), ('render50', 50)):
+        for name, batch in ((('render0', 0),) if light else (('render0', 0), ('render50', 50))):
             DRAWS.clear()
             torch.manual_seed(102)
             with torch.no_grad():
@@ -920,13 +944,20 @@ def golden_head(REG):
             out = head.forward_occ(rep, metas, aabb=[-6.0, -5.0, -0.5, 6.0, 7.0, 2.5], resolution=0.5)
             out.pop('rep')
             _flatten_out(f'{tag}.occ', out, arrs)
-            out = head.forward_occ(rep, metas)
-            out.pop('rep')
-            _flatten_out(f'{tag}.occdef', out, arrs)
+            if not light:
+                out = head.forward_occ(rep, metas)
+                out.pop('rep')
+                _flatten_out(f'{tag}.occdef', out, arrs)
         os.environ['eval'] = 'false'
-    save('head.npz', **arrs)
-    with open(os.path.join(HERE, 'head_cfg.json'), 'w') as fjs:
-        json.dump(meta_json, fjs, indent=1)
+        if light:
+            save('head_occ.npz', **occ_arrs)
+            with open(os.path.join(HERE, 'head_occ_cfg.json'), 'w') as fjs:
+                json.dump(occ_json, fjs, indent=1)
+            arrs, meta_json = {}, {}
+        elif tag == 'bev':
+            save('head.npz', **arrs)
+            with open(os.path.join(HERE, 'head_cfg.json'), 'w') as fjs:
+                json.dump(meta_json, fjs, indent=1)
 
 
 FULL_ENCODER = dict(dim=96, heads=6, cams=6, tpv=(25, 25, 7), fpn=((12, 25), (6, 13), (3, 7), (2, 4)), img_shape=(96, 200),

@@ -44,8 +44,9 @@ class Replay:
 def _load(tag, **over):
     from selfocc_amd.registry import MODELS
     import selfocc_amd.model  # noqa: F401
-    z = np.load(os.path.join(G, "head.npz"))
-    cfg = json.load(open(os.path.join(G, "head_cfg.json")))[tag]
+    stem = "head_occ" if tag == 'occ' else "head"      # 'occ' = the shipped nuscenes_occ head (its own file)
+    z = np.load(os.path.join(G, stem + ".npz"))
+    cfg = json.load(open(os.path.join(G, stem + "_cfg.json")))[tag]
     cfg = dict(copy.deepcopy(cfg), **over)
     head = MODELS.build(dict(type='NeuSHead', **cfg))
     sd = {k[len(tag) + 4:].replace('model.field.net.density_net', 'model.field.density_net'): torch.tensor(z[k])
@@ -87,7 +88,25 @@ def close(a, b, rtol, atol):
 
 GEOM = ('ms_rays', 'origin', 'direction', 'direction_norm', 'ts', 'deltas', 'ms_fars', 'xyz')      # 1e-5: neus_head.py's own math
 FIELD = ('uniform_sdf', 'sdf', 'logits', 'sample_sdf', 'second_grad')                              # volume MLP + trilinear lookup
-RENDER = ('ms_depths', 'ms_colors', 'ms_accs', 'sem', 'weights', 'vis_normal')                      # composited (oracle tolerance)
+RENDER = ('ms_depths', 'ms_colors', 'ms_accs', 'sem', 'vis_normal')                                 # composited: 1e-4 relative
+
+LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "head_parity.jsonl")
+
+
+def _log(where, k, i, **m):
+    """measured worst case per (call, key) -> gpurun_out/head_parity.jsonl (the asserted bounds below are these x 10)"""
+    try:
+        os.makedirs(os.path.dirname(LOG), exist_ok=True)
+        with open(LOG, "a") as f:
+            f.write(json.dumps(dict(where=where, key=k, idx=i, **{a: (float(b) if b is not None else None) for a, b in m.items()})) + "\n")
+    except OSError:
+        pass
+
+
+def rel_err(a, b, floor):
+    """max over elements of |a - b| / max(|b|, floor): relative where the reference is large, absolute (in units of
+    `floor`) where it is small"""
+    return ((a - b).abs() / b.abs().clamp_min(floor)).max().item()
 
 
 def compare(ours, ref, where):
@@ -106,27 +125,51 @@ def compare(ours, ref, where):
             tag = (where, k, i)
             if b.numel() == 0:          # colourless heads return (1, cams, rays, 0) `ms_colors`
                 continue
+            sc = max(1e-30, b.abs().max().item())
             if k == 'ray_indices':
                 assert a.dtype == b.dtype == torch.int64 and torch.equal(a, b), tag
             elif k in GEOM:
+                e = rel_err(a, b, sc)
+                _log(where, k, i, err=e, scale=sc)
                 assert close(a, b, 1e-5, 1e-5).all(), (tag, (a - b).abs().max().item())
             elif k in FIELD:
-                assert close(a, b, 1e-4, 2e-5).all(), (tag, (a - b).abs().max().item())
+                e = rel_err(a, b, sc)                       # measured <= 1.3e-6 of the tensor's scale
+                _log(where, k, i, err=e, scale=sc)
+                assert e <= 2e-5 and close(a, b, 1e-4, 2e-5).all(), (tag, e, (a - b).abs().max().item())
             elif k == 'sem' and a.dtype == torch.int64:
                 pass        # arg-max of the logits: checked against the logits by the caller
             elif k == 'ms_max_depths':
                 # arg-max over w / delta: an (almost) tie may legitimately resolve to the neighbouring sample
-                assert close(a, b, 1e-5, 1e-5).float().mean() >= 0.97, (tag, close(a, b, 1e-5, 1e-5).float().mean().item())
+                frac = close(a, b, 1e-5, 1e-5).float().mean().item()   # measured 1.0 on every recorded call
+                _log(where, k, i, frac=frac)
+                assert frac >= 0.99, (tag, frac)
             elif k == 'eik_grad':
                 # trilinear gradients jump across voxel faces: a sample within rounding of a face may sit next door
                 ok = close(a, b, 1e-4, 1e-4 * b.abs().max().item()).all(-1)
-                assert ok.float().mean() >= 0.999, (tag, ok.float().mean().item())
+                e = rel_err(a[ok], b[ok], sc) if ok.any() else 0.0        # measured: every sample, <= 1e-6 of the scale
+                _log(where, k, i, frac=ok.float().mean().item(), err=e)
+                assert ok.float().mean() >= 0.999 and e <= 1e-5, (tag, ok.float().mean().item(), e)
+            elif k == 'weights':
+                # per-SAMPLE weights w_i = alpha_i T_i: alpha subtracts two sigmoids that agree to ~1e-5 in free space, so a
+                # float32 evaluation (the reference's as much as ours) carries ~1e-7 of ABSOLUTE rounding noise per sample
+                # whatever the weight's size (tests/util.py: parity_report); their sums (ms_accs), weighted sums (ms_depths,
+                # ms_colors, sem) are held to 1e-4 relative below.  Measured: <= 1.5e-6 absolute on every element of every call.
+                ea = (a - b).abs().max().item()
+                _log(where, k, i, err=rel_err(a, b, 1e-2 * sc), err_abs=ea, scale=sc)
+                assert ea <= 1.5e-5, (tag, ea)
             elif k in RENDER:
-                sc = max(1.0, b.abs().max().item())
-                assert close(a, b, 1e-4, 2e-5 * sc).float().mean() >= 0.995, (tag, (a - b).abs().max().item())
-                assert (a - b).abs().max().item() <= 2e-3 * sc, (tag, (a - b).abs().max().item())
+                # north_star: rendered depth / RGB within 1e-4 relative.  `err` = max |a - b| / max(|b|, scale_floor) with
+                # scale_floor = 1e-2 of the tensor's largest value (a colour channel of 1e-9 carries no 1e-4-relative
+                # information in float32); EVERY element of EVERY call is held to it (round 3: 99.5 % of them, 2e-3 of the
+                # scale on the rest).  Measured worst case: 4.8e-5 (`sem` of the shipped nuscenes_occ head, 256 samples).
+                e = rel_err(a, b, 1e-2 * sc)
+                _log(where, k, i, err=e, err_abs=(a - b).abs().max().item(), scale=sc)
+                assert e <= RENDER_TOL, (tag, e, (a - b).abs().max().item())
             else:
                 raise AssertionError(f"no comparison rule for key {k!r}")
+
+
+RENDER_TOL = 1e-4
 
 
 def _sem_argmax_consistent(ours, ref):
@@ -137,7 +180,7 @@ def _sem_argmax_consistent(ours, ref):
     assert ours['sem'].dtype == torch.int64
 
 
-@pytest.mark.parametrize("tag", ['tpv', 'bev'])
+@pytest.mark.parametrize("tag", ['tpv', 'bev', 'occ'])
 def test_head_train_forward_vs_reference_head(hip, monkeypatch, tag):
     z, cfg, head, rep, metas = _load(tag)
     os.environ['eval'] = 'false'
@@ -170,8 +213,8 @@ def test_head_eval_forward_vs_reference_head(hip, monkeypatch, tag):
         os.environ['eval'] = 'false'
 
 
-@pytest.mark.parametrize("tag", ['tpv', 'bev'])
-@pytest.mark.parametrize("name,batch", [('render0', 0), ('render50', 50)])
+@pytest.mark.parametrize("tag,name,batch", [('tpv', 'render0', 0), ('tpv', 'render50', 50), ('bev', 'render0', 0),
+                                            ('bev', 'render50', 50), ('occ', 'render0', 0)])
 def test_head_prepare_render_vs_reference_head(hip, monkeypatch, tag, name, batch):
     """eval_depth.py:165-166 — prepare() + render(batch): the reference's chunk loop and ours (one launch) agree"""
     z, cfg, head, rep, metas = _load(tag, render_normal=True)
@@ -189,12 +232,14 @@ def test_head_prepare_render_vs_reference_head(hip, monkeypatch, tag, name, batc
         os.environ['eval'] = 'false'
 
 
-@pytest.mark.parametrize("tag", ['tpv', 'bev'])
+@pytest.mark.parametrize("tag", ['tpv', 'bev', 'occ'])
 def test_head_forward_occ_vs_reference_head(hip, tag):
     z, cfg, head, rep, metas = _load(tag)
     head.eval()
     with torch.no_grad():
         for name, kw in (('occ', dict(aabb=[-6.0, -5.0, -0.5, 6.0, 7.0, 2.5], resolution=0.5)), ('occdef', {})):
+            if tag == 'occ' and name == 'occdef':
+                continue            # the shipped-shape fixture records the explicit-box call only
             out = head.forward_occ(rep, metas, **kw)
             assert out.pop('rep') is rep
             ref = _ref_dict(z, f'{tag}.{name}')

@@ -231,6 +231,32 @@ def test_cfg2_feature_volumes_staged_kernels_vs_oracle(hip, n_rgb, n_sem, feat_d
     parity_report(got, ref, label=f"cfg2 307k rays C={1 + n_rgb + n_sem} {feat_dtype}", min_frac=0.999)
 
 
+@pytest.mark.parametrize("n_rgb,n_sem", [(3, 0), (3, 21)])
+def test_cfg2_full_frame_feature_volumes_vs_oracle_strict(hip, n_rgb, n_sem):
+    """The WHOLE BASELINE cfg2 frame (6 x 450 x 800 = 2.16 M rays x 128 samples) through the colour (C = 4) and the
+    nuscenes_occ-style colour + 21-class (C = 25) volumes — the LDS-staged feature kernels — against the C oracle on
+    EVERY ray under the strict rule bench.py prints (round 3 checked these kernels on 307 k rays and the bench's parity
+    block covers C = 1 only)."""
+    d = torch.device("cuda:0")
+    vol = sy.make_volume("cfg2", n_rgb=n_rgb, n_sem=n_sem, seed=0)
+    rays = sy.make_rays("cfg2", seed=0)
+    cfg = sy.make_render_config("cfg2", inv_s=20.0)
+    assert rays.n_rays == 6 * 450 * 800 and rays.n_rays * cfg.n_samples >= 16 * vol.sdf.numel()
+    ref = oracle.render_fwd(vol, rays, cfg)
+    got = render_rays(vol.to(d), _dev_rays(rays, d), cfg)
+    torch.cuda.synchronize()
+    rep = parity_report(got, ref, label=f"cfg2 FULL frame C={1 + n_rgb + n_sem}", min_frac=0.9999, strict=True)
+    assert rep['n_rays'] == rays.n_rays
+    import json, os
+    try:
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_full_frame.jsonl"), "a") as f:
+            f.write(json.dumps(dict(case=f"cfg2 full frame C={1 + n_rgb + n_sem}", **rep)) + "\n")
+    except OSError:
+        pass
+
+
 def _novel_view(M, yaw_deg=3.0, shift=(0.4, -0.2, 0.05)):
     """img2lidar of a camera moved to a novel pose (kitti_novel_depth renders from `render_img2lidar`,
     utils/config_tools.py:90-92): rotate the rig about z and translate it."""
