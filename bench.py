@@ -208,6 +208,12 @@ def main():
                 roofline["valu"] = {"achieved_Tlaneops": round(ach, 2), "peak_Tlaneops": round(peak, 2),
                                     "frac": round(ach / peak, 3),
                                     "note": "SQ_INSTS_VALU x 64 lanes / kernel time vs 256 CU x 4 SIMD x 32 lanes x 2.4 GHz"}
+                roofline["valu_frac"] = round(ach / peak, 3)
+            if rec.get("ta_busy_cycles") and rec.get("gui_active_cycles"):
+                # the OPERATIVE bound of the march (same PMC run): the texture-address units are busy for this share of the
+                # kernel's cycles; `frac` above stays the HBM number the contract asks for (the volume sits in L2 / MALL)
+                roofline["ta_busy_frac"] = round(rec["ta_busy_cycles"] / rec["gui_active_cycles"], 3)
+                roofline["bound_operative"] = "TA" if roofline["ta_busy_frac"] >= 0.8 else ("VALU" if roofline.get("valu_frac", 0) >= 0.6 else "latency")
 
     extras = {}
     if rank == 0 and world == 1 and not args.no_extras:
@@ -314,7 +320,7 @@ def main():
             spent += time.perf_counter() - c0
             done = sl.stop
         torch.set_num_threads(default_threads)
-        cpu_baseline = {"value": round(done / spent, 1), "unit": "rays/s", "cores": cores, "kind": "port",
+        cpu_baseline = {"value": round(done / spent, 1), "unit": "rays/s", "cores": os.cpu_count(), "threads_used": cores, "kind": "port",
                         "sample": f"first {done} rays of the same cfg2 frame (chunks of 90000), C={args.channels}, "
                                   f"torch CPU F.grid_sample + NeuS compositing, {spent:.1f} s; {cores} torch threads = "
                                   f"the fastest of a 8..256 sweep on this host ({os.cpu_count()} hardware threads)"}
@@ -369,6 +375,32 @@ def main():
         except Exception as e:
             roofline_linear = {"error": repr(e)[:300]}
 
+    # ---- the training backward's scatter kernels: measured HBM-side bytes against their algorithmic bytes ----
+    # (rocprofv3 --pmc cannot run inside bench.py: scripts/pmc_train_bwd.sh on the training iteration, committed per
+    # round as profiles/pmc_bwd.json next to the text summary it was made from)
+    roofline_bwd = None
+    bwd_file = os.path.join(ROOT, "profiles", "pmc_bwd.json")
+    if rank == 0 and world == 1 and os.path.exists(bwd_file):
+        rec = json.load(open(bwd_file))
+        # algorithmic bytes per launch at the nuscenes_occ training shape: the gradient the kernel produces, written once
+        alg = {"render_bwd": 257 * 257 * 25 * 25 * 4,                       # d L / d (sdf + 24-channel feature) volume
+               "field_volume_bwd": (257 * 257 + 2 * 25 * 257) * 96 * 4,     # the three plane gradients
+               "msda_bwd_band_list": 6 * 25500 * 96 * 4}                    # d L / d value of one cross-attention call
+        groups = {"render_bwd": ("render_bwd_kernel", "rb_brick_kernel", "rb_count_kernel"),
+                  "field_volume_bwd": ("field_volume_bwd_kernel",), "msda_bwd_band_list": ("msda_bwd_band_list_kernel",)}
+        roofline_bwd = {"source": "profiles/pmc_bwd.json (scripts/pmc_train_bwd.sh, training iteration at nuscenes_occ shapes)"}
+        for name, pats in groups.items():
+            ks = {k: v for k, v in rec.items() if any(k.startswith(p) for p in pats) and v.get("write_kb") is not None}
+            if not ks:
+                continue
+            per_it = max(v["calls"] for v in ks.values()) or 1
+            w = sum(v["write_kb"] * v["calls"] for v in ks.values()) / per_it * 1024
+            f = sum((v["fetch_kb"] or 0) * v["calls"] for v in ks.values()) / per_it * 1024
+            us = sum(v["avg_us"] * v["calls"] for v in ks.values()) / per_it
+            roofline_bwd[name] = {"kernels": sorted(ks), "alg_MB": round(alg[name] / 1e6, 1), "write_MB": round(w / 1e6, 1),
+                                  "fetch_MB": round(f / 1e6, 1), "write_over_alg": round(w / alg[name], 2),
+                                  "us_per_launch": round(us, 1)}
+
     strong = None
     if world > 1 and not split:
         # the same ranks, ONE frame split into row blocks (SURVEY cfg3), after the timed region
@@ -406,6 +438,9 @@ def main():
         dist.all_gather_object(seen, me)
         ranks_seen = {"backend": dist.get_backend(), "world_size": world, "ranks": seen,
                       "distinct_devices": len({(r["uuid"], r["pci_bus_id"], r["device_index"]) for r in seen})}
+        if not share:   # a real multi-GPU line: one GPU per rank over RCCL, or no line at all
+            assert ranks_seen["backend"] == "nccl", ranks_seen
+            assert ranks_seen["distinct_devices"] == world, ranks_seen
     else:
         ranks_seen = {"backend": None, "world_size": 1, "ranks": [me], "distinct_devices": 1,
                       "launched_by": "torchrun" if "RANK" in os.environ else "python"}
@@ -435,6 +470,8 @@ def main():
             line["roofline_msda"] = roofline_msda
         if roofline_linear:
             line["roofline_linear"] = roofline_linear
+        if roofline_bwd:
+            line["roofline_bwd"] = roofline_bwd
         if strong:
             line["strong_scaling"] = strong
         if extras:

@@ -26,6 +26,7 @@ for c, key in ((1, "c1_f32_fast"), (4, "c4_f32_fast"), (25, "c25_f32_fast")):
     out[key] = {"kernel_source_sha1": sha, "traffic_bytes": int((2 * fetch + write) * 1024), "fetch_kb": round(fetch),
                 "write_kb": round(write), "traffic_bytes_uncorrected": int((fetch + write) * 1024),
                 "valu_wave_insts": vals.get("SQ_INSTS_VALU"),
+                "gui_active_cycles": vals.get("GRBM_GUI_ACTIVE"), "ta_busy_cycles": vals.get("GRBM_TA_BUSY"),
                 "note": (f"{kern.strip()} only: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes "
                          f"(scripts/pmc_render.sh {c} {tag}_c{c}), mean of the launches of one run, MI355X, round 3 "
                          f"(profiles/{tag}_render_c{c}_pmc.txt). traffic_bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB: the guide's gfx950 "
