@@ -174,6 +174,10 @@ class RayShard:
     """What a loss needs to know about a ray-sharded head output: the UNSHARDED lattice, this rank's shard of it and
     the pixel coordinates of the local rays (one camera's rows, shared by all cameras)."""
 
+    # head outputs that hold only this rank's samples under ray sharding (the head also lists the shard itself under
+    # outputs['ray_shard']: losses read it from there — a python attribute on a tensor does not survive .float() / .contiguous())
+    local_keys = ('weights', 'ts', 'deltas', 'ray_indices', 'sample_sdf', 'eik_grad')
+
     def __init__(self, full: RaySet, local: RaySet, pix_local):
         self.full, self.local, self.pix_local = full, local, pix_local
         self.rank, self.world_size = world()

@@ -17,10 +17,14 @@ class BaseLoss(nn.Module):
 
     def forward(self, inputs):
         args = {arg: inputs[key] for arg, key in self.input_dict.items()}
+        # ray-sharded head: outputs['ray_shard'] names the shard explicitly (dist.RayShard.local_keys = the per-sample
+        # outputs that hold this rank's rows only); LocalRows / tagged tensors carry it as well
+        shard = inputs.get('ray_shard') if hasattr(inputs, 'get') else None
+        self._ray_shard = shard
         if not self.supports_ray_shard:
             from ..dist import shard_of
             for arg, v in args.items():
-                if shard_of(v) is not None:
+                if shard_of(v) is not None or (shard is not None and self.input_dict[arg] in shard.local_keys):
                     raise NotImplementedError(
                         f"{type(self).__name__} received '{arg}' from a ray-sharded head (per-sample tensors of this rank's "
                         f"rows only) but does not reduce them locally; run it with NeuSHead(ray_shard=False)")

@@ -95,10 +95,9 @@ class EikonalLoss(BaseLoss):
 
     supports_ray_shard = True
 
-    @staticmethod
-    def eikonal(eik_grad):
+    def eikonal(self, eik_grad):
         from ..dist import shard_of, global_value_local_grad
-        shard = shard_of(eik_grad)
+        shard = getattr(self, '_ray_shard', None) or shard_of(eik_grad)     # explicit (outputs['ray_shard']) first
         n_local = eik_grad.numel() // max(eik_grad.shape[-1], 1)
         if (eik_grad.is_cuda and eik_grad.dtype == torch.float32 and eik_grad.shape[-1] == 3 and n_local > 0
                 and not torch.is_autocast_enabled()):

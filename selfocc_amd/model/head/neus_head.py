@@ -410,25 +410,27 @@ class NeuSHead(BaseModule):
 
     def _agree_on_lattice(self, rays, pix, vol=None):
         """'cellular' lattices are drawn with numpy's generator on every rank: rank 0's draw wins.  The same
-        broadcast carries a fingerprint of rank 0's frame — the camera matrices and a strided sample of the SDF volume:
-        ray sharding splits ONE frame over the ranks, so a launch that feeds every rank its own
-        frame (the reference's DistributedSampler, dataset/__init__.py:86-87) would stitch row blocks of different
-        scenes together and sum gradients of unrelated volumes; that raises here instead."""
+        broadcast carries a fingerprint of rank 0's frame — the camera matrices themselves, compared EXACTLY (they are
+        rank-invariant inputs: the same numpy metas uploaded on every rank; a float sum of the SDF volume is not — the ranks'
+        encoders may differ in the last bit, and a signed sum cancels towards zero): ray sharding splits ONE frame over the
+        ranks, so a launch that feeds every rank its own frame (the reference's DistributedSampler,
+        dataset/__init__.py:86-87) would stitch row blocks of different scenes together and sum gradients of unrelated
+        volumes; that raises here instead.  The comparison (one more all-reduce and a host read) runs on the first call and
+        then every SELFOCC_RAY_SHARD_CHECK_EVERY-th (default 64; 1 = always, 0 = first call only)."""
         dev = pix.device if dist.get_backend() == 'nccl' else 'cpu'                         # RCCL moves device memory only
-        finger = [rays.img2lidar.double().sum().reshape(1), rays.img2lidar.double().abs().sum().reshape(1)]
-        if vol is not None:
-            flat = vol.sdf.detach().reshape(-1)
-            finger.append(flat[::max(1, flat.numel() // 4096)].double().sum().reshape(1))
-        mine = torch.cat([torch.tensor([rays.sx, rays.sy, rays.ox, rays.oy], dtype=torch.float64, device=pix.device)] +
-                         [f.to(pix.device) for f in finger]).to(dev)
+        mine = torch.cat([torch.tensor([rays.sx, rays.sy, rays.ox, rays.oy], dtype=torch.float64, device=pix.device),
+                          rays.img2lidar.detach().double().reshape(-1)]).to(dev)
         lat = mine.clone()
         dist.broadcast(lat, 0)
-        same = torch.isclose(lat[4:], mine[4:], rtol=1e-6, atol=1e-9).all().to(torch.int32).reshape(1)
-        dist.all_reduce(same, op=dist.ReduceOp.MIN)          # every rank learns of a mismatch anywhere, so all raise together
-        if int(same.item()) == 0:
-            raise RuntimeError("NeuSHead(ray_shard=True): the ranks hold DIFFERENT frames (camera matrices / field volume differ "
-                               "from rank 0's). Ray sharding splits one frame over the ranks; feed every rank the same batch "
-                               "(no DistributedSampler) or turn ray_shard off for frame-per-GPU data parallelism.")
+        every = int(os.environ.get('SELFOCC_RAY_SHARD_CHECK_EVERY', '64'))
+        n = self._shard_calls = getattr(self, '_shard_calls', -1) + 1
+        if n == 0 or (every > 0 and n % every == 0):
+            same = (lat[4:] == mine[4:]).all().to(torch.int32).reshape(1)
+            dist.all_reduce(same, op=dist.ReduceOp.MIN)          # every rank learns of a mismatch anywhere, so all raise together
+            if int(same.item()) == 0:
+                raise RuntimeError("NeuSHead(ray_shard=True): the ranks hold DIFFERENT frames (camera matrices differ from rank "
+                                   "0's). Ray sharding splits one frame over the ranks; feed every rank the same batch "
+                                   "(no DistributedSampler) or turn ray_shard off for frame-per-GPU data parallelism.")
         sx, sy, ox, oy = (float(np.float32(v)) for v in lat[:4].tolist())
         if (sx, sy, ox, oy) != (rays.sx, rays.sy, rays.ox, rays.oy):
             rays = RaySet(img2lidar=rays.img2lidar, nx=rays.nx, ny=rays.ny, sx=sx, sy=sy, ox=ox, oy=oy)
@@ -538,6 +540,9 @@ class NeuSHead(BaseModule):
         cfg = self._render_cfg(self.training)
         full_rays = None
         if self._sharding(rays):
+            if self.two_split and self.img2lidar.two_split:
+                raise NotImplementedError("NeuSHead(ray_shard=True) with two_split: the losses' gather of per-ray terms assumes "
+                                          "every camera of the lattice (no shipped config combines them)")
             # the volume is replicated, the rays are split.  Each rank renders (and later
             # back-propagates) its row block; dL/d(volume) is summed over the ranks by ONE all-reduce.
             from ... import dist as sdist
@@ -591,6 +596,8 @@ class NeuSHead(BaseModule):
                    'ray_indices': ray_idx, 'weights': per_cam(weights), 'ts': per_cam(ts), 'deltas': per_cam(deltas),
                    'eik_grad': out['grad'].reshape(-1, 3) if shard is None else sdist.tag_local(out['grad'].reshape(-1, 3), shard),
                    'uniform_sdf': None}
+        if shard is not None:
+            outputs['ray_shard'] = shard       # the losses read the shard from here (dist.RayShard.local_keys)
         if self.return_uniform_sdf:
             outputs['uniform_sdf'] = self.get_uniform_sdf(self.aabb, self.resolution, device, True)[0]
         if self.return_max_depth:

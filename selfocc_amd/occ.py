@@ -113,13 +113,22 @@ _LATTICES = {}
 
 def uniform_lattice(aabb, resolution, device, shift=False):
     """xyz lattice of NeuSHead.get_uniform_sdf (neus_head.py:266-281): (H, W, D, 3).  The unshifted lattice is a constant of
-    (aabb, resolution, device): built once (it was three linspace kernels, a stack and a 7.7 MB copy per evaluation frame)."""
-    key = (tuple(float(v) for v in aabb), float(resolution), str(device))
+    (aabb, resolution, device): built once (it was three linspace kernels, a stack and a 7.7 MB copy per evaluation frame).
+    The cached tensor is handed to every caller (NeuSHead.forward_occ returns it as `xyz`), so it is READ-ONLY by
+    contract; an in-place edit by a caller bumps the tensor's version counter, which is checked here: an edited lattice is
+    rebuilt, never served again."""
+    dev = torch.device(device)
+    if dev.type == 'cuda' and dev.index is None:
+        dev = torch.device('cuda', torch.cuda.current_device())      # 'cuda' and 'cuda:0' are one cache entry
+    key = (tuple(float(v) for v in aabb), float(resolution), dev.type, dev.index)
     if not shift and key in _LATTICES:
-        return _LATTICES[key]
-    xs = torch.linspace(aabb[0], aabb[3], int((aabb[3] - aabb[0]) / resolution), device=device)
-    ys = torch.linspace(aabb[1], aabb[4], int((aabb[4] - aabb[1]) / resolution), device=device)
-    zs = torch.linspace(aabb[2], aabb[5], int((aabb[5] - aabb[2]) / resolution), device=device)
+        xyz, version = _LATTICES[key]
+        if xyz._version == version:
+            return xyz
+        del _LATTICES[key]
+    xs = torch.linspace(aabb[0], aabb[3], int((aabb[3] - aabb[0]) / resolution), device=dev)
+    ys = torch.linspace(aabb[1], aabb[4], int((aabb[4] - aabb[1]) / resolution), device=dev)
+    zs = torch.linspace(aabb[2], aabb[5], int((aabb[5] - aabb[2]) / resolution), device=dev)
     W, H, D = len(xs), len(ys), len(zs)
     xyz = torch.stack([xs[None, :, None].expand(H, W, D), ys[:, None, None].expand(H, W, D),
                        zs[None, None, :].expand(H, W, D)], dim=-1)
@@ -127,7 +136,7 @@ def uniform_lattice(aabb, resolution, device, shift=False):
         return xyz + torch.rand_like(xyz) * resolution
     if len(_LATTICES) > 8:
         _LATTICES.clear()
-    _LATTICES[key] = xyz
+    _LATTICES[key] = (xyz, xyz._version)
     return xyz
 
 
