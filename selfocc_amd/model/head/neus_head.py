@@ -361,6 +361,30 @@ class NeuSHead(BaseModule):
         # the pass costs ~25 x the depth render
         self.render_normal = render_normal
         self.last_inv_s = None
+        self._register_load_state_dict_pre_hook(self._report_foreign_field_keys, with_module=True)
+
+    @staticmethod
+    def _report_foreign_field_keys(module, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        """train.py:152-170 loads checkpoints with strict=False: a checkpoint written by the reference (whose `head.model.*`
+        parameters are the sdfstudio fork's NeuSCustomModel / SDFCustomField — not on disk, so their names cannot be
+        mapped) would silently lose every head weight.  This hook renames the one known alias (the authors' in-repo field,
+        `model.field.net.density_net.*`) and otherwise REPORTS, by name, which checkpoint keys under this head match nothing
+        and which of the head's own parameters the checkpoint does not provide."""
+        own = {prefix + k for k in module.state_dict().keys()}
+        alias = prefix + 'model.field.net.density_net.'
+        for k in [k for k in state_dict if k.startswith(alias)]:
+            tgt = prefix + 'model.field.density_net.' + k[len(alias):]
+            if tgt in own and tgt not in state_dict:
+                state_dict[tgt] = state_dict.pop(k)
+        given = {k for k in state_dict if k.startswith(prefix)}
+        foreign, absent = sorted(given - own), sorted(own - given)
+        if foreign or (absent and given):
+            import warnings
+            warnings.warn(f"NeuSHead.load_state_dict: {len(foreign)} checkpoint key(s) under '{prefix}' match no parameter of "
+                          f"this head and are NOT loaded: {foreign[:12]}{' ...' if len(foreign) > 12 else ''}; "
+                          f"{len(absent)} parameter(s) of this head keep their initial values: {absent[:12]}"
+                          f"{' ...' if len(absent) > 12 else ''}.  (The reference's head parameters belong to its sdfstudio "
+                          "fork; see README 'Deviations'.)")
 
     # ---- helpers -----------------------------------------------------------------------
     def _render_cfg(self, training):

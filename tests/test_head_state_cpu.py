@@ -1,0 +1,48 @@
+"""CPU: NeuSHead.load_state_dict reports checkpoint keys it cannot place (train.py:152-170 loads with strict=False, so a
+reference checkpoint's sdfstudio-fork head parameters would otherwise be dropped without a word) and maps the one known
+alias (the authors' in-repo field, model/head/nerfacc_head/bev_nerf.py)."""
+import json
+import os
+import warnings
+
+import torch
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _model():
+    from selfocc_amd.registry import MODELS
+    import selfocc_amd.model  # noqa: F401
+    cfg = json.load(open(os.path.join(G, "head_occ_cfg.json")))['occ']
+
+    class Seg(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.head = MODELS.build(dict(type='NeuSHead', **cfg))
+    return Seg()
+
+
+def test_own_checkpoint_loads_silently():
+    m = _model()
+    sd = {k: torch.randn_like(v) for k, v in m.state_dict().items()}
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        res = m.load_state_dict(sd, strict=False)
+    assert not res.missing_keys and not res.unexpected_keys and not w
+    assert all(torch.equal(m.state_dict()[k], v) for k, v in sd.items())
+
+
+def test_alias_is_mapped_and_foreign_keys_are_named():
+    m = _model()
+    own = m.state_dict()
+    sd = {k.replace('model.field.density_net', 'model.field.net.density_net'): torch.randn_like(v) for k, v in own.items()}
+    sd['head.model.field.glin0.weight'] = torch.zeros(3)          # a name only the fork's SDFCustomField could define
+    del sd['head.model.field.variance']
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        res = m.load_state_dict(sd, strict=False)
+    assert res.unexpected_keys == ['head.model.field.glin0.weight'] and res.missing_keys == ['head.model.field.variance']
+    msg = "".join(str(x.message) for x in w)
+    assert 'head.model.field.glin0.weight' in msg and 'head.model.field.variance' in msg and 'NOT loaded' in msg
+    k = 'head.model.field.density_net.1.weight'
+    assert torch.equal(m.state_dict()[k], sd['head.model.field.net.density_net.1.weight'])
