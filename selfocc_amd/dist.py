@@ -227,3 +227,124 @@ def global_value_local_grad(local):
     else:
         dist.all_reduce(tot)
     return local + (tot - local.detach())
+
+
+# ---- encoder row sharding ("shard queries across ranks, values replicated, all-gather the updated
+# planes per layer") ------------------------------------------------------------------------------------------------------
+def _all_reduce_(t):
+    """in-place sum over the ranks (gloo cannot reduce CUDA tensors: staged through the host on the test rigs)"""
+    if t.is_cuda and dist.get_backend() == 'gloo':
+        h = t.cpu()
+        dist.all_reduce(h)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t)
+    return t
+
+
+class PlaneRowShard:
+    """Row blocks of the TPV / BEV planes per rank: EVERY plane is cut into world_size contiguous blocks (a zh / wz row costs
+    six times the sampling points of an hw row at the shipped pillar sizes, so cutting the concatenated tensor instead would
+    leave the last ranks with most of the work).  ``local`` rows of a rank = its block of plane 0, then of plane 1, ..."""
+
+    def __init__(self, sizes, rank=None, world_size=None):
+        if rank is None:
+            rank, world_size = world()
+        assert min(sizes) >= world_size, f"row sharding needs >= {world_size} rows in every plane, got {sizes}"
+        self.sizes, self.rank, self.world_size = list(sizes), rank, world_size
+        self.blocks = [[row_block(n, r, world_size) for n in sizes] for r in range(world_size)]     # [rank][plane] = (a, b)
+        self.local = self.blocks[rank]
+        self.local_sizes = [b - a for a, b in self.local]
+        self.n_local = sum(self.local_sizes)
+        self.max_local = max(sum(b - a for a, b in blk) for blk in self.blocks)
+        self._index = {}
+
+    def take(self, x, dim=1):
+        """local rows of a tensor whose ``dim`` runs over the concatenated planes, or of a list of per-plane tensors"""
+        if torch.is_tensor(x):
+            off, parts = 0, []
+            for n, (a, b) in zip(self.sizes, self.local):
+                parts.append(x.narrow(dim, off + a, b - a))
+                off += n
+            return torch.cat(parts, dim)
+        return torch.cat([t.narrow(dim, a, b - a) for t, (a, b) in zip(x, self.local)], dim)
+
+    def take_plane(self, t, i, dim):
+        a, b = self.local[i]
+        return t.narrow(dim, a, b - a)
+
+    def gather_index(self, device):
+        """row of the (world_size * max_local) padded all-gather buffer that holds row j of the concatenated planes"""
+        idx = self._index.get(str(device))
+        if idx is None:
+            parts = []
+            for i in range(len(self.sizes)):
+                for r in range(self.world_size):
+                    off = sum(b - a for a, b in self.blocks[r][:i])
+                    a, b = self.blocks[r][i]
+                    parts.append(torch.arange(b - a) + (r * self.max_local + off))
+            idx = self._index[str(device)] = torch.cat(parts).to(device)
+        return idx
+
+
+def _gather_plane_rows(loc, shard):
+    """(1, n_local, C) of every rank -> (1, N, C) in plane order"""
+    C = loc.shape[-1]
+    pad = loc.new_zeros(shard.max_local, C)
+    pad[:shard.n_local] = loc.reshape(-1, C)
+    bufs = [torch.empty_like(pad) for _ in range(shard.world_size)]
+    _all_gather(bufs, pad)
+    return torch.cat(bufs, 0).index_select(0, shard.gather_index(loc.device)).unsqueeze(0)
+
+
+class _GatherPlaneRows(torch.autograd.Function):
+    """all-gather of the ranks' row blocks in forward.  Backward: the gathered tensor is consumed by EVERY rank (as the
+    next layer's local rows and as its self-attention value), each contributing a part of its gradient, so the parts are
+    summed over the ranks first (``reduce_grad``; not for the encoder's final output, whose gradient arrives complete
+    and identical on every rank from the replicated field volume) and each rank keeps the rows it produced."""
+
+    @staticmethod
+    def forward(ctx, loc, shard, reduce_grad):
+        ctx.shard, ctx.reduce_grad = shard, reduce_grad
+        return _gather_plane_rows(loc, shard)
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        if ctx.reduce_grad:
+            g = _all_reduce_(g.clone())
+        return ctx.shard.take(g, 1).contiguous(), None, None
+
+
+def gather_plane_rows(loc, shard, reduce_grad=True):
+    if torch.is_grad_enabled() and loc.requires_grad:
+        return _GatherPlaneRows.apply(loc, shard, reduce_grad)
+    return _gather_plane_rows(loc, shard)
+
+
+class _GroupGradSum(torch.autograd.Function):
+    """Identity on a group of (parameter) tensors; backward = ONE coalesced all-reduce(sum) of all their gradients: under
+    row sharding a rank's parameter gradients cover its own rows only."""
+
+    @staticmethod
+    def forward(ctx, *ts):
+        return tuple(t.view_as(t) for t in ts)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        flat = torch.cat([g.reshape(-1).float() for g in gs])
+        _all_reduce_(flat)
+        out, off = [], 0
+        for g in gs:
+            n = g.numel()
+            out.append(flat[off:off + n].view_as(g).to(g.dtype))
+            off += n
+        return tuple(out)
+
+
+def group_grad_sum(tensors):
+    """``tensors`` unchanged in forward; their gradients summed over the ranks in one all-reduce in backward."""
+    tensors = list(tensors)
+    if world()[1] == 1 or not torch.is_grad_enabled() or not any(t.requires_grad for t in tensors):
+        return tensors
+    return list(_GroupGradSum.apply(*tensors))

@@ -202,7 +202,11 @@ class TPVFormerLayer(_FormerLayerBase):
     def forward(self, query, key=None, value=None, tpv_pos=None, ref_2d=None, spatial_shapes=None,
                 level_start_index=None, reference_points_cams=None, tpv_masks=None, tpv_size=None, **kwargs):
         H, W, Z = tpv_size
-        sizes = [H * W, Z * H, W * Z]
+        # row-sharded encoder (TPVFormerEncoder(row_shard=True)): `query` holds this rank's rows of every plane
+        # (`plane_sizes`), the cross-view self-attention still samples ALL rows (`self_attn_value`, replicated); every other
+        # step is row-wise
+        sizes = kwargs.pop('plane_sizes', None) or [H * W, Z * H, W * Z]
+        self_value = kwargs.pop('self_attn_value', None)
         tpv_pos_cat = kwargs.pop('tpv_pos_cat', None)
         if tpv_pos_cat is None:
             tpv_pos_cat = torch.cat(tpv_pos, dim=1)
@@ -227,7 +231,8 @@ class TPVFormerLayer(_FormerLayerBase):
             if op == 'self_attn':   # cross-view hybrid attention: the 3 planes are the 3 "levels"
                 ss, lsi = _plane_shapes(H, W, Z, device)     # constants: uploaded once, not once per layer call
                 q = _as_cat(query)
-                query = self.attentions[attn_i](q, q, q, _as_cat(identity) if self.pre_norm else None,
+                v = q if self_value is None else self_value
+                query = self.attentions[attn_i](q, v, v, _as_cat(identity) if self.pre_norm else None,
                                                 query_pos=tpv_pos_cat, reference_points=ref_2d,
                                                 spatial_shapes=ss, level_start_index=lsi, post_norm=post_norm, **kwargs)
                 attn_i += 1
@@ -444,8 +449,9 @@ class _FlattenFeats(torch.autograd.Function):
 class TPVFormerEncoder(_EncoderBase):
     def __init__(self, mapping_args, embed_dims=128, num_cams=6, num_feature_levels=4, positional_encoding=None,
                  num_points_cross=[64, 64, 8], num_points_self=[16, 16, 16], transformerlayers=None,
-                 num_layers=None, camera_aware=False, camera_aware_mid_channels=None, init_cfg=None):
+                 num_layers=None, camera_aware=False, camera_aware_mid_channels=None, init_cfg=None, row_shard=False):
         super().__init__(init_cfg)
+        self.row_shard = row_shard          # split the plane rows over the ranks (one frame on all ranks; dist.PlaneRowShard)
         if camera_aware:
             raise NotImplementedError("camera_aware=True (CameraAwareSE) is off in every shipped config")
         self.embed_dims, self.num_feature_levels, self.num_cams = embed_dims, num_feature_levels, num_cams
@@ -477,6 +483,57 @@ class TPVFormerEncoder(_EncoderBase):
             self.register_buffer(name, g2m(g).flatten(0, 1).transpose(0, 1).contiguous(), False)   # (D, Q, 3) as point_sampling reads it
         self.register_buffer('cross_view_ref_points', get_cross_view_ref_points(H, W, Z, num_points_self), False)
 
+    def _row_sharding(self):
+        """True when this call splits the plane rows over the ranks: ``row_shard=True`` (or SELFOCC_ENC_SHARD=1) and an
+        initialised process group with world_size > 1.  Like NeuSHead(ray_shard=True) it assumes that every rank holds
+        the SAME frame (one frame's work split over the ranks)."""
+        import torch.distributed as tdist
+        on = self.row_shard or os.environ.get('SELFOCC_ENC_SHARD', '0') == '1'
+        return bool(on and tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1)
+
+    def _forward_layers_sharded(self, tpv_query, key, value, tpv_pos, tpv_pos_cat, spatial_shapes, level_start_index,
+                                reference_points_cams, tpv_masks, ref_cross_view, **kwargs):
+        """every rank owns a row block of each plane.  Per layer: cross-view self-attention of the local
+        rows over the full (replicated) planes, image cross-attention / norms / FFN on the local rows, then ONE all-gather
+        of the updated rows (78 899 x 96 floats = 30 MB at the shipped size).  Under autograd the gather's backward sums
+        the ranks' partial gradients of the gathered planes, and each layer's parameter gradients (computed from the local
+        rows only) are summed in one coalesced all-reduce per layer, so that every rank ends up with the gradients of the
+        unsharded encoder; the image features' and the incoming queries' gradients likewise (replicate_grad_sum)."""
+        from ... import dist as sdist
+        from torch.func import functional_call
+        H, W, Z = self.tpv_size
+        sizes = [H * W, Z * H, W * Z]
+        shard = getattr(self, '_row_shard_plan', None)
+        if shard is None or shard.sizes != sizes or (shard.rank, shard.world_size) != sdist.world():
+            shard = self._row_shard_plan = sdist.PlaneRowShard(sizes)
+        grad = torch.is_grad_enabled()
+        q_full = _as_cat(tpv_query)
+        if grad:
+            q_full = sdist.replicate_grad_sum(q_full)                    # the lifter's queries: used by local rows only
+            key = value = sdist.replicate_grad_sum(value)                # image features: sampled by local queries only
+            tpv_pos_cat = sdist.replicate_grad_sum(torch.cat(tpv_pos, dim=1) if tpv_pos_cat is None else tpv_pos_cat)
+        elif tpv_pos_cat is None:
+            tpv_pos_cat = torch.cat(tpv_pos, dim=1)
+        pos_loc = shard.take(tpv_pos_cat, 1)
+        pos_planes = list(torch.split(pos_loc, shard.local_sizes, 1))
+        ref_loc = shard.take(ref_cross_view, 1)
+        cams_loc = [shard.take_plane(c, i, 2) for i, c in enumerate(reference_points_cams)]
+        masks_loc = [shard.take_plane(m, i, 2) for i, m in enumerate(tpv_masks)]
+        last = len(self.layers) - 1
+        for li, layer in enumerate(self.layers):
+            q_loc = _as_planes(shard.take(q_full, 1), shard.local_sizes)
+            call = dict(tpv_pos=pos_planes, tpv_pos_cat=pos_loc, ref_2d=ref_loc, spatial_shapes=spatial_shapes,
+                        level_start_index=level_start_index, reference_points_cams=cams_loc, tpv_masks=masks_loc,
+                        tpv_size=self.tpv_size, rebatch_plans=None, plane_sizes=shard.local_sizes, self_attn_value=q_full,
+                        **kwargs)
+            if grad:
+                names, ps = zip(*layer.named_parameters())
+                out = functional_call(layer, dict(zip(names, sdist.group_grad_sum(ps))), (q_loc, key, value), call)
+            else:
+                out = layer(q_loc, key, value, **call)
+            q_full = sdist.gather_plane_rows(_as_cat(out), shard, reduce_grad=li < last)
+        return _as_planes(q_full, sizes)
+
     def forward_layers(self, tpv_query, key, value, tpv_pos=None, spatial_shapes=None, level_start_index=None,
                        img_metas=None, **kwargs):
         bs = tpv_query[0].shape[0]
@@ -490,6 +547,9 @@ class TPVFormerEncoder(_EncoderBase):
         # (batch > 1, shapes the banded scatter does not cover) builds its own
         plans = None
         tpv_pos_cat = kwargs.pop('tpv_pos_cat', None)
+        if self._row_sharding():
+            return self._forward_layers_sharded(tpv_query, key, value, tpv_pos, tpv_pos_cat, spatial_shapes, level_start_index,
+                                                reference_points_cams, tpv_masks, ref_cross_view, **kwargs)
         if tpv_pos_cat is None:
             tpv_pos_cat = torch.cat(tpv_pos, dim=1)    # once per forward, not once per layer
         for layer in self.layers:

@@ -179,3 +179,76 @@ def test_sharded_loss_terms_world2_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert all(ret.get(r) for r in range(ws)), dict(ret)
+
+
+# ---- encoder row sharding: the collectives and the bookkeeping on CPU tensors (the encoder's kernels need a GPU: the
+# two-rank comparison with the real modules is tests/test_dist_gpu.py::test_row_sharded_encoder_equals_unsharded_world2)
+def test_plane_row_shard_bookkeeping():
+    from selfocc_amd.dist import PlaneRowShard
+    sizes = [13, 5, 7]
+    full = torch.arange(sum(sizes) * 2, dtype=torch.float32).reshape(1, sum(sizes), 2)
+    for ws in (2, 3, 5):
+        shards = [PlaneRowShard(sizes, r, ws) for r in range(ws)]
+        assert sum(s.n_local for s in shards) == sum(sizes)
+        assert all(max(s.local_sizes[i] for s in shards) - min(s.local_sizes[i] for s in shards) <= 1 for i in range(3))
+        # pad every rank's local rows to max_local, stack, index: the concatenated planes come back in order
+        pad = torch.zeros(ws * shards[0].max_local, 2)
+        for r, s in enumerate(shards):
+            pad[r * s.max_local:r * s.max_local + s.n_local] = s.take(full, 1)[0]
+        assert torch.equal(pad.index_select(0, shards[0].gather_index('cpu'))[None], full)
+        planes = list(torch.split(full, sizes, 1))
+        assert all(torch.equal(s.take(planes, 1), s.take(full, 1)) for s in shards)
+    with pytest.raises(AssertionError):
+        PlaneRowShard([4, 1, 4], 0, 2)
+
+
+def _worker_rows(rank, ws, port, ret):
+    from selfocc_amd.dist import PlaneRowShard, gather_plane_rows, group_grad_sum, replicate_grad_sum
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        g = torch.Generator().manual_seed(0)
+        sizes, C = [11, 4, 6], 3
+        x = torch.randn(1, sum(sizes), C, generator=g)                  # replicated input planes
+        w1, w2 = torch.randn(C, C, generator=g), torch.randn(C, C, generator=g)
+        coef = torch.randn(1, sum(sizes), C, generator=g)
+
+        def layers(xf, a, b, shard):
+            """two 'layers': rows mix with the column means of ALL rows (the value path) through a shared weight"""
+            for li, w in enumerate((a, b)):
+                if shard is None:
+                    xf = torch.tanh(xf @ w) + xf.mean(1, keepdim=True) @ w
+                else:
+                    (wl,) = group_grad_sum([w])
+                    loc = torch.tanh(shard.take(xf, 1) @ wl) + xf.mean(1, keepdim=True) @ wl
+                    xf = gather_plane_rows(loc, shard, reduce_grad=li < 1)
+            return xf
+
+        xa, a0, b0 = x.clone().requires_grad_(True), w1.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+        ref = layers(xa, a0, b0, None)
+        (ref * coef).sum().backward()
+        xb, a1, b1 = x.clone().requires_grad_(True), w1.clone().requires_grad_(True), w2.clone().requires_grad_(True)
+        got = layers(replicate_grad_sum(xb), a1, b1, PlaneRowShard(sizes))
+        (got * coef).sum().backward()                                     # the same (replicated) loss on every rank
+        ok = torch.allclose(got, ref, atol=1e-6)
+        for p, q in ((xa, xb), (a0, a1), (b0, b1)):
+            ok = ok and torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-6)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_sharded_layers_equal_unsharded_world2_gloo():
+    """gather_plane_rows / group_grad_sum / replicate_grad_sum: a two-layer stand-in whose rows read ALL rows (like the
+    cross-view self-attention's value) gives the unsharded outputs and gradients on both ranks."""
+    ws = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_rows, args=(r, ws, port, ret)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert all(ret.get(r) is True for r in range(ws)), dict(ret)

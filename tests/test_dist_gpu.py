@@ -118,6 +118,67 @@ def test_ray_sharded_head_equals_unsharded_world2(hip):
         assert ret.get(r) == [], f"rank {r}: {ret.get(r)}"
 
 
+def _enc_worker(rank, ws, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        import test_golden_encoder_full_gpu as tf
+        msgs = []
+        z, enc, lifter, feats, metas, loss_dirs = tf._setup()          # shipped structure, reduced grid (25 x 25 x 7)
+        base = tf._train_pass(enc, lifter, feats, metas, loss_dirs)
+        with torch.no_grad():
+            base_inf = [o.clone() for o in enc(lifter(feats)['representation'], ms_img_feats=feats, metas=metas)['representation']]
+        enc.row_shard = True                                            # every plane's rows split over the two ranks
+        got = tf._train_pass(enc, lifter, feats, metas, loss_dirs)
+        with torch.no_grad():
+            got_inf = [o.clone() for o in enc(lifter(feats)['representation'], ms_img_feats=feats, metas=metas)['representation']]
+        plan = enc._row_shard_plan
+        if plan.world_size != ws or plan.n_local >= sum(plan.sizes) or min(plan.local_sizes) < 1:
+            msgs.append(f"no sharding happened: {plan.local_sizes} of {plan.sizes}")
+        for i, (a, b) in enumerate(zip(base[0], got[0])):
+            if (a - b).abs().max().item() > 1e-5 * max(1.0, a.abs().max().item()):
+                msgs.append(f"train forward plane {i}: max diff {(a - b).abs().max().item():.3e}")
+        for i, (a, b) in enumerate(zip(base_inf, got_inf)):
+            if (a - b).abs().max().item() > 1e-5 * max(1.0, a.abs().max().item()):
+                msgs.append(f"inference plane {i}: max diff {(a - b).abs().max().item():.3e}")
+        if abs(base[1].item() - got[1].item()) > 1e-6 * abs(base[1].item()) + 1e-9:
+            msgs.append(f"loss {base[1].item()} vs {got[1].item()}")
+        worst = 0.0
+        for k, a in base[2].items():
+            b = got[2][k]
+            e = (a - b).abs().max().item() / max(a.abs().max().item(), 1e-30)
+            worst = max(worst, e)
+            if e > 1e-4:      # float32 sums in a different order (row blocks, all-reduced partial sums)
+                msgs.append(f"grad {k}: {e:.3e} of its scale")
+        ret[rank] = msgs
+        ret[f'worst{rank}'] = worst
+    except Exception as e:   # surface the failure in the parent
+        import traceback
+        ret[rank] = [f"exception: {e!r}\n{traceback.format_exc()}"]
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_sharded_encoder_equals_unsharded_world2(hip):
+    """TPVFormerEncoder(row_shard=True) on two ranks (queries sharded, values replicated, one all-gather
+    of the planes per layer): forward planes (inference and training route) and EVERY gradient — parameters, lifter queries,
+    FPN maps — equal the unsharded encoder's on both ranks."""
+    ws = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_enc_worker, args=(r, ws, port, ret)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    for r in range(ws):
+        assert ret.get(r) == [], f"rank {r}: {ret.get(r)}"
+    print("worst relative gradient difference", [ret.get(f'worst{r}') for r in range(ws)])
+
+
 @pytest.mark.parametrize("shard", ["frames", "rays"])
 def test_bench_two_ranks_on_one_gpu(shard):
     """bench.py's N > 1 path exactly as the driver launches it (torch.distributed.run, 2 ranks), both ranks on cuda:0 over
