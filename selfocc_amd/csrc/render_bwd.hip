@@ -134,7 +134,7 @@ struct RbBin {
     int2 *blk_tot;     // [ceil(n_bricks / 1024)] (samples, items) per scan block
     int4 *items;       // [max_items] {brick, begin, end, -}
     int nbh, nbw, nbd, chunk;
-    int dbg;           // dev switches (SELFOCC_RB_DBG): 1 = no LDS adds, 2 = no flush
+    int dbg;           // dev switches (SELFOCC_RB_DBG): 1 = no accumulation, 2 = no flush, 4 = no run merging
 };
 
 SO_DEVFN int rb_key(const RbBin &b, const so_cell &c, int H, int W, int D) {
@@ -182,6 +182,8 @@ SO_DEVFN int rb_run(int key, int lane, int &head_lane) {
 // block's four waves share one ray, wave w taking step (j * 4 + w) — at the shipped 256 samples per ray
 // that is M = 1, which cuts the per-sample register state 4x (the M = 4 form needed > 256 VGPRs: one wave
 // per SIMD, latency-bound); scan carries and per-ray sums cross the waves through a few floats of LDS.
+// (Measured and dropped, round 4: forcing the 24-channel BIN instantiation to 3 / 4 waves per SIMD with
+// amdgpu_waves_per_eu — 168 / 128 VGPRs, 296 / 484 B of scratch — 0.98 -> 1.67 / 1.96 ms: the spills land in the corner loops.)
 template <int NF, bool BF16, int M, int WPR, bool BIN>
 __global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba, RbBin bin) {
     static_assert(WPR == 1 || WPR == 4, "waves per ray");
@@ -729,15 +731,54 @@ __global__ __launch_bounds__(NT) void rb_brick_kernel(RbBin b, float *__restrict
     const bool sdf_lane = sub >= RECF - 8;
     const int mk = sub - (RECF - 8), mkd = mk & 1, mkw = (mk >> 1) & 1, mkh = (mk >> 2) & 1;
     const int moff = ((mkh * kTW + mkw) * kTD + mkd) * RW + NCH;
-    // consecutive groups take consecutive records: a block step reads NG * RECF * 4 contiguous bytes
-    for (int i0 = it.y; i0 < it.z; i0 += NG * U) {
+    // Group g walks the CONTIGUOUS slice [y + g * per, ...) of the item, U records at a time.  The records of an item are
+    // in ray order (a run of consecutive samples of one ray takes consecutive slots), and consecutive samples of a ray share
+    // their cell 2 - 6 times at the shipped step / voxel ratio: the group sums such a run in registers and issues its LDS
+    // atomics once per run (the kernel sits on the ds_add_f64 issue rate: ~15 clocks per instruction, 35 M of them per launch
+    // before this).  SELFOCC_RB_DBG & 4: no merging (every sample flushes).
+    const int per = (it.z - it.y + NG - 1) / NG;
+    const int gb = it.y + grp * per, ge = min(it.z, gb + per);
+    const bool merge = !(b.dbg & 4);
+    int cur = -1;                 // packed cell of the open run
+    float acc[8];                 // feature lanes: the run's sum per corner; sdf lanes: acc[0] = the own corner's sum
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[k] = 0.0f;
+    auto flush = [&]() {
+        const int h0 = (cur >> 20) - 1, w0 = ((cur >> 10) & 1023) - 1, d0 = (cur & 1023) - 1;
+        const int lh = h0 - oh, lw = w0 - ow, ld = d0 - od;
+        // a corner counts when it is inside the volume AND inside this brick's tile (the second never fails: the
+        // counting pass and the ray kernel derive the cell with the same code; it only keeps a mismatch inside the tile)
+        const bool okh[2] = {((unsigned)h0 < (unsigned)H) && ((unsigned)lh < (unsigned)kTH),
+                             ((unsigned)(h0 + 1) < (unsigned)H) && ((unsigned)(lh + 1) < (unsigned)kTH)};
+        const bool okw[2] = {((unsigned)w0 < (unsigned)W) && ((unsigned)lw < (unsigned)kTW),
+                             ((unsigned)(w0 + 1) < (unsigned)W) && ((unsigned)(lw + 1) < (unsigned)kTW)};
+        const bool okd[2] = {((unsigned)d0 < (unsigned)D) && ((unsigned)ld < (unsigned)kTD),
+                             ((unsigned)(d0 + 1) < (unsigned)D) && ((unsigned)(ld + 1) < (unsigned)kTD)};
+        double *t0 = tile + ((lh * kTW + lw) * kTD + ld) * RW;
+        if constexpr (NCH > 0) {
+            if (sub < NCH) {
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const int kd = kk & 1, kw = (kk >> 1) & 1, kh = kk >> 2;
+                    if (okd[kd] && okw[kw] && okh[kh] && acc[kk] != 0.0f)
+                        __hip_atomic_fetch_add(t0 + ((kh * kTW + kw) * kTD + kd) * RW + sub, (double)acc[kk], __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+            }
+        }
+        if (sdf_lane && okd[mkd] && okw[mkw] && okh[mkh] && acc[0] != 0.0f)
+            __hip_atomic_fetch_add(t0 + moff, (double)acc[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc[k] = 0.0f;
+    };
+    for (int i0 = gb; i0 < ge; i0 += U) {
         bool ok[U];
         float v[U];
         float4 ta[U], tb[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int i = i0 + u * NG + grp;
-            ok[u] = i < it.z;
+            const int i = i0 + u;
+            ok[u] = i < ge;
             if (ok[u]) {
                 const float *r = b.rec + (size_t)i * RECF;
                 v[u] = r[sub];
@@ -749,29 +790,16 @@ __global__ __launch_bounds__(NT) void rb_brick_kernel(RbBin b, float *__restrict
         for (int u = 0; u < U; ++u) {
             if (!ok[u] || (b.dbg & 1)) continue;
             const int pack = __float_as_int(ta[u].y);
-            const int h0 = (pack >> 20) - 1, w0 = ((pack >> 10) & 1023) - 1, d0 = (pack & 1023) - 1;
-            const int lh = h0 - oh, lw = w0 - ow, ld = d0 - od;
+            if (pack != cur || !merge) {
+                if (cur >= 0) flush();
+                cur = pack;
+            }
             const float fh[2] = {1.0f - ta[u].z, ta[u].z}, fw[2] = {1.0f - ta[u].w, ta[u].w}, fd[2] = {1.0f - tb[u].x, tb[u].x};
-            // a corner counts when it is inside the volume AND inside this brick's tile (the second never fails: the
-            // counting pass and the ray kernel derive the cell with the same code; it only keeps a mismatch inside the tile)
-            const bool okh[2] = {((unsigned)h0 < (unsigned)H) && ((unsigned)lh < (unsigned)kTH),
-                                 ((unsigned)(h0 + 1) < (unsigned)H) && ((unsigned)(lh + 1) < (unsigned)kTH)};
-            const bool okw[2] = {((unsigned)w0 < (unsigned)W) && ((unsigned)lw < (unsigned)kTW),
-                                 ((unsigned)(w0 + 1) < (unsigned)W) && ((unsigned)(lw + 1) < (unsigned)kTW)};
-            const bool okd[2] = {((unsigned)d0 < (unsigned)D) && ((unsigned)ld < (unsigned)kTD),
-                                 ((unsigned)(d0 + 1) < (unsigned)D) && ((unsigned)(ld + 1) < (unsigned)kTD)};
-            double *t0 = tile + ((lh * kTW + lw) * kTD + ld) * RW;
             if constexpr (NCH > 0) {
                 if (sub < NCH) {
                     const float fdfw[2][2] = {{fd[0] * fw[0], fd[0] * fw[1]}, {fd[1] * fw[0], fd[1] * fw[1]}};
 #pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) {
-                        const int kd = kk & 1, kw = (kk >> 1) & 1, kh = kk >> 2;
-                        const float val = (fdfw[kd][kw] * fh[kh]) * v[u];
-                        if (okd[kd] && okw[kw] && okh[kh] && val != 0.0f)
-                            __hip_atomic_fetch_add(t0 + ((kh * kTW + kw) * kTD + kd) * RW + sub, (double)val, __ATOMIC_RELAXED,
-                                                   __HIP_MEMORY_SCOPE_WORKGROUP);
-                    }
+                    for (int kk = 0; kk < 8; ++kk) acc[kk] = fmaf(fdfw[kk & 1][(kk >> 1) & 1] * fh[kk >> 2], v[u], acc[kk]);
                 }
             }
             if (sdf_lane) {
@@ -781,12 +809,11 @@ __global__ __launch_bounds__(NT) void rb_brick_kernel(RbBin b, float *__restrict
                 const float dWd = (mkd ? 1.0f : -1.0f) * (fws * fhs);
                 const float dWw = (mkw ? 1.0f : -1.0f) * (fds * fhs);
                 const float dWh = (mkh ? 1.0f : -1.0f) * (fds * fws);
-                const float val = fmaf(Wk, ta[u].x, fmaf(dWd, tb[u].w, fmaf(dWw, tb[u].y, dWh * tb[u].z)));
-                if (okd[mkd] && okw[mkw] && okh[mkh] && val != 0.0f)
-                    __hip_atomic_fetch_add(t0 + moff, (double)val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                acc[0] += fmaf(Wk, ta[u].x, fmaf(dWd, tb[u].w, fmaf(dWw, tb[u].y, dWh * tb[u].z)));
             }
         }
     }
+    if (cur >= 0) flush();
     __syncthreads();
     if (b.dbg & 2) return;
     // flush.  Feature rows: RECF lanes per voxel row, consecutive groups = consecutive d (contiguous rows in HBM).
