@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SELFOCC_ABI_VERSION 28
+#define SELFOCC_ABI_VERSION 29
 
 int selfocc_abi_version(void);
 const char *selfocc_last_error(void);
@@ -422,6 +422,15 @@ int selfocc_iou_counts(const int32_t *pred, const int32_t *target, const uint8_t
 int selfocc_eikonal_partials(int64_t n);
 int selfocc_eikonal_fwd(const float *grad, float *partial, int64_t n, void *stream);
 int selfocc_eikonal_bwd(const float *grad, const float *scale, float *g_grad, int64_t n, void *stream);
+
+/* `y = identity + dropout(x)` of the attention / FFN outputs (mmcv: `self.dropout(output) + identity`,
+ * /root/reference/model/encoder/bevformer/attention/image_cross_attention.py:137-139,
+ * tpvformer/attention/cross_view_hybrid_attention.py:119-124) in one pass, and its backward g_x = keep ? g / (1 - p) : 0.
+ * Element i is kept iff a counter-based hash of (seed, i) maps to >= p (keep probability 1 - p, as torch's dropout; not
+ * torch's Philox stream), so no mask is stored: pass the SAME seed to the backward call.  n elements of float32,
+ * 16-byte aligned pointers; y may alias x or identity. */
+int selfocc_dropout_add_fwd(const float *x, const float *identity, float *y, int64_t n, float p, uint64_t seed, void *stream);
+int selfocc_dropout_bwd(const float *g, float *g_x, int64_t n, float p, uint64_t seed, void *stream);
 
 /* Compact second differences of the SDF volume (H, W, D) along h, w, d — NeuSHead's `second_grad`, the input of
  * SecondGradLoss (/root/reference/loss/second_grad_loss.py:6-19; this repo's declared compact form):

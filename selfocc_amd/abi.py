@@ -6,7 +6,7 @@ its exported symbols being callable with these layouts.
 """
 import ctypes as C
 
-ABI_VERSION = 28
+ABI_VERSION = 29
 
 # enums ---------------------------------------------------------------------------
 RAYS_EXPLICIT, RAYS_PIXEL_GRID = 0, 1
@@ -147,6 +147,8 @@ SYMBOLS = {
     "selfocc_eikonal_partials": (C.c_int, [C.c_int64]),
     "selfocc_eikonal_fwd": (C.c_int, [_p, _p, C.c_int64, _p]),
     "selfocc_eikonal_bwd": (C.c_int, [_p, _p, _p, C.c_int64, _p]),
+    "selfocc_dropout_add_fwd": (C.c_int, [_p, _p, _p, C.c_int64, C.c_float, C.c_uint64, _p]),
+    "selfocc_dropout_bwd": (C.c_int, [_p, _p, C.c_int64, C.c_float, C.c_uint64, _p]),
     "selfocc_ssim_fwd": (C.c_int, [_p] * 4 + [_i] * 4 + [_p, _p]),
     "selfocc_ssim_bwd": (C.c_int, [_p] * 4 + [_i] * 4 + [_p, _p, _p, _p]),
     "selfocc_reproj_fwd": (C.c_int, [C.POINTER(SoReprojArgs), _p]),

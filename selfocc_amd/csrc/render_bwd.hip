@@ -612,26 +612,43 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba, 
 }
 
 // ---- the binned scatter's own kernels ---------------------------------------------------------------------
-// one wave per ray (the ray's geometry once per lane, then S / 64 steps of 64 consecutive samples)
-__global__ __launch_bounds__(256) void rb_count_kernel(so_render_args a, RbBin b) {
-    const int ray = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (ray >= a.n_rays) return;
-    const int S = a.n_samples;
-    const RayGeomB g = load_ray(a, ray);
-    float tn, tf;
-    ray_bounds(a, g, tn, tf);
-    const int H = a.map.h.tot_len, W = a.map.w.tot_len, D = a.map.d.tot_len;
-    for (int s0 = 0; s0 < S; s0 += 64) {
-        const int smp = s0 + lane;
-        int key = -1;
-        if (smp < S) {
-            const so_cell c = sample_cell(a, g, edge_t(a, ray, smp, tn, tf), edge_t(a, ray, smp + 1, tn, tf));
-            key = rb_key(b, c, H, W, D) * kShards + rb_shard((long long)ray * S + smp);
+// one wave per ray (the ray's geometry once per lane, then S / 64 steps of 64 consecutive samples), 16 rays per block.
+// Neighbouring rays cross the same bricks, and every ray starts in the bricks around the cameras: the block first sums its
+// runs in a small LDS table (direct-mapped on the counter index; a collision goes to memory directly) and adds each
+// occupied slot to the global counter once — same-address device atomics serialise, and the hottest counters were hit by
+// every wave of the launch (0.24 ms with one atomic per run and 8 shards, 0.16 ms with 32 shards).
+constexpr int kCountWaves = 16, kCountSlots = 1024;
+__global__ __launch_bounds__(kCountWaves * 64) void rb_count_kernel(so_render_args a, RbBin b) {
+    __shared__ int tkey[kCountSlots], tcnt[kCountSlots];
+    for (int k = threadIdx.x; k < kCountSlots; k += kCountWaves * 64) { tkey[k] = -1; tcnt[k] = 0; }
+    __syncthreads();
+    const int ray = blockIdx.x * kCountWaves + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (ray < a.n_rays) {   // wave-uniform
+        const int S = a.n_samples;
+        const RayGeomB g = load_ray(a, ray);
+        float tn, tf;
+        ray_bounds(a, g, tn, tf);
+        const int H = a.map.h.tot_len, W = a.map.w.tot_len, D = a.map.d.tot_len;
+        for (int s0 = 0; s0 < S; s0 += 64) {
+            const int smp = s0 + lane;
+            int key = -1;
+            if (smp < S) {
+                const so_cell c = sample_cell(a, g, edge_t(a, ray, smp, tn, tf), edge_t(a, ray, smp + 1, tn, tf));
+                key = rb_key(b, c, H, W, D) * kShards + rb_shard((long long)ray * S + smp);
+            }
+            int hl;
+            const int run = rb_run(key, lane, hl);
+            if (run > 0 && key >= 0) {
+                const int slot = (key * 0x9E3779B1u) >> 22;                  // 10 bits
+                const int old = atomicCAS(&tkey[slot], -1, key);
+                if (old == -1 || old == key) atomicAdd(&tcnt[slot], run);
+                else atomicAdd(b.counts + key, run);
+            }
         }
-        int hl;
-        const int run = rb_run(key, lane, hl);
-        if (run > 0 && key >= 0) atomicAdd(b.counts + key, run);
     }
+    __syncthreads();
+    for (int k = threadIdx.x; k < kCountSlots; k += kCountWaves * 64)
+        if (tkey[k] >= 0 && tcnt[k] > 0) atomicAdd(b.counts + tkey[k], tcnt[k]);
 }
 
 // counts -> cursors + items, in two launches of ceil(n_bricks / 1024) blocks: per-block totals, then the scan proper
@@ -922,7 +939,7 @@ int launch_m(const so_render_bwd_args &ba, hipStream_t st) {
     hipError_t e = hipMemsetAsync(ba.scatter_ws, 0, rb_zeroed_bytes(a), st);
     SO_REQUIRE(e == hipSuccess, "render_bwd: hipMemsetAsync failed: %s", hipGetErrorString(e));
     const unsigned sblocks = (unsigned)((rb_bricks(a, nullptr) + 1023) / 1024);
-    hipLaunchKernelGGL(rb_count_kernel, dim3((unsigned)((a.n_rays + 3) / 4)), dim3(256), 0, st, a, bin);
+    hipLaunchKernelGGL(rb_count_kernel, dim3((unsigned)((a.n_rays + kCountWaves - 1) / kCountWaves)), dim3(kCountWaves * 64), 0, st, a, bin);
     hipLaunchKernelGGL(rb_scan1_kernel, dim3(sblocks), dim3(1024), 0, st, bin);
     hipLaunchKernelGGL(rb_scan2_kernel, dim3(sblocks), dim3(1024), 0, st, bin);
     if (int rc = launch_ray<NF, BF16, true>(ba, bin, st)) return rc;

@@ -10,6 +10,7 @@ import torch
 import torch.nn as nn
 
 from ..registry import MODELS
+from ..dropout import dropout_add
 from ..linear import (linear_wgrad, wgrad_supported, linear_fwd, linear_fwd_supported, linear_fwd_heads, linear_dgrad, dgrad_supported,
                       linear_fwd_heads_supported)
 from ..msda import (MultiScaleDeformableAttnFunction, msda_fused_inference, MSDAFusedFunction, to_head_major,
@@ -416,7 +417,12 @@ class FFN(BaseModule):
                 and (x.requires_grad or lin0.weight.requires_grad)):
             h = _TallLinearReLU.apply(x.reshape(rows, x.shape[-1]), lin0.weight, lin0.bias)
             h = self.layers[0][2](h.view(*x.shape[:-1], lin0.weight.shape[0]))
-            out = self.layers[2](self.layers[1](h))
+            out = self.layers[1](h)
+            if FUSED_DROPOUT_ADD and self.add_identity and isinstance(self.dropout_layer, nn.Identity):
+                # the last Dropout and the residual add as one pass (csrc/dropout.hip)
+                drop = self.layers[2]
+                return dropout_add(out, x if identity is None else identity, drop.p, drop.training)
+            out = self.layers[2](out)
         else:
             out = self.layers(x)
         if not self.add_identity:
@@ -428,6 +434,9 @@ class FFN(BaseModule):
 
 # training: the FFN's Linear + ReLU as one autograd node (_TallLinearReLU); env SELFOCC_FUSED_FFN_RELU=0: nn.Sequential
 FUSED_FFN_RELU = os.environ.get('SELFOCC_FUSED_FFN_RELU', '1') == '1'
+# training: `identity + dropout(x)` at the end of every attention / FFN block as one HIP pass per direction with a
+# counter-based mask (selfocc_amd/dropout.py); env SELFOCC_FUSED_DROPOUT=0: torch's dropout + add
+FUSED_DROPOUT_ADD = os.environ.get('SELFOCC_FUSED_DROPOUT', '1') == '1'
 # training path of deformable_sampling: fused prologue + MSDA in both directions (msda.MSDAFusedFunction)
 FUSED_TRAINING = True
 # inference: the sampling_offsets / attention_weights Linears inside the sampling kernel's prologue (csrc/msda_pro.hip)
@@ -604,5 +613,8 @@ class MultiScaleDeformableAttention(BaseModule):
         output = self.output_proj(output)
         if not self.batch_first:
             output = output.permute(1, 0, 2)
-        output = self.dropout(output) + identity
+        if FUSED_DROPOUT_ADD:
+            output = dropout_add(output, identity, self.dropout.p, self.dropout.training)
+        else:
+            output = self.dropout(output) + identity
         return post_norm(output) if post_norm is not None else output

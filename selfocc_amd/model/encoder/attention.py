@@ -153,7 +153,10 @@ class BEVCrossAttention(BaseModule):
         slots.index_add_(1, q_idx, sampled[:, cam_idx, slot])
         slots = slots / count[..., None]
         slots = self.output_proj(slots)
-        slots = self.dropout(slots) + residual
+        if bricks.FUSED_DROPOUT_ADD:
+            slots = bricks.dropout_add(slots, residual, self.dropout.p, self.dropout.training)
+        else:
+            slots = self.dropout(slots) + residual
         post_norm = kwargs.get('post_norm')
         return post_norm(slots) if post_norm is not None else slots
 
@@ -208,7 +211,10 @@ class BEVCrossAttention(BaseModule):
             # straight into the caller's slice of the concatenated plane buffer (`out`)
             return fused_linear(self.output_proj, slots, residual=residual, norm=post_norm, out=out)
         slots = self.output_proj(slots)
-        slots = self.dropout(slots) + residual
+        if bricks.FUSED_DROPOUT_ADD:
+            slots = bricks.dropout_add(slots, residual, self.dropout.p, self.dropout.training)
+        else:
+            slots = self.dropout(slots) + residual
         return post_norm(slots) if post_norm is not None else slots
 
 

@@ -234,3 +234,34 @@ def test_second_differences_hip_vs_torch_expression(hip, shape):
         go = torch.randn(ya.shape, generator=g).to(D0)
         ya.backward(go); yb.backward(go)
         assert torch.allclose(a.grad, b.grad, rtol=1e-5, atol=1e-5)     # <= 9 taps of magnitude ~10 summed in another order
+
+
+@pytest.mark.parametrize("shape,p", [((1, 78899, 96), 0.1), ((3, 1001, 7), 0.5), ((5,), 0.25)])
+def test_dropout_add_hip_statistics_and_gradient(hip, shape, p):
+    """selfocc_dropout_add_fwd / _bwd (the `self.dropout(output) + identity` tail of the attention / FFN blocks): every
+    element of y is identity or identity + x / (1 - p); the kept fraction is 1 - p; the backward applies the SAME mask;
+    the seed follows torch.manual_seed; eval mode / p = 0 are the plain sum."""
+    from selfocc_amd.dropout import dropout_add
+    g = torch.Generator().manual_seed(1)
+    x = (torch.randn(*shape, generator=g) + 3.0).to(D0).requires_grad_(True)        # no zeros: kept <=> y != identity
+    idt = torch.randn(*shape, generator=g).to(D0).requires_grad_(True)
+    torch.manual_seed(5)
+    y = dropout_add(x, idt, p, True)
+    kept = (y.detach() - idt.detach()).abs() > 0
+    assert torch.allclose(y.detach()[kept], (idt + x / (1 - p)).detach()[kept], rtol=1e-6, atol=1e-6)
+    assert torch.equal(y.detach()[~kept], idt.detach()[~kept])
+    n = x.numel()
+    if n > 1000:
+        assert abs(kept.float().mean().item() - (1 - p)) < 4 * (p * (1 - p) / n) ** 0.5 + 1e-3
+        # no structure along rows / columns: per-column keep rates are all close to 1 - p
+        if x.dim() == 3:
+            assert (kept.float().mean((0, 1)) - (1 - p)).abs().max() < 6 * (p * (1 - p) / (n / x.shape[-1])) ** 0.5 + 1e-3
+    w = torch.randn(*shape, generator=g).to(D0)
+    (y * w).sum().backward()
+    assert torch.allclose(idt.grad, w)
+    assert torch.allclose(x.grad, torch.where(kept, w / (1 - p), torch.zeros_like(w)), rtol=1e-6, atol=1e-7)
+    torch.manual_seed(5)
+    assert torch.equal(dropout_add(x, idt, p, True).detach(), y.detach())            # same seed, same mask
+    assert not torch.equal(dropout_add(x, idt, p, True).detach(), y.detach()) or n < 8
+    assert torch.equal(dropout_add(x, idt, p, False).detach(), (x + idt).detach())
+    assert torch.equal(dropout_add(x, idt, 0.0, True).detach(), (x + idt).detach())
