@@ -8,7 +8,7 @@ template <> __device__ double mk<double>(float v) { return (double)v; }
 template <> __device__ unsigned mk<unsigned>(float v) { return (unsigned)(int)(v * 1024.f); }
 template <> __device__ unsigned long long mk<unsigned long long>(float v) { return (unsigned long long)(long long)(v * 1048576.f); }
 
-template <typename T, int ROWW>
+template <typename T, int ROWW, int ACTIVE_ROWS = 64>
 __global__ __launch_bounds__(512) void k(float *out, int iters, unsigned seed, int n_pix) {
     extern __shared__ unsigned char raw[];
     T *tile = (T *)raw;
@@ -21,22 +21,22 @@ __global__ __launch_bounds__(512) void k(float *out, int iters, unsigned seed, i
         rng = rng * 1664525u + 1013904223u;
         const unsigned r = (rng >> 8) * (2 * row + 1) + row * 977u;
         const int pix = r % n_pix;
-        atomicAdd(&tile[pix * ROWW + sub], mk<T>(v));
+        if (row < ACTIVE_ROWS) atomicAdd(&tile[pix * ROWW + sub], mk<T>(v));
     }
     __syncthreads();
     double s = 0;
     for (int e = threadIdx.x; e < n_pix * ROWW; e += 512) s += (double)tile[e];
     if (s == 12345.0) out[0] = (float)s;
 }
-template <typename T, int ROWW>
+template <typename T, int ROWW, int ACTIVE_ROWS = 64>
 void run(const char *name, float *out) {
     const int n_pix = 400, iters = 8192, blocks = 512;
     const size_t shm = (size_t)n_pix * ROWW * sizeof(T);
-    hipFuncSetAttribute((const void *)k<T, ROWW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    hipFuncSetAttribute((const void *)k<T, ROWW, ACTIVE_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
     hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-    hipLaunchKernelGGL((k<T, ROWW>), dim3(blocks), dim3(512), shm, 0, out, 16, 1u, n_pix);
+    hipLaunchKernelGGL((k<T, ROWW, ACTIVE_ROWS>), dim3(blocks), dim3(512), shm, 0, out, 16, 1u, n_pix);
     hipEventRecord(a);
-    hipLaunchKernelGGL((k<T, ROWW>), dim3(blocks), dim3(512), shm, 0, out, iters, 1u, n_pix);
+    hipLaunchKernelGGL((k<T, ROWW, ACTIVE_ROWS>), dim3(blocks), dim3(512), shm, 0, out, iters, 1u, n_pix);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     // 512 blocks x 8 waves on 256 CUs: 16 waves per CU (2 blocks resident if LDS allows), iters instructions each
@@ -53,7 +53,8 @@ int main() {
     run<double, 32>("ds_add_f64", out);
     run<unsigned, 32>("ds_add_u32", out);
     run<unsigned long long, 32>("ds_add_u64", out);
-    run<double, 64>("ds_add_f64", out);
-    run<unsigned long long, 64>("ds_add_u64", out);
+    run<double, 16, 1>("ds_add_f64 1 of 4 rows active", out);
+    run<double, 16, 2>("ds_add_f64 2 of 4 rows active", out);
+    run<double, 16, 3>("ds_add_f64 3 of 4 rows active", out);
     return 0;
 }
