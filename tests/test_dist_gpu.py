@@ -151,8 +151,62 @@ def _enc_worker(rank, ws, port, ret):
             worst = max(worst, e)
             if e > 1e-4:      # float32 sums in a different order (row blocks, all-reduced partial sums)
                 msgs.append(f"grad {k}: {e:.3e} of its scale")
+        # ---- the two switches together: row-sharded encoder -> ray-sharded head -> losses, one training step ----
+        # (the encoder's LAST all-gather passes its gradient through un-reduced: it must arrive complete and identical on
+        # every rank from the head's all-reduced volume gradient)
+        from selfocc_amd.registry import MODELS, OPENOCC_LOSS
+        import selfocc_amd.loss  # noqa: F401
+        import json
+        cfg = json.load(open(os.path.join(tf.G, "encoder_full_cfg.json")))
+        l2i = np.asarray(metas[0]['lidar2img'], dtype=np.float64)
+        metas2 = [dict(metas[0], img2lidar=np.linalg.inv(l2i), temImg2lidar=np.linalg.inv(l2i))]
+        torch.manual_seed(3)
+        head = MODELS.build(dict(type='NeuSHead', roi_aabb=[-40.0, -40.0, -1.0, 40.0, 40.0, 5.4], resolution=1.6, near_plane=0.0,
+                                 far_plane=1e10, num_samples=64, num_samples_importance=0, num_up_sample_steps=0, base_variance=4,
+                                 beta_init=0.1, beta_hand_tune=False, use_numerical_gradients=False, sample_gradient=True,
+                                 return_uniform_sdf=False, return_second_grad=True, use_compact_2nd_grad=True, return_sem=True,
+                                 ray_sample_mode='fixed', ray_number=[7, 10], ray_img_size=[96, 200], trans_kw='temImg2lidar',
+                                 render_bkgd='white', mapping_args=cfg['encoder']['mapping_args'], embed_dims=96, color_dims=8,
+                                 density_layers=2, sh_deg=0, sh_act='relu', two_split=False, tpv=True, single_jitter=True)).to(tf.D0).eval()
+        with torch.no_grad():
+            head.model.field.density_net[-1].bias[0] = 0.5
+        loss_fn = OPENOCC_LOSS.build(dict(type='MultiLoss', sync_items=False, loss_cfgs=[
+            dict(type='EikonalLoss', weight=0.1), dict(type='SecondGradLoss', weight=0.01)]))
+        gcoef = torch.Generator().manual_seed(9)
+        cd = torch.randn(1, 6, 70, generator=gcoef).to(tf.D0)
+        cc = torch.randn(1, 6, 70, 3, generator=gcoef).to(tf.D0)
+
+        def step(shard):
+            enc.row_shard = head.ray_shard = shard
+            os.environ['eval'] = 'false'
+            for p in list(enc.parameters()) + list(lifter.parameters()) + list(head.parameters()):
+                p.grad = None
+            fs = [f.detach().clone().requires_grad_(True) for f in feats]
+            rep = enc(lifter(fs)['representation'], ms_img_feats=fs, metas=metas2)['representation']
+            out = head(rep, metas2, global_iter=0)
+            total, _ = loss_fn(dict(out, metas=metas2))
+            total = total + (out['ms_depths'][0] * cd).mean() + (out['ms_colors'][0] * cc).mean()
+            total.backward()
+            g = {('enc', n): p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}
+            g.update({('lift', n): p.grad.clone() for n, p in lifter.named_parameters() if p.grad is not None})
+            g.update({('head', n): p.grad.clone() for n, p in head.named_parameters() if p.grad is not None})
+            g.update({('feat', str(i)): f.grad.clone() for i, f in enumerate(fs)})
+            return total.detach(), g
+        l0, g0 = step(False)
+        l1, g1 = step(True)
+        if abs(l0.item() - l1.item()) > 1e-4 * abs(l0.item()) + 1e-7:
+            msgs.append(f"combined: loss {l0.item()} vs {l1.item()}")
+        if set(g0) != set(g1):
+            msgs.append(f"combined: gradient sets differ {sorted(set(g0) ^ set(g1))[:5]}")
+        worst2 = 0.0
+        for k in g0:
+            if k in g1:
+                e = (g0[k] - g1[k]).abs().max().item() / max(g0[k].abs().max().item(), 1e-30)
+                worst2 = max(worst2, e)
+                if e > 2e-4:
+                    msgs.append(f"combined grad {k}: {e:.3e} of its scale")
         ret[rank] = msgs
-        ret[f'worst{rank}'] = worst
+        ret[f'worst{rank}'] = (worst, worst2)
     except Exception as e:   # surface the failure in the parent
         import traceback
         ret[rank] = [f"exception: {e!r}\n{traceback.format_exc()}"]
@@ -163,7 +217,8 @@ def _enc_worker(rank, ws, port, ret):
 def test_row_sharded_encoder_equals_unsharded_world2(hip):
     """TPVFormerEncoder(row_shard=True) on two ranks (queries sharded, values replicated, one all-gather
     of the planes per layer): forward planes (inference and training route) and EVERY gradient — parameters, lifter queries,
-    FPN maps — equal the unsharded encoder's on both ranks."""
+    FPN maps — equal the unsharded encoder's on both ranks; then the two switches together (row-sharded encoder -> ray-sharded
+    NeuSHead -> losses): loss and every gradient of one training step equal the unsharded step's."""
     ws = 2
     ctx = mp.get_context("spawn")
     ret = ctx.Manager().dict()
@@ -176,7 +231,7 @@ def test_row_sharded_encoder_equals_unsharded_world2(hip):
         assert p.exitcode == 0
     for r in range(ws):
         assert ret.get(r) == [], f"rank {r}: {ret.get(r)}"
-    print("worst relative gradient difference", [ret.get(f'worst{r}') for r in range(ws)])
+    print("worst relative gradient difference (encoder alone, encoder + ray-sharded head + losses)", [ret.get(f'worst{r}') for r in range(ws)])
 
 
 @pytest.mark.parametrize("shard", ["frames", "rays"])
