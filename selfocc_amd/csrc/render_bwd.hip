@@ -94,8 +94,8 @@ SO_DEVFN void load_feat(const void *vol, size_t vox, float f[NF > 0 ? NF : 1]) {
 // ---- brick-binned scatter (so_render_bwd_args::scatter_ws) -----------------------------------------------
 // The volume is cut into bricks of kBH x kBW x kBD CELLS; the voxels a brick's samples touch are the
 // (kBH + 1)(kBW + 1)(kBD + 1) tile that shares its upper faces with the neighbouring bricks.
-//   rb_count_kernel   one thread per sample: the sample's cell (same code as the ray kernel) -> its brick; counts the
-//                     samples per (brick, shard), one integer atomic per run of consecutive samples with one counter
+//   rb_count_kernel   one wave per ray: every sample's cell (same code as the ray kernel) -> its brick; counts the samples
+//                     per (brick, shard): runs of consecutive samples with one counter, summed per 16-ray block in LDS first
 //   rb_scan1 / scan2  counts -> slot cursors per (brick, shard) and a list of work items (brick, <= chunk samples)
 //   render_bwd_kernel<.., BIN = true>  takes the slots of its runs (one returning atomic per run, issued early) and
 //                     writes ONE RECORD PER SAMPLE AT ITS SLOT, i.e. in brick order.  A record is RECF floats:
@@ -106,16 +106,15 @@ SO_DEVFN void load_feat(const void *vol, size_t vox, float f[NF > 0 ? NF : 1]) {
 //                         [RECF - 3 .. -1]  qx, qy, qz        (coefficients of the weights' axis derivatives)
 //   rb_brick_kernel   one workgroup per item: streams the item's records, sums them into the brick's tile in LDS and
 //                     adds the tile's non-zero rows to the gradient volumes: (items x touched rows) row atomics instead
-//                     of (sample runs x 8).  The tile is DOUBLE: ds_add_f64 issues in ~10 clocks per 64-lane
-//                     instruction on gfx950, ds_add_f32 in ~3 clocks per LANE (measured again here:
-//                     7.7 ms with a float tile).
+//                     of (sample runs x 8).  The tile is DOUBLE: ds_add_f64 issues in ~15 clocks per 64-lane
+//                     instruction on gfx950, ds_add_f32 in ~190 (scripts/micro/lds_atomic_types.hip; the first version
+//                     of this kernel, with a float tile, took 7.7 ms).
 constexpr int kBH = 4, kBW = 4, kBD = 8;
 constexpr int kTH = kBH + 1, kTW = kBW + 1, kTD = kBD + 1;
 constexpr int kTileVox = kTH * kTW * kTD;   // 225
 constexpr int kInvsSlots = 1024;
 constexpr int kShards = 32;  // counters per brick (shard = bits 8.. of the sample index): the bricks around the cameras
-                             // are entered by every ray, and same-address device atomics serialise (8 shards: the counting
-                             // pass took 0.24 ms for 0.6 M atomics)
+                             // are entered by every ray, and same-address device atomics serialise
 SO_DEVFN int rb_shard(long long sample) { return (int)(sample >> 8) & (kShards - 1); }
 
 template <int NF>
@@ -615,8 +614,9 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba, 
 // one wave per ray (the ray's geometry once per lane, then S / 64 steps of 64 consecutive samples), 16 rays per block.
 // Neighbouring rays cross the same bricks, and every ray starts in the bricks around the cameras: the block first sums its
 // runs in a small LDS table (direct-mapped on the counter index; a collision goes to memory directly) and adds each
-// occupied slot to the global counter once — same-address device atomics serialise, and the hottest counters were hit by
-// every wave of the launch (0.24 ms with one atomic per run and 8 shards, 0.16 ms with 32 shards).
+// occupied slot to the global counter once.  (0.24 ms with one atomic per run and 8 shards, 0.16 - 0.22 ms with 32 shards,
+// with or without the table: what is left is the ~30 IEEE divisions per sample of the canonical cell, which the pass must
+// repeat exactly.)
 constexpr int kCountWaves = 16, kCountSlots = 1024;
 __global__ __launch_bounds__(kCountWaves * 64) void rb_count_kernel(so_render_args a, RbBin b) {
     __shared__ int tkey[kCountSlots], tcnt[kCountSlots];
