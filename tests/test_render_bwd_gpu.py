@@ -151,3 +151,42 @@ def test_render_backward_binned_vs_atomic_bf16_features(hip, n_sem, S):
     # the feature gradient is handed back in the volume's storage dtype (bfloat16): one rounding of nearly equal float32 sums
     assert _rel_l2(b[1].double(), a[1].double()) < 1e-2 and (b[1] - a[1]).abs().max() <= 2e-2 * a[1].abs().max()
     assert abs(b[2].item() - a[2].item()) <= 1e-3 * abs(a[2].item()) + 1e-6
+
+
+def test_render_backward_rejects_a_short_or_misaligned_scatter_workspace(hip):
+    """C ABI error behaviour of the optional scratch: selfocc_render_bwd refuses a workspace smaller than
+    selfocc_render_bwd_ws_bytes() or not 256-byte aligned with an argument error (rc < 0, text in selfocc_last_error),
+    launches nothing, and the same arguments with scatter_ws = NULL run the atomic path."""
+    from selfocc_amd._lib import lib, ptr, current_stream
+    from selfocc_amd.render import marshal_render_args
+    vol = sy.make_volume("cfg1", n_rgb=3, n_sem=5, seed=2).to(D0)
+    ex = sy.explicit_rays(sy.make_rays("cfg1", seed=2))
+    rg = RaySet(origins=ex.origins.to(D0), dirs=ex.dirs.to(D0), dir_norm=ex.dir_norm.to(D0))
+    cfg = sy.make_render_config("cfg1")
+    a, _out, _keep = marshal_render_args(vol, rg, cfg, outputs={})
+    ba = abi.SoRenderBwdArgs()
+    ba.fwd = a
+    g_depth = torch.ones(rg.n_rays, device=D0)
+    g_sdf_vol, g_feat = torch.zeros_like(vol.sdf), torch.zeros_like(vol.feat)
+    g_inv_s = torch.zeros(1, device=D0)
+    ba.g_depth, ba.g_sdf_vol, ba.g_feat_vol, ba.g_inv_s = ptr(g_depth), ptr(g_sdf_vol), ptr(g_feat), ptr(g_inv_s)
+    need = int(lib().selfocc_render_bwd_ws_bytes(ba))
+    assert need >= rg.n_rays * cfg.n_samples * 64 and need % 256 == 0           # 8 channels: 64-byte records
+    ws = torch.empty(need + 512, dtype=torch.uint8, device=D0)
+    st = current_stream(D0)
+    ba.scatter_ws, ba.scatter_ws_bytes = ptr(ws), need - 256
+    assert lib().selfocc_render_bwd(ba, st) < 0 and b"scatter_ws holds" in lib().selfocc_last_error()
+    ba.scatter_ws, ba.scatter_ws_bytes = ptr(ws[16:]), need
+    assert lib().selfocc_render_bwd(ba, st) < 0 and b"256-byte aligned" in lib().selfocc_last_error()
+    torch.cuda.synchronize()
+    assert g_sdf_vol.abs().max() == 0 and g_feat.abs().max() == 0                # nothing was launched
+    ba.scatter_ws, ba.scatter_ws_bytes = ptr(ws), need
+    assert lib().selfocc_render_bwd(ba, st) == 0
+    torch.cuda.synchronize()
+    binned = (g_sdf_vol.clone(), g_feat.clone())
+    g_sdf_vol.zero_(); g_feat.zero_(); g_inv_s.zero_()
+    ba.scatter_ws, ba.scatter_ws_bytes = None, 0
+    assert lib().selfocc_render_bwd(ba, st) == 0
+    torch.cuda.synchronize()
+    assert g_sdf_vol.abs().max() > 0
+    assert _rel_l2(binned[0].double(), g_sdf_vol.double()) < 1e-5 and _rel_l2(binned[1].double(), g_feat.double()) < 1e-5
