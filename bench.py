@@ -400,6 +400,9 @@ def main():
             roofline_bwd[name] = {"kernels": sorted(ks), "alg_MB": round(alg[name] / 1e6, 1), "write_MB": round(w / 1e6, 1),
                                   "fetch_MB": round(f / 1e6, 1), "write_over_alg": round(w / alg[name], 2),
                                   "us_per_launch": round(us, 1)}
+            if len(ks) > 1:      # which kernel writes what (render_bwd: the brick kernel's writes ARE the gradient, the ray
+                # kernel's are the per-sample records it hands over)
+                roofline_bwd[name]["write_MB_by_kernel"] = {k.split("<")[0]: round(v["write_kb"] * 1024 / 1e6, 1) for k, v in ks.items()}
 
     strong = None
     if world > 1 and not split:
