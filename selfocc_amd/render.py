@@ -122,7 +122,8 @@ class RenderConfig:
     ray_per_lane: bool = False        # per-sample launches through the ray-per-lane kernels (A/B; default: sample-parallel)
     bwd_scatter: str = 'auto'         # backward: 'binned' = brick-binned LDS scatter of the volume gradients (needs a scratch
                                       # of ~(record + 8) bytes per sample), 'atomic' = per-sample row atomics, 'auto' = binned
-                                      # from 2^18 samples per launch (SELFOCC_RB_SCATTER overrides 'auto')
+                                      # from 2^19 samples per launch — measured cross-over 0.4 - 0.5 M samples at 25 channels, scripts/time_render_bwd_sizes.py
+                                      # (SELFOCC_RB_SCATTER overrides 'auto')
 
 
 def _c(t, dtype=torch.float32):
@@ -312,7 +313,7 @@ class _RenderFunction(torch.autograd.Function):
         g_inv_s = torch.zeros(1, device=vol.sdf.device)
         ba.g_inv_s = ptr(g_inv_s)
         mode = cfg.bwd_scatter if cfg.bwd_scatter != 'auto' else os.environ.get('SELFOCC_RB_SCATTER', 'auto')
-        if mode == 'binned' or (mode == 'auto' and rays.n_rays * cfg.n_samples >= (1 << 18)):
+        if mode == 'binned' or (mode == 'auto' and rays.n_rays * cfg.n_samples >= (1 << 19)):
             need = int(lib().selfocc_render_bwd_ws_bytes(ba))
             if need > 0:
                 ws = _scatter_workspace(vol.sdf.device, need)
