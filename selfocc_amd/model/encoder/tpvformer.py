@@ -263,6 +263,7 @@ class BEVFormerLayer(_FormerLayerBase):
                 level_start_index=None, reference_points_cams=None, bev_masks=None, bev_size=None, **kwargs):
         norm_i = attn_i = ffn_i = 0
         identity = query
+        self_value = kwargs.pop('self_attn_value', None)   # row-sharded encoder: `query` = this rank's rows, the self-attention samples ALL rows
         # inference, post-norm layers: a `norm` that follows an attention / ffn step rides in that step's last
         # projection (selfocc_linear_fwd), as in TPVFormerLayer
         fuse_norm = not torch.is_grad_enabled() and not self.training and not self.pre_norm and query.is_cuda
@@ -275,7 +276,8 @@ class BEVFormerLayer(_FormerLayerBase):
                 skip_norm = True
             if op == 'self_attn':
                 ss, lsi = _level_shapes((tuple(int(v) for v in bev_size),), query.device)   # cached: no upload per call
-                query = self.attentions[attn_i](query, query, query, identity if self.pre_norm else None,
+                sv = query if self_value is None else self_value
+                query = self.attentions[attn_i](query, sv, sv, identity if self.pre_norm else None,
                                                 query_pos=bev_pos, reference_points=ref_2d, spatial_shapes=ss,
                                                 level_start_index=lsi, post_norm=post_norm, **kwargs)
                 attn_i += 1
@@ -313,6 +315,23 @@ class _EncoderBase(BaseModule):
         self.pre_norm = self.layers[0].pre_norm
         self.level_embeds = nn.Parameter(torch.randn(self.num_feature_levels, self.embed_dims))
         self.cams_embeds = nn.Parameter(torch.randn(self.num_cams, self.embed_dims))
+
+    row_shard = False
+
+    def _row_sharding(self):
+        """True when this call splits the plane rows over the ranks: ``row_shard=True`` (or SELFOCC_ENC_SHARD=1) and an
+        initialised process group with world_size > 1.  Like NeuSHead(ray_shard=True) it assumes that every rank holds
+        the SAME frame (one frame's work split over the ranks; DESIGN section 6)."""
+        import torch.distributed as tdist
+        on = self.row_shard or os.environ.get('SELFOCC_ENC_SHARD', '0') == '1'
+        return bool(on and tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1)
+
+    def _row_shard_plan_for(self, sizes):
+        from ... import dist as sdist
+        shard = getattr(self, '_row_shard_plan', None)
+        if shard is None or shard.sizes != list(sizes) or (shard.rank, shard.world_size) != sdist.world():
+            shard = self._row_shard_plan = sdist.PlaneRowShard(list(sizes))
+        return shard
 
     def init_weights(self):
         for p in self.parameters():
@@ -483,14 +502,6 @@ class TPVFormerEncoder(_EncoderBase):
             self.register_buffer(name, g2m(g).flatten(0, 1).transpose(0, 1).contiguous(), False)   # (D, Q, 3) as point_sampling reads it
         self.register_buffer('cross_view_ref_points', get_cross_view_ref_points(H, W, Z, num_points_self), False)
 
-    def _row_sharding(self):
-        """True when this call splits the plane rows over the ranks: ``row_shard=True`` (or SELFOCC_ENC_SHARD=1) and an
-        initialised process group with world_size > 1.  Like NeuSHead(ray_shard=True) it assumes that every rank holds
-        the SAME frame (one frame's work split over the ranks; DESIGN section 6)."""
-        import torch.distributed as tdist
-        on = self.row_shard or os.environ.get('SELFOCC_ENC_SHARD', '0') == '1'
-        return bool(on and tdist.is_available() and tdist.is_initialized() and tdist.get_world_size() > 1)
-
     def _forward_layers_sharded(self, tpv_query, key, value, tpv_pos, tpv_pos_cat, spatial_shapes, level_start_index,
                                 reference_points_cams, tpv_masks, ref_cross_view, **kwargs):
         """every rank owns a row block of each plane.  Per layer: cross-view self-attention of the local
@@ -503,9 +514,7 @@ class TPVFormerEncoder(_EncoderBase):
         from torch.func import functional_call
         H, W, Z = self.tpv_size
         sizes = [H * W, Z * H, W * Z]
-        shard = getattr(self, '_row_shard_plan', None)
-        if shard is None or shard.sizes != sizes or (shard.rank, shard.world_size) != sdist.world():
-            shard = self._row_shard_plan = sdist.PlaneRowShard(sizes)
+        shard = self._row_shard_plan_for(sizes)
         grad = torch.is_grad_enabled()
         q_full = _as_cat(tpv_query)
         if grad:
@@ -571,8 +580,10 @@ class TPVFormerEncoder(_EncoderBase):
 @MODELS.register_module()
 class BEVFormerEncoder(_EncoderBase):
     def __init__(self, mapping_args, embed_dims=128, num_cams=6, num_feature_levels=4, positional_encoding=None,
-                 num_points_cross=32, num_points_self=16, transformerlayers=None, num_layers=None, init_cfg=None):
+                 num_points_cross=32, num_points_self=16, transformerlayers=None, num_layers=None, init_cfg=None,
+                 row_shard=False):
         super().__init__(init_cfg)
+        self.row_shard = row_shard          # split the BEV rows over the ranks (one frame on all ranks; dist.PlaneRowShard)
         self.embed_dims, self.num_feature_levels, self.num_cams = embed_dims, num_feature_levels, num_cams
         self.mapping = GridMeterMapping(**mapping_args)
         H, W, Z = self.mapping.size_h, self.mapping.size_w, self.mapping.size_d
@@ -592,11 +603,42 @@ class BEVFormerEncoder(_EncoderBase):
         normed[..., 1] = normed[..., 1] / (W - 1)
         self.register_buffer('ref_2d', normed, False)
 
+    def _forward_layers_sharded(self, bev_query, key, value, bev_pos, spatial_shapes, level_start_index, cam, mask, ref_2d):
+        """Row blocks of the ONE BEV plane per rank (see TPVFormerEncoder._forward_layers_sharded): self-attention of the
+        local rows over the full replicated plane, image cross-attention / norms / FFN on the local rows, one all-gather
+        per layer; gradients of the unsharded encoder on every rank."""
+        from ... import dist as sdist
+        from torch.func import functional_call
+        shard = self._row_shard_plan_for([self.bev_size[0] * self.bev_size[1]])
+        grad = torch.is_grad_enabled()
+        q_full = bev_query
+        if grad:
+            q_full = sdist.replicate_grad_sum(q_full)
+            key = value = sdist.replicate_grad_sum(value)
+            bev_pos = sdist.replicate_grad_sum(bev_pos)
+        pos_loc, ref_loc = shard.take(bev_pos, 1), shard.take(ref_2d, 1)
+        cam_loc, mask_loc = shard.take_plane(cam, 0, 2), shard.take_plane(mask, 0, 2)
+        last = len(self.layers) - 1
+        for li, layer in enumerate(self.layers):
+            call = dict(bev_pos=pos_loc, ref_2d=ref_loc, spatial_shapes=spatial_shapes, level_start_index=level_start_index,
+                        reference_points_cams=cam_loc, bev_masks=mask_loc, bev_size=self.bev_size, rebatch_plan=None,
+                        self_attn_value=q_full)
+            q_loc = shard.take(q_full, 1)
+            if grad:
+                names, ps = zip(*layer.named_parameters())
+                out = functional_call(layer, dict(zip(names, sdist.group_grad_sum(ps))), (q_loc, key, value), call)
+            else:
+                out = layer(q_loc, key, value, **call)
+            q_full = sdist.gather_plane_rows(out, shard, reduce_grad=li < last)
+        return q_full
+
     def forward_layers(self, bev_query, key, value, bev_pos=None, spatial_shapes=None, level_start_index=None,
                        img_metas=None, **kwargs):
         bs = bev_query.shape[0]
         cam, mask = point_sampling(self.ref_3d.unsqueeze(0).expand(bs, -1, -1, -1), img_metas)   # read-only
         ref_2d = self.ref_2d.unsqueeze(0).expand(bs, -1, -1, -1).reshape(bs, -1, 1, 2)
+        if self._row_sharding():
+            return self._forward_layers_sharded(bev_query, key, value, bev_pos, spatial_shapes, level_start_index, cam, mask, ref_2d)
         plan = None   # see TPVFormerEncoder.forward_layers
         for layer in self.layers:
             bev_query = layer(bev_query, key, value, bev_pos=bev_pos, ref_2d=ref_2d, spatial_shapes=spatial_shapes,

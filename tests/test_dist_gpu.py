@@ -214,6 +214,86 @@ def _enc_worker(rank, ws, port, ret):
         dist.destroy_process_group()
 
 
+def _bev_worker(rank, ws, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        import copy, json
+        from selfocc_amd.registry import MODELS
+        import selfocc_amd.model  # noqa: F401
+        G = os.path.join(os.path.dirname(__file__), "golden")
+        D0 = torch.device("cuda:0")
+        z = np.load(os.path.join(G, "bev_encoder.npz"))
+        cfg = json.load(open(os.path.join(G, "bev_encoder_cfg.json")))
+        enc = MODELS.build(dict(type='BEVFormerEncoder', **copy.deepcopy(cfg['encoder'])))
+        lifter = MODELS.build(dict(type='BEVQueryLifter', **cfg['lifter']))
+        enc.load_state_dict({k[4:]: torch.tensor(v) for k, v in z.items() if k.startswith('enc.')}, strict=True)
+        lifter.load_state_dict({k[5:]: torch.tensor(v) for k, v in z.items() if k.startswith('lift.')}, strict=True)
+        enc, lifter = enc.to(D0).eval(), lifter.to(D0).eval()
+        metas = [dict(lidar2img=z['lidar2img'], img_shape=tuple(cfg['img_shape']))]
+        coef = None
+        msgs = []
+
+        def step(shard):
+            nonlocal coef
+            enc.row_shard = shard
+            for p in list(enc.parameters()) + list(lifter.parameters()):
+                p.grad = None
+            fs = [torch.tensor(z['feat0']).to(D0).requires_grad_(True), torch.tensor(z['feat1']).to(D0).requires_grad_(True)]
+            with torch.no_grad():
+                inf = enc(lifter(fs)['representation'], ms_img_feats=fs, metas=metas)['representation'].clone()
+            out = enc(lifter(fs)['representation'], ms_img_feats=fs, metas=metas)['representation']
+            if coef is None:
+                coef = torch.randn(out.shape, generator=torch.Generator().manual_seed(4)).to(D0)
+            (out * coef).mean().backward()
+            g = {('enc', n): p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}
+            g.update({('lift', n): p.grad.clone() for n, p in lifter.named_parameters() if p.grad is not None})
+            g.update({('feat', str(i)): f.grad.clone() for i, f in enumerate(fs)})
+            return inf, out.detach(), g
+        i0, o0, g0 = step(False)
+        i1, o1, g1 = step(True)
+        if enc._row_shard_plan.n_local >= sum(enc._row_shard_plan.sizes):
+            msgs.append("no sharding happened")
+        for nm, a, b in (("inference", i0, i1), ("train forward", o0, o1)):
+            if (a - b).abs().max().item() > 1e-5 * max(1.0, a.abs().max().item()):
+                msgs.append(f"{nm}: max diff {(a - b).abs().max().item():.3e}")
+        if set(g0) != set(g1):
+            msgs.append(f"gradient sets differ: {sorted(set(g0) ^ set(g1))[:5]}")
+        worst = 0.0
+        for k in g0:
+            if k in g1:
+                e = (g0[k] - g1[k]).abs().max().item() / max(g0[k].abs().max().item(), 1e-30)
+                worst = max(worst, e)
+                if e > 1e-4:
+                    msgs.append(f"grad {k}: {e:.3e} of its scale")
+        ret[rank] = msgs
+        ret[f'worst{rank}'] = worst
+    except Exception as e:   # surface the failure in the parent
+        import traceback
+        ret[rank] = [f"exception: {e!r}\n{traceback.format_exc()}"]
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_sharded_bev_encoder_equals_unsharded_world2(hip):
+    """BEVFormerEncoder(row_shard=True) on two ranks (the reference's own state dict, tests/golden/bev_encoder.npz): forward
+    (inference and training route) and every gradient equal the unsharded encoder's."""
+    ws = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_bev_worker, args=(r, ws, port, ret)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    for r in range(ws):
+        assert ret.get(r) == [], f"rank {r}: {ret.get(r)}"
+    print("worst relative gradient difference (BEV)", [ret.get(f'worst{r}') for r in range(ws)])
+
+
 def test_row_sharded_encoder_equals_unsharded_world2(hip):
     """TPVFormerEncoder(row_shard=True) on two ranks (queries sharded, values replicated, one all-gather
     of the planes per layer): forward planes (inference and training route) and EVERY gradient — parameters, lifter queries,
