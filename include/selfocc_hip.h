@@ -176,18 +176,21 @@ typedef struct so_render_bwd_args {
     /* Optional scratch for the BRICK-BINNED volume-gradient scatter (round 4).  NULL: every sample adds its
      * 8 corner rows to g_sdf_vol / g_feat_vol with device-scope float atomics (on MI355X each one is a write
      * through the fabric: 3.1 GB of them for a 165 MB gradient at the nuscenes_occ training shape).  Given
-     * (>= selfocc_render_bwd_ws_bytes() bytes, 256-B aligned): the ray kernel writes one record per sample
-     * (cell, fractions, d L / d feature row, SDF coefficients) and a brick key (8 x 8 x 8 cells); a counting
-     * sort groups the samples by brick; one workgroup per (brick, <= chunk samples) sums them into a
-     * 9 x 9 x 9-voxel tile in LDS (ds_add_f32) and adds the tile's non-zero rows to the gradient once.
-     * Same sums, different (still unspecified) float addition order.                                       */
+     * (>= selfocc_render_bwd_ws_bytes() bytes, 256-B aligned): a counting pre-pass gives every sample a slot in
+     * brick order (bricks of 4 x 4 x 8 CELLS); the ray kernel writes one record per sample at its slot (cell,
+     * fractions, d L / d feature row, SDF coefficients: 32 / 64 / 128 B at 0 / 3-8 / 20-24 channels); one
+     * workgroup per (brick, <= chunk samples) streams its records, sums them into the brick's 5 x 5 x 9-voxel
+     * tile in LDS — a DOUBLE tile: ds_add_f64 issues ~12 x faster than ds_add_f32 on gfx950 — and adds the
+     * tile's non-zero rows to the gradient once.  A sample whose cell lies outside the volume contributes
+     * nothing in either mode.  Same sums, different (still unspecified) float addition order.              */
     void *scatter_ws;
     uint64_t scatter_ws_bytes;
 } so_render_bwd_args;
 
 int selfocc_render_bwd(const so_render_bwd_args *args, void *stream);
-/* bytes of so_render_bwd_args::scatter_ws for this call (0: the shape is outside the binned path's range,
- * i.e. an axis longer than 1022 grid points; pass NULL then) */
+/* bytes of so_render_bwd_args::scatter_ws for this call.  0 = the call is outside the binned path's range — pass
+ * NULL then (the atomic path runs): args == NULL, n_rays <= 0 or n_samples <= 0, an axis longer than 1021 grid
+ * points, n_rays * n_samples >= 2^31, or a channel count other than 0 / 3 / 8 / 20 / 24. */
 size_t selfocc_render_bwd_ws_bytes(const so_render_bwd_args *args);
 
 /* ------------------------------------------------------------------------------------

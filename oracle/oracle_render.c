@@ -24,6 +24,10 @@
  *     430-438, 571-587);
  *   - rays: RaySampler lattice + Img2LiDAR (nerfacc_head/ray_sampler.py:23-68,
  *     img2lidar.py:58-69).
+ * Declared omission: upstream's expected-depth renderer clips the depth to the smallest /
+ * largest sample mid-point of the whole CALL (a chunk-dependent value that only changes rays
+ * with sum(w) ~ 0); this restatement, the torch port and the kernels do not (README
+ * "Deviations").
  * The trilinear lookup itself IS pinned: tests compare it bit-for-bit with
  * torch.nn.functional.grid_sample (the op the reference calls).
  *

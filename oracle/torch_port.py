@@ -289,7 +289,8 @@ def render_port_differentiable(mapping, vol_chw, n_rgb, n_sem, o, d, dn, cfg, in
     depth = (weights * mids).sum(-1) / (acc + 1e-10)
     if cfg.depth_div_norm:
         depth = depth / dn
-    out = dict(depth=depth, acc=acc, weights=weights, sdf=sdf, grad=grad)
+    out = dict(depth=depth, acc=acc, weights=weights, sdf=sdf, grad=grad, nears=nears[:, 0], fars=fars[:, 0],
+               starts=starts, ends=ends)
     if n_rgb:
         col = sh0_color(h[:, 1:1 + n_rgb]).reshape(-1, S, 3)
         rgb = (weights[..., None] * col).sum(-2)

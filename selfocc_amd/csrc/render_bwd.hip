@@ -101,7 +101,7 @@ SO_DEVFN void load_feat(const void *vol, size_t vox, float f[NF > 0 ? NF : 1]) {
 //                     writes ONE RECORD PER SAMPLE AT ITS SLOT, i.e. in brick order.  A record is RECF floats:
 //                         [0 .. NCH)        d L / d (interpolated feature channel)
 //                         [RECF - 8]        ds                (coefficient of the trilinear weights in d L / d sdf corner)
-//                         [RECF - 7]        packed cell       ((h0 + 1) << 20 | (w0 + 1) << 10 | (d0 + 1), as bits)
+//                         [RECF - 7]        packed cell       ((h0 + 2) << 20 | (w0 + 2) << 10 | (d0 + 2), as bits; indices clamped to [-2, 1021])
 //                         [RECF - 6 .. -4]  fh1, fw1, fd1     (fractions inside the cell)
 //                         [RECF - 3 .. -1]  qx, qy, qz        (coefficients of the weights' axis derivatives)
 //   rb_brick_kernel   one workgroup per item: streams the item's records, sums them into the brick's tile in LDS and
@@ -565,8 +565,11 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba, 
             const so_cell &c = cell[j];
             const int slot = __shfl(slot_base[j], slot_head[j], 64) + (lane - slot_head[j]);
             if (live[j]) {
-                const int pack = ((min(max(c.h0, -1), 1022) + 1) << 20) | ((min(max(c.w0, -1), 1022) + 1) << 10) |
-                                 (min(max(c.d0, -1), 1022) + 1);
+                // so_locate does not clamp: a sample outside the box (a ray that misses it, near_plane past the exit, an
+                // aabb larger than the mapping) has h0 <= -2 or h0 >= H.  The clamp keeps such an index OUTSIDE the volume
+                // (-2 and 1021 >= tot_len fail every corner test of rb_brick_kernel), as the atomic path's `in` test does.
+                const int pack = ((min(max(c.h0, -2), 1021) + 2) << 20) | ((min(max(c.w0, -2), 1021) + 2) << 10) |
+                                 (min(max(c.d0, -2), 1021) + 2);
                 float4 *dst = (float4 *)(bin.rec + (size_t)slot * RECF + (RECF - 8));
                 dst[0] = make_float4(r_ds, __int_as_float(pack), c.fh1, c.fw1);
                 dst[1] = make_float4(c.fd1, r_qx, r_qy, r_qz);
@@ -761,7 +764,7 @@ __global__ __launch_bounds__(NT) void rb_brick_kernel(RbBin b, float *__restrict
 #pragma unroll
     for (int k = 0; k < 8; ++k) acc[k] = 0.0f;
     auto flush = [&]() {
-        const int h0 = (cur >> 20) - 1, w0 = ((cur >> 10) & 1023) - 1, d0 = (cur & 1023) - 1;
+        const int h0 = (cur >> 20) - 2, w0 = ((cur >> 10) & 1023) - 2, d0 = (cur & 1023) - 2;
         const int lh = h0 - oh, lw = w0 - ow, ld = d0 - od;
         // a corner counts when it is inside the volume AND inside this brick's tile (the second never fails: the
         // counting pass and the ray kernel derive the cell with the same code; it only keeps a mismatch inside the tile)
@@ -900,7 +903,7 @@ inline int rb_chunk() { static const int c = max(256, rb_env_int("SELFOCC_RB_CHU
 inline int rb_threads() { static const int t = rb_env_int("SELFOCC_RB_THREADS", 512); return t; }
 
 inline bool rb_in_range(const so_render_args &a) {
-    return a.map.h.tot_len <= 1022 && a.map.w.tot_len <= 1022 && a.map.d.tot_len <= 1022 &&
+    return a.map.h.tot_len <= 1021 && a.map.w.tot_len <= 1021 && a.map.d.tot_len <= 1021 &&
            (size_t)a.n_rays * a.n_samples < ((size_t)1 << 31);
 }
 

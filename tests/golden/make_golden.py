@@ -742,9 +742,19 @@ def install_nerfstudio_stubs():
                 DRAWS['t_rand'] = t_rand
             if bkr is not None:
                 DRAWS.setdefault('bkgd', []).append(bkr)
-            with torch.no_grad():
-                r = tp.render_port(f.mapping, f.net.density_color.detach(), f.n_rgb, f.n_sem if c.return_sem else 0, o, d, dn, rc,
-                                   t_rand=t_rand, bkgd_rays=bkr, return_samples=True)
+            if getattr(self, 'differentiable', False):
+                # golden_train_step: the same restatement with every op differentiable w.r.t. the volume and inv_s
+                # (float64 inside; the dict goes back to float32, the dtype the real head and losses compute in)
+                dd = torch.float64
+                r = tp.render_port_differentiable(
+                    f.mapping, f.net.density_color[0].to(dd), f.n_rgb, f.n_sem if c.return_sem else 0, o.to(dd), d.to(dd),
+                    dn.to(dd), rc, f.inv_s().to(dd), t_rand=None if t_rand is None else t_rand.to(dd),
+                    bkgd_rays=None if bkr is None else bkr.to(dd))
+                r = {k: v.float() for k, v in r.items()}
+            else:
+                with torch.no_grad():
+                    r = tp.render_port(f.mapping, f.net.density_color.detach(), f.n_rgb, f.n_sem if c.return_sem else 0, o, d, dn,
+                                       rc, t_rand=t_rand, bkgd_rays=bkr, return_samples=True)
             g = r['grad']
             normal = (r['weights'][..., None] * (g / g.norm(dim=-1, keepdim=True).clamp_min(1e-12))).sum(1)
             out = {'rgb': r['rgb'] if 'rgb' in r else o.new_zeros(N, 0), 'accumulation': r['acc'][:, None],
@@ -792,29 +802,60 @@ def _flatten_out(prefix, d, arrs):
             arrs[f'{prefix}.{k}'] = v.detach().cpu().numpy()
 
 
+def _cams(n, seed, img=(64, 64), f=60.0):
+    rng = np.random.RandomState(seed)
+    Kinv = np.linalg.inv(np.array([[f, 0, img[1] / 2, 0], [0, f, img[0] / 2, 0], [0, 0, 1, 0], [0, 0, 0, 1]]))
+    out = []
+    for i in range(n):
+        yaw = 0.4 + 2 * np.pi * i / n + 0.1 * rng.randn()
+        c2w = np.eye(4)
+        c2w[:3, :3] = np.array([[np.sin(yaw), 0, np.cos(yaw)], [-np.cos(yaw), 0, np.sin(yaw)], [0, -1, 0]])
+        c2w[:3, 3] = [0.6 * rng.randn(), 0.6 * rng.randn(), 0.4 + 0.2 * rng.randn()]
+        out.append(c2w @ Kinv)
+    return np.stack(out)
+
+
+
+# the SHIPPED head of config/nuscenes/nuscenes_occ.py:303-352, key for key: 256 samples, 6 cameras, color_dims 24
+# (rgb + 21 semantic logits), cellular lattice on the 768 x 1600 image, random background, learnable beta 0.1,
+# the 80 m x 80 m x 6.4 m box.  Reduced for a CPU fixture: the TPV grid (65 x 65 x 13 instead of 257 x 257 x 25)
+# the lattice (6 x 10 rays per camera instead of 48 x 100) and the dense-query resolution (1.6 m instead of 0.4);
+# `use_compact_2nd_grad=True` because the fork's non-compact form is not on disk (README).
+# Saved to its own file (head_occ.npz): training forward, prepare + render, forward_occ.
+OCC_HEAD_CFG = dict(
+    roi_aabb=[-40.0, -40.0, -1.0, 40.0, 40.0, 5.4], resolution=1.6, near_plane=0.0, far_plane=1e10, num_samples=256, num_samples_importance=0, num_up_sample_steps=0, base_variance=4, beta_init=0.1,
+            beta_max=0.195, total_iters=3516 * 11, beta_hand_tune=False, use_numerical_gradients=False,
+            sample_gradient=True, return_uniform_sdf=False, return_second_grad=True, use_compact_2nd_grad=True,
+            return_sem=True, return_sample_sdf=False, ray_sample_mode='cellular', ray_number=[6, 10],
+            ray_img_size=[768, 1600], ray_upper_crop=0, trans_kw='temImg2lidar', novel_view=None,
+            render_bkgd='random',
+            mapping_args=dict(nonlinear_mode='linear', h_size=[32, 0], h_range=[40.0, 0], h_half=False,
+                              w_size=[32, 0], w_range=[40.0, 0], w_half=False, d_size=[12, 0], d_range=[-1.0, 5.4, 5.4]),
+            embed_dims=96, color_dims=24, density_layers=2, sh_deg=0, sh_act='relu', two_split=False, tpv=True)
+
+
+_HEAD_ENV = []
+
+
+def _head_env():
+    """(the reference's neus_head module, the stand-ins' record of random draws); stubs installed once per process"""
+    if not _HEAD_ENV:
+        if 'dataset' not in sys.modules:
+            ds = types.ModuleType('dataset'); ds.__path__ = [os.path.join(REF, 'dataset')]; sys.modules['dataset'] = ds
+        namespace('model.head.neus_head')
+        draws = install_nerfstudio_stubs()
+        ref_import('model.head.base_head')
+        _HEAD_ENV.extend([ref_import('model.head.neus_head.neus_head'), draws])
+    return _HEAD_ENV
+
+
 def golden_head(REG):
     """The REAL NeuSHead (model/head/neus_head/neus_head.py) over the nerfstudio stand-ins: forward (train: cellular
     rays, two-split; eval: fixed rays), prepare + render (chunked and unchunked), forward_occ, for a TPV and a BEV
     configuration.  Every key of every returned dict is saved together with the inputs, the state and the random draws."""
     import json
-    if 'dataset' not in sys.modules:
-        ds = types.ModuleType('dataset'); ds.__path__ = [os.path.join(REF, 'dataset')]; sys.modules['dataset'] = ds
-    namespace('model.head.neus_head')
-    DRAWS = install_nerfstudio_stubs()
-    ref_import('model.head.base_head')
-    nh = ref_import('model.head.neus_head.neus_head')
-
-    def cams(n, seed, img=(64, 64), f=60.0):
-        rng = np.random.RandomState(seed)
-        Kinv = np.linalg.inv(np.array([[f, 0, img[1] / 2, 0], [0, f, img[0] / 2, 0], [0, 0, 1, 0], [0, 0, 0, 1]]))
-        out = []
-        for i in range(n):
-            yaw = 0.4 + 2 * np.pi * i / n + 0.1 * rng.randn()
-            c2w = np.eye(4)
-            c2w[:3, :3] = np.array([[np.sin(yaw), 0, np.cos(yaw)], [-np.cos(yaw), 0, np.sin(yaw)], [0, -1, 0]])
-            c2w[:3, 3] = [0.6 * rng.randn(), 0.6 * rng.randn(), 0.4 + 0.2 * rng.randn()]
-            out.append(c2w @ Kinv)
-        return np.stack(out)
+    nh, DRAWS = _head_env()
+    cams = _cams
 
     cfgs = {
         # TPV, colour + semantics, cellular training lattice, two-split (first half: depth cams, second half: temporal)
@@ -838,22 +879,7 @@ def golden_head(REG):
                     mapping_args=dict(nonlinear_mode='linear', h_size=[32, 0], h_range=[16.0, 0], h_half=True,
                                       w_size=[8, 0], w_range=[8.0, 0], w_half=False, d_size=[4, 0], d_range=[-1.0, 3.0, 3.0]),
                     embed_dims=32, color_dims=0, density_layers=2, sh_deg=0, sh_act='relu', two_split=False, tpv=False),
-        # the SHIPPED head of config/nuscenes/nuscenes_occ.py:303-352, key for key: 256 samples, 6 cameras, color_dims 24
-        # (rgb + 21 semantic logits), cellular lattice on the 768 x 1600 image, random background, learnable beta 0.1,
-        # the 80 m x 80 m x 6.4 m box.  Reduced for a CPU fixture: the TPV grid (65 x 65 x 13 instead of 257 x 257 x 25)
-        # the lattice (6 x 10 rays per camera instead of 48 x 100) and the dense-query resolution (1.6 m instead of 0.4);
-        # `use_compact_2nd_grad=True` because the fork's non-compact form is not on disk (README).
-        # Saved to its own file (head_occ.npz): training forward, prepare + render, forward_occ.
-        'occ': dict(roi_aabb=[-40.0, -40.0, -1.0, 40.0, 40.0, 5.4], resolution=1.6, near_plane=0.0, far_plane=1e10,
-                    num_samples=256, num_samples_importance=0, num_up_sample_steps=0, base_variance=4, beta_init=0.1,
-                    beta_max=0.195, total_iters=3516 * 11, beta_hand_tune=False, use_numerical_gradients=False,
-                    sample_gradient=True, return_uniform_sdf=False, return_second_grad=True, use_compact_2nd_grad=True,
-                    return_sem=True, return_sample_sdf=False, ray_sample_mode='cellular', ray_number=[6, 10],
-                    ray_img_size=[768, 1600], ray_upper_crop=0, trans_kw='temImg2lidar', novel_view=None,
-                    render_bkgd='random',
-                    mapping_args=dict(nonlinear_mode='linear', h_size=[32, 0], h_range=[40.0, 0], h_half=False,
-                                      w_size=[32, 0], w_range=[40.0, 0], w_half=False, d_size=[12, 0], d_range=[-1.0, 5.4, 5.4]),
-                    embed_dims=96, color_dims=24, density_layers=2, sh_deg=0, sh_act='relu', two_split=False, tpv=True),
+        'occ': OCC_HEAD_CFG,          # the shipped nuscenes_occ head (module level: golden_train_step uses it too)
     }
     arrs, meta_json = {}, {}
     occ_arrs, occ_json = {}, {}
@@ -958,6 +984,142 @@ def golden_head(REG):
             save('head.npz', **arrs)
             with open(os.path.join(HERE, 'head_cfg.json'), 'w') as fjs:
                 json.dump(meta_json, fjs, indent=1)
+
+
+TRAIN_STEP = dict(n_cams=6, img=(768, 1600), focal=1266.0, n_sem=21, seed_params=23, seed_rep=5, seed_imgs=41, seed_np=77,
+                  seed_torch=100, global_iter=7)
+
+
+def train_step_inputs(spec=TRAIN_STEP):
+    """Seeded inputs of the training-step fixture that are too large to commit (354 MB of float32 images): the four image
+    stacks train.py:205-208 moves to the device, the OpenSeeD label map train.py:214-215 puts into the metas, and the
+    pixel-depth transforms to the temporal frames.  Shared with tests/test_golden_train_step_gpu.py, which regenerates
+    them from the same seeds (CPU generator: the same numbers wherever the same torch build runs).
+    Images are smooth (a bilinear blow-up of 48 x 100 noise, like photographs at the scale of a ray footprint) plus 2 % of
+    pixel noise: on white noise the bilinear taps would amplify the float32 rounding of a projected pixel coordinate by
+    the full dynamic range, which says nothing about either implementation."""
+    g = torch.Generator().manual_seed(spec['seed_imgs'])
+    H, W = spec['img']
+    N = spec['n_cams']
+    imgs = {}
+    for k in ('curr_imgs', 'prev_imgs', 'next_imgs', 'color_imgs'):
+        low = torch.rand(N, 3, 48, 100, generator=g)
+        up = torch.nn.functional.interpolate(low, size=(H, W), mode='bilinear', align_corners=True)
+        imgs[k] = (0.96 * up + 0.04 * torch.rand(N, 3, H, W, generator=g)).unsqueeze(0).contiguous()
+    sem_low = torch.randint(0, spec['n_sem'], (N, 1, 24, 50), generator=g).float()
+    sem = torch.nn.functional.interpolate(sem_low, size=(H, W), mode='nearest')[:, 0].long()
+    f = spec['focal']
+    K = np.array([[f, 0, W / 2, 0], [0, f, H / 2, 0], [0, 0, 1, 0], [0, 0, 0, 1]])
+
+    def motion(yaw, tx, tz):
+        y = np.deg2rad(yaw)
+        Rm = np.array([[np.cos(y), 0, np.sin(y), tx], [0, 1, 0, 0.02], [-np.sin(y), 0, np.cos(y), tz], [0, 0, 0, 1]])
+        return K @ Rm @ np.linalg.inv(K)
+    prev = np.stack([motion(2.0 + 0.3 * c, 0.3, -0.6) for c in range(N)])
+    nxt = np.stack([motion(-2.5 - 0.3 * c, -0.2, 0.7) for c in range(N)])
+    return imgs, sem, prev, nxt
+
+
+def shipped_loss_cfg(ray_resize):
+    """`loss` and `loss_input_convertion` of the SHIPPED config/nuscenes/nuscenes_occ.py:111-186, read by executing the
+    config file itself (plain Python; `_base_` is only a list of paths), with `num_rays` replaced by the fixture's lattice."""
+    path = os.path.join(REF, 'config', 'nuscenes', 'nuscenes_occ.py')
+    src = open(path).read()
+    ns = {}
+    exec(compile(src, path, 'exec'), ns)
+    assert ns['num_rays'] == [48, 100] and ns['img_size'] == [768, 1600]
+    loss = ns['loss']
+    for c in loss['loss_cfgs']:
+        if 'ray_resize' in c:
+            c['ray_resize'] = list(ray_resize)
+    return loss, ns['loss_input_convertion']
+
+
+def golden_train_step(REG, LOSS_REG):
+    """ONE training step of the head + losses exactly as train.py:219-239 runs it: the REAL NeuSHead.forward
+    (model/head/neus_head/neus_head.py:473-713) at the shipped nuscenes_occ head configuration -> `loss_input_convertion`
+    -> the REAL MultiLoss (loss/multi_loss.py:24-43) over the REAL loss classes wired by the shipped `loss` list
+    (config/nuscenes/nuscenes_occ.py:111-186) -> loss.backward().  The absent sdfstudio fork is served by the declared
+    restatement in its differentiable float64 form (oracle/torch_port.py: render_port_differentiable).  Saved: the
+    total, every loss term, the gradients w.r.t. the three TPV planes, every field-MLP parameter, `variance`, and the
+    dense field volume (which separates the renderer's backward from the MLP's)."""
+    import copy
+    import json
+    nh, DRAWS = _head_env()
+    namespace('loss')
+    sys.modules['loss'].OPENOCC_LOSS = LOSS_REG
+    for m in ('base_loss', 'reproj_loss_mono_multi_new_combine', 'rgb_loss_ms', 'eikonal_loss', 'second_grad_loss', 'multi_loss'):
+        ref_import('loss.' + m)
+    spec = TRAIN_STEP
+    cfg = copy.deepcopy(OCC_HEAD_CFG)
+    torch.manual_seed(spec['seed_params'])
+    head = nh.NeuSHead(**copy.deepcopy(cfg))
+    head.model.differentiable = True
+    f = head.model.field
+    with torch.no_grad():
+        f.net.density_net[-1].bias[0] = 0.4          # surfaces inside the box (as in golden_head)
+    H, W, D, C = f.mapping.size_h, f.mapping.size_w, f.mapping.size_d, cfg['embed_dims']
+    g = torch.Generator().manual_seed(spec['seed_rep'])
+    rep = [torch.randn(1, H * W, C, generator=g).requires_grad_(True), torch.randn(1, D * H, C, generator=g).requires_grad_(True),
+           torch.randn(1, W * D, C, generator=g).requires_grad_(True)]
+    img = tuple(cfg['ray_img_size'])
+    c0, c1 = _cams(spec['n_cams'], 1, img, spec['focal']), _cams(spec['n_cams'], 2, img, spec['focal'])
+    imgs, sem, prev, nxt = train_step_inputs(spec)
+    img_metas = [dict(img2lidar=list(c0), temImg2lidar=list(c1), img2prevImg=prev, img2nextImg=nxt, sem=sem)]
+    loss_cfg, conv = shipped_loss_cfg(cfg['ray_number'])
+    loss_func = LOSS_REG.build(copy.deepcopy(loss_cfg))
+
+    os.environ['eval'] = 'false'
+    head.train()
+    DRAWS.clear()
+    np.random.seed(spec['seed_np'])
+    torch.manual_seed(spec['seed_torch'])
+    # ---- train.py:219-239 ----
+    result_dict = head(rep, img_metas, global_iter=spec['global_iter'])
+    vol = f.net.density_color
+    vol.retain_grad()
+    loss_input = {'curr_imgs': imgs['curr_imgs'], 'prev_imgs': imgs['prev_imgs'], 'next_imgs': imgs['next_imgs'],
+                  'curr_feats': imgs['curr_imgs'], 'prev_feats': imgs['prev_imgs'], 'next_feats': imgs['next_imgs'],
+                  'metas': img_metas, 'color_imgs': imgs['color_imgs']}
+    for loss_input_key, loss_input_val in conv.items():
+        loss_input.update({loss_input_key: result_dict[loss_input_val]})
+    # per-term gradient digests w.r.t. the field volume (which terms reach the renderer, and how strongly), taken from the
+    # same graph before the step's own backward
+    term_digest = {}
+    for lf in loss_func.losses:
+        gv, = torch.autograd.grad(lf(loss_input), vol, retain_graph=True)
+        term_digest[lf.__class__.__name__] = np.array([float(gv.double().abs().sum()), float(gv.double().sum()),
+                                                       float(gv.abs().max())])
+    vol.grad = None                 # retain_grad's hook also fires under autograd.grad
+    loss, loss_dict = loss_func(loss_input)
+    loss.backward()
+
+    arrs = {f'sd.{k}': v for k, v in to_np(head.state_dict()).items()}
+    for k, v in term_digest.items():
+        arrs[f'termgrad.{k}'] = v
+    for i, r in enumerate(rep):
+        arrs[f'rep{i}'] = r.detach().numpy()
+        arrs[f'grad.rep{i}'] = r.grad.numpy()
+    for n, p in head.named_parameters():
+        assert p.grad is not None, n
+        arrs[f'grad.sd.{n}'] = p.grad.numpy()
+    arrs['grad.volume'] = vol.grad[0].numpy()                    # (1 + color_dims, H, W, D): d loss / d density_color
+    arrs['img2lidar'], arrs['temImg2lidar'], arrs['img2prevImg'], arrs['img2nextImg'] = c0, c1, prev, nxt
+    arrs['draw.t_rand'] = DRAWS['t_rand'].numpy()
+    arrs['draw.bkgd'] = DRAWS['bkgd'][0].numpy()
+    arrs['loss.total'] = loss.detach().numpy()
+    for k, v in loss_dict.items():
+        arrs[f'loss.{k}'] = np.float64(v)
+    _flatten_out('out', {k: result_dict[k] for k in ('ms_depths', 'ms_colors', 'ms_accs', 'ms_rays', 'sem', 'second_grad')}, arrs)
+    # digests of the regenerated inputs: the GPU test checks that its seeds gave the same images
+    for k, v in imgs.items():
+        arrs[f'digest.{k}'] = np.array([float(v.double().sum()), float(v[0, :, :, ::97, ::101].double().sum())])
+    arrs['digest.sem'] = np.array([int(sem.sum()), int(sem[:, ::97, ::101].sum())])
+    save('train_step.npz', **arrs)
+    with open(os.path.join(HERE, 'train_step_cfg.json'), 'w') as fjs:
+        json.dump(dict(head=cfg, loss=loss_cfg, loss_input_convertion=conv, spec=spec), fjs, indent=1)
+    print('train_step: total', float(loss), loss_dict, '|g_vol|', float(vol.grad.abs().max()),
+          {n: float(p.grad.abs().max()) for n, p in head.named_parameters()}, {k: v.tolist() for k, v in term_digest.items()})
 
 
 FULL_ENCODER = dict(dim=96, heads=6, cams=6, tpv=(25, 25, 7), fpn=((12, 25), (6, 13), (3, 7), (2, 4)), img_shape=(96, 200),
@@ -1086,6 +1248,7 @@ if __name__ == '__main__':
     todo = dict(geometry=golden_geometry, losses=lambda: golden_losses(LOSS_REG), more=lambda: golden_more(LOSS_REG),
                 encoder=lambda: golden_encoder(REG), bev_encoder=lambda: golden_bev_encoder(REG),
                 segmentor=lambda: golden_segmentor(REG), head=lambda: golden_head(REG),
+                train_step=lambda: golden_train_step(REG, LOSS_REG),
                 encoder_full=lambda: golden_encoder_full(REG))
     for name, fn in todo.items():
         if not only or name in only:

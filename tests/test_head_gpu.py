@@ -102,16 +102,12 @@ def test_head_eval_render_vs_oracle(hip):
         rays = RaySet(img2lidar=cams, nx=10, ny=6, sx=6.4, sy=64 / 6)
         from selfocc_amd.render import SDFVolume
         ref = oracle.render_fwd(SDFVolume(vol.mapping, vol.sdf.detach().cpu(), vol.feat.detach().cpu(), vol.n_rgb, vol.n_sem), rays, cfg)
-        ok = ref['acc'] > 0.05
-        # default fast path (canonical cell selection near faces): 1e-4 on (nearly) every ray, all bounded
-        close = lambda a, b, rtol, atol: ((a - b).abs() <= atol + rtol * b.abs())
-        d = out['ms_depths'][0].flatten().cpu()
-        if ok.any():
-            assert close(d[ok], ref['depth'][ok], 1e-4, 1e-5).float().mean() >= 0.98 and close(d[ok], ref['depth'][ok], 2e-2, 1e-3).all()
-        assert close(out['ms_accs'][0].flatten().cpu(), ref['acc'], 1e-4, 1e-4).float().mean() >= 0.98
-        assert close(out['ms_colors'][0].reshape(-1, 3).cpu(), ref['rgb'], 1e-4, 1e-4).float().mean() >= 0.98
-        assert close(out['sem'][0].reshape(-1, 5).cpu(), ref['sem'], 1e-4, 1e-4).float().mean() >= 0.98
-        assert (out['ms_accs'][0].flatten().cpu() - ref['acc']).abs().max() < 5e-3
+        # every ray under the strict rule of tests/test_render_gpu.py::parity_report (depth 1e-4 relative on every ray that
+        # accumulates, acc / rgb / sem within 1e-4 absolute on every ray) — until round 4 this test accepted 98 % of the rays
+        from test_render_gpu import parity_report
+        got = dict(depth=out['ms_depths'][0].flatten(), acc=out['ms_accs'][0].flatten(), rgb=out['ms_colors'][0].reshape(-1, 3),
+                   sem=out['sem'][0].reshape(-1, 5), nears=ref['nears'], fars=ref['fars'])
+        parity_report(got, ref, label="head eval render (cfg1, 2 cams)", strict=True, min_frac=1.0)
         assert out['ms_max_depths'][0].shape == (1, 2, 60)
         # vis_normal (the fork's normal_vis; reference neus_head.py:379, 414, 463): zeros unless asked for, then the
         # weighted sum of the unit SDF gradients from the chunked per-sample pass == the oracle's per-sample outputs

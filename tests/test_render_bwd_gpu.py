@@ -1,5 +1,8 @@
 """GPU parity of selfocc_render_bwd: gradients wrt the SDF volume, the feature volume and
 inv_s against float64 autograd through the differentiable torch port of the same path."""
+import json
+import os
+
 import pytest
 import torch
 
@@ -78,6 +81,121 @@ def test_render_backward_vs_float64_autograd(hip, n_rgb, n_sem, jitter, sample_p
     # a heavily cancelling sum of N*S signed terms: float32 torch autograd of the same port is
     # itself ~2 % off the float64 value on these inputs
     assert e_s < 5e-2, f"d/d inv_s rel {e_s:.3e} ({inv_s.grad.item()} vs {inv_s64.grad.item()})"
+
+
+LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "render_bwd_parity.jsonl")
+
+
+@pytest.mark.parametrize("scatter", ["atomic", "binned"])
+def test_render_backward_vs_float64_autograd_at_the_training_shape(hip, scatter):
+    """The kernel at the shape it ships at (nuscenes_occ: 257 x 257 x 25 volume, 1 + 24 channels, 256 samples per ray,
+    single jitter, random background) against float64 autograd of the port, on every 14th ray of the 6 x 48 x 100
+    training lattice (2 058 rays, 527 k samples; random upstream gradients on every differentiable output).  Measured rel-L2 / max errors go to gpurun_out/render_bwd_parity.jsonl;
+    the bounds are ~10 x the measured values (profiles/r5_a_render_bwd_parity.jsonl)."""
+    n_rgb, n_sem = 3, 21
+    vol = sy.make_volume("cfg5", n_rgb=n_rgb, n_sem=n_sem, seed=3)
+    full = sy.explicit_rays(sy.make_rays("cfg5", seed=3))
+    idx = torch.arange(0, full.n_rays, 14)
+    ex = RaySet(origins=full.origins[idx].contiguous(), dirs=full.dirs[idx].contiguous(), dir_norm=full.dir_norm[idx].contiguous())
+    cfg = sy.make_render_config("cfg5", inv_s=12.0, jitter_mode=abi.JITTER_SINGLE, bkgd_mode=abi.BKGD_PER_RAY)
+    cfg.bwd_scatter = scatter
+    N, S = ex.n_rays, cfg.n_samples
+    assert S == 256 and N > 2000
+    g = torch.Generator().manual_seed(4)
+    t_rand, bk = torch.rand(N, generator=g), torch.rand(N, 3, generator=g)
+    G = dict(depth=torch.randn(N, generator=g), acc=torch.randn(N, generator=g), weights=torch.randn(N, S, generator=g),
+             sdf=0.1 * torch.randn(N, S, generator=g), grad=0.1 * torch.randn(N, S, 3, generator=g),
+             rgb=torch.randn(N, 3, generator=g), sem=torch.randn(N, n_sem, generator=g))
+    dd = torch.float64
+    vol64 = vol.to_reference_layout()[0].to(dd).requires_grad_(True)
+    inv_s64 = torch.tensor(cfg.inv_s, dtype=dd, requires_grad=True)
+    ref = tp.render_port_differentiable(vol.mapping, vol64, n_rgb, n_sem, ex.origins.to(dd), ex.dirs.to(dd), ex.dir_norm.to(dd),
+                                        cfg, inv_s64, t_rand.to(dd), bk.to(dd))
+    # The kernel marches ALL rays; the upstream gradients are zeroed on the rays where a float32 and a float64 evaluation are
+    # not comparable (measured with one upstream gradient at a time, scripts/diag/render_bwd_by_upstream.py):
+    #  * a sample within 1e-4 voxel of a voxel face (float32 positions resolve ~1e-5 voxel at 40 m): the trilinear gradient
+    #    is piece-wise constant per cell, so such a sample's d sdf / d x — and with it cos, alpha and every weight behind it on
+    #    the ray — belongs to the neighbouring cell in one of the two evaluations (forward `grad` off by 35 % of its maximum on
+    #    those samples; they alone put 3.5e-3 into the rel-L2 of d L / d sdf_vol);
+    #  * `depth` of a ray that accumulates < 0.05: a ratio of two rounding-noise sums (tests/test_render_gpu.py).
+    pos = ex.origins.to(dd)[:, None, :] + ex.dirs.to(dd)[:, None, :] * ref['starts'].detach()[..., None]
+    gc = vol.mapping.meter2grid(pos)
+    fr = gc - torch.floor(gc)
+    keep = (torch.minimum(fr, 1 - fr).amin(dim=(1, 2)) > 1e-4)
+    assert keep.float().mean() > 0.8
+    for k in G:
+        G[k] = G[k] * keep.reshape(-1, *([1] * (G[k].dim() - 1))).to(G[k].dtype)
+    G['depth'] = G['depth'] * (ref['acc'].detach() > 0.05).float()
+    sum((ref[k] * G[k].to(dd)).sum() for k in G).backward()
+    ref_gsdf, ref_gfeat = vol64.grad[0], vol64.grad[1:].permute(1, 2, 3, 0)
+
+    v = vol.to(D0)
+    sdf_p, feat_p = v.sdf.clone().requires_grad_(True), v.feat.clone().requires_grad_(True)
+    inv_s = torch.tensor([cfg.inv_s], device=D0, requires_grad=True)
+    out = render_rays_autograd(SDFVolume(v.mapping, sdf_p, feat_p, n_rgb, n_sem), inv_s,
+                               RaySet(origins=ex.origins.to(D0), dirs=ex.dirs.to(D0), dir_norm=ex.dir_norm.to(D0)),
+                               cfg, want_grad_samples=True, t_rand=t_rand.to(D0), bkgd_rays=bk.to(D0))
+    sum((out[k] * G[k].to(D0)).sum() for k in G).backward()
+    got_s, got_f = sdf_p.grad.cpu().double(), feat_p.grad.cpu().double()
+    m = dict(scatter=scatter, n_rays=N, n_samples=S, rays_with_upstream=keep.float().mean().item(),
+             sdf_l2=_rel_l2(got_s, ref_gsdf), sdf_max=((got_s - ref_gsdf).abs().max() / ref_gsdf.abs().max()).item(),
+             feat_l2=_rel_l2(got_f, ref_gfeat), feat_max=((got_f - ref_gfeat).abs().max() / ref_gfeat.abs().max()).item(),
+             inv_s_rel=abs(inv_s.grad.item() - inv_s64.grad.item()) / abs(inv_s64.grad.item()))
+    try:
+        os.makedirs(os.path.dirname(LOG), exist_ok=True)
+        with open(LOG, "a") as f:
+            f.write(json.dumps(m) + "\n")
+    except OSError:
+        pass
+    assert m['sdf_l2'] < TRAIN_SHAPE_TOL['sdf_l2'] and m['sdf_max'] < TRAIN_SHAPE_TOL['sdf_max'], m
+    assert m['feat_l2'] < TRAIN_SHAPE_TOL['feat_l2'] and m['feat_max'] < TRAIN_SHAPE_TOL['feat_max'], m
+    assert m['inv_s_rel'] < TRAIN_SHAPE_TOL['inv_s_rel'], m
+
+
+# ~10 x the measured values (profiles/r5_a_render_bwd_parity.jsonl: sdf 1.08e-5 / 1.40e-5, feat 6.9e-6 / 1.2e-5, inv_s 8.1e-5;
+# without the face / low-acc mask on the upstream gradients: 3.0e-3 / 2.0e-2 / 3.8e-4 / 4.7e-3 / 2.3e-2, the float32 torch
+# port itself 4.3e-3 / 2.0e-2 / 7.4e-4 / - / 2.1e-2 from the float64 value)
+TRAIN_SHAPE_TOL = dict(sdf_l2=1e-4, sdf_max=1.5e-4, feat_l2=7e-5, feat_max=1.2e-4, inv_s_rel=1e-3)
+
+
+@pytest.mark.parametrize("n_rgb,n_sem", [(0, 0), (3, 5)])
+def test_render_backward_binned_vs_atomic_with_samples_outside_the_volume(hip, n_rgb, n_sem):
+    """Samples OUTSIDE the volume (so_locate does not clamp): rays that miss the box (all samples collapse to one
+    outside point), a near plane beyond the exit, and an aabb larger than the mapping's range.  The atomic path tests
+    every corner on the true indices; the binned path must add nothing for such samples either (round-4 advisor finding:
+    its packed cell clamped h0 <= -2 to -1 and then scattered onto the face voxels)."""
+    vol = sy.make_volume("cfg1", n_rgb=n_rgb, n_sem=n_sem, seed=9, noise=0.02).to(D0)
+    ex = sy.explicit_rays(sy.make_rays("cfg1", seed=9))
+    o, d = ex.origins.clone(), ex.dirs.clone()
+    n = o.shape[0]
+    o[: n // 4] += torch.tensor([-30.0, 4.0, 0.0])           # far outside, most of these rays miss the box entirely
+    o[n // 4: n // 2] += torch.tensor([0.0, -25.0, 3.0])     # outside and above: enter through a face or miss
+    d[: n // 8] = -d[: n // 8]                                # pointing away
+    rg = RaySet(origins=o.to(D0), dirs=d.to(D0), dir_norm=ex.dir_norm.to(D0))
+    for aabb, near in ((None, 0.0), (None, 9.0), ((-6.0, -6.0, -3.0, 20.0, 20.0, 4.0), 0.0)):
+        res = {}
+        for mode in ("atomic", "binned"):
+            cfg = sy.make_render_config("cfg1", inv_s=12.0, near_plane=near)
+            if aabb is not None:
+                cfg.aabb = aabb
+            cfg.n_samples, cfg.bwd_scatter = 100, mode
+            inv_s = torch.tensor([12.0], device=D0, requires_grad=True)
+            sdf = vol.sdf.detach().clone().requires_grad_(True)
+            feat = None if vol.feat is None else vol.feat.detach().clone().requires_grad_(True)
+            out = render_rays_autograd(SDFVolume(vol.mapping, sdf, feat, n_rgb, n_sem), inv_s, rg, cfg)
+            loss = out['depth'].mean() + out['sdf'].abs().mean() + (out['grad'].norm(dim=-1) - 1).square().mean() + \
+                (out['weights'] * torch.linspace(0, 1, 100, device=D0)).sum(-1).mean()
+            if n_rgb:
+                loss = loss + out['rgb'].mean() + out['sem'].square().mean()
+            loss.backward()
+            res[mode] = (sdf.grad, None if feat is None else feat.grad)
+        a, b = res["atomic"], res["binned"]
+        # near = 9 m puts (nearly) every sample beyond the 12.8 m box: the atomic path then adds nothing at all, and so must
+        # the binned one (<= with a zero right-hand side)
+        assert a[0].abs().max() > 0 or near > 0
+        assert (b[0] - a[0]).abs().max() <= 1e-4 * a[0].abs().max(), (aabb, near, (b[0] - a[0]).abs().max().item(), a[0].abs().max().item())
+        if n_rgb:
+            assert (b[1] - a[1]).abs().max() <= 1e-4 * a[1].abs().max(), (aabb, near)
 
 
 def test_render_backward_zero_upstream(hip):
