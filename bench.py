@@ -8,7 +8,8 @@ nuScenes-sized frame of BASELINE.json configs[1] — 6 cameras x 450x800 rays, 1
 samples / ray, 200x200x16 volume — rendered by selfocc_render_fwd (ray generation,
 AABB clip, sampling, trilinear SDF/colour/semantic lookup, NeuS alpha, compositing).
 Inputs (volume, camera matrices) are resident in HBM before the timed region.
-N > 1: one process per GPU (torchrun env).  Default (`--shard frames`): the global ray batch is N
+N > 1: one process per GPU — under torch.distributed.run as the driver launches it, or started by bench.py itself when it
+is run as plain `python bench.py --gpus N` (it re-executes under torch.distributed.run).  Default (`--shard frames`): the global ray batch is N
 frames, every rank marches one frame's worth of rays (rays are independent units: no data-path
 collective) and the ranks all-reduce the scalar rendered-depth loss over RCCL each step, as
 north_star describes => weak scaling.  `--shard rays`: ONE frame is split into
@@ -32,6 +33,7 @@ import torch
 import torch.distributed as dist
 
 HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+L1_PEAK_GBPS = 256 * 64 * 2.4   # vector L1 (TCP): 64 B / clk / CU x 256 CUs x 2.4 GHz = 39.3 TB/s
 
 
 def algorithmic_bytes(vol, n_rays, n_sem):
@@ -83,10 +85,22 @@ def main():
                     help="skip the whole-path stage timings (scripts/bench_hotpath_*.py) reported under \"hot_path\"")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks ourselves (the reference spawns its own, train.py:400-401) by
+        # re-executing this command under torch.distributed.run — one process per GPU, rendezvous on 127.0.0.1.  A line whose
+        # n_gpus differs from --gpus is never printed.
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    assert world == args.gpus, f"WORLD_SIZE={world} but --gpus {args.gpus}: the line's n_gpus must be the number asked for"
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the hot path has no CPU fallback)")
     # SELFOCC_BENCH_SHARE_GPU=1 (testing only): every rank uses cuda:0 over gloo, so that the N > 1 code
@@ -209,11 +223,30 @@ def main():
                                     "frac": round(ach / peak, 3),
                                     "note": "SQ_INSTS_VALU x 64 lanes / kernel time vs 256 CU x 4 SIMD x 32 lanes x 2.4 GHz"}
                 roofline["valu_frac"] = round(ach / peak, 3)
+            # The OPERATIVE bound of the march, from per-unit utilisations of the same PMC session — not from GRBM_TA_BUSY, which
+            # counts the cycles in which ANY of the 256 texture addressers is busy (0.95 on this kernel; kept as
+            # `ta_any_busy_frac` for continuity) and over-states the load (round-4 review):
+            #   ta_util        = TA_BUSY_avr / (GRBM_GUI_ACTIVE / 8 XCDs)     the AVERAGE addresser's busy share of the kernel
+            #   ta_unit_util   = TA_TA_BUSY_sum / 256 TAs / the same cycles
+            #   l1_gather_frac = bytes gathered through the vector L1 / (64 B/clk/CU x 256 CUs x 2.4 GHz = 39.3 TB/s)
+            # `frac` above stays the HBM number the contract asks for (the volume sits in L2 / MALL).
             if rec.get("ta_busy_cycles") and rec.get("gui_active_cycles"):
-                # the OPERATIVE bound of the march (same PMC run): the texture-address units are busy for this share of the
-                # kernel's cycles; `frac` above stays the HBM number the contract asks for (the volume sits in L2 / MALL)
-                roofline["ta_busy_frac"] = round(rec["ta_busy_cycles"] / rec["gui_active_cycles"], 3)
-                roofline["bound_operative"] = "TA" if roofline["ta_busy_frac"] >= 0.8 else ("VALU" if roofline.get("valu_frac", 0) >= 0.6 else "latency")
+                roofline["ta_any_busy_frac"] = round(rec["ta_busy_cycles"] / rec["gui_active_cycles"], 3)
+            if rec.get("ta_busy_avr") and rec.get("gui_active_cycles_ta_pass"):
+                per_xcd = rec["gui_active_cycles_ta_pass"] / 8.0
+                roofline["ta_util"] = round(rec["ta_busy_avr"] / per_xcd, 3)
+                if rec.get("ta_ta_busy_sum"):
+                    roofline["ta_unit_util"] = round(rec["ta_ta_busy_sum"] / 256.0 / per_xcd, 3)
+            if rec.get("tcp_total_cache_accesses"):
+                roofline["l1_accesses_per_launch"] = rec["tcp_total_cache_accesses"]
+    roofline["l1_gather_frac"] = round(roofline["touch_GBps"] / L1_PEAK_GBPS, 3)
+    utils = {"TA": roofline.get("ta_util"), "L1": roofline["l1_gather_frac"], "VALU": roofline.get("valu_frac")}
+    if utils["TA"] is not None:
+        top = max((v, k) for k, v in utils.items() if v is not None)
+        # a pipe is "the bound" only when it is (nearly) saturated; otherwise the kernel is limited by instruction issue and
+        # gather latency at the occupancy its registers allow, and the largest utilisation says how far from that pipe's roof
+        roofline["bound_operative"] = top[1] if top[0] >= 0.8 else "issue/latency"
+        roofline["bound_operative_util"] = {k: v for k, v in utils.items() if v is not None}
 
     extras = {}
     if rank == 0 and world == 1 and not args.no_extras:
@@ -388,7 +421,9 @@ def main():
                "msda_bwd_band_list": 6 * 25500 * 96 * 4}                    # d L / d value of one cross-attention call
         groups = {"render_bwd": ("render_bwd_kernel", "rb_brick_kernel", "rb_count_kernel"),
                   "field_volume_bwd": ("field_volume_bwd_kernel",), "msda_bwd_band_list": ("msda_bwd_band_list_kernel",)}
-        roofline_bwd = {"source": "profiles/pmc_bwd.json (scripts/pmc_train_bwd.sh, training iteration at nuscenes_occ shapes)"}
+        roofline_bwd = {"source": "profiles/pmc_bwd.json (scripts/pmc_train_bwd.sh, training iteration at nuscenes_occ shapes)",
+                        "measured_in_this_run": False,      # RECORDED counters + durations of that PMC session, not of this process
+                        "recorded_round": rec.get("_round")}
         for name, pats in groups.items():
             ks = {k: v for k, v in rec.items() if any(k.startswith(p) for p in pats) and v.get("write_kb") is not None}
             if not ks:

@@ -9,7 +9,10 @@ API-visible output byte once — against the 8 TB/s HBM peak.
     cross     value + ref + vis + off_raw + logits + out     (selfocc_msda_cross_fwd / _cross_bwd, camera loop)
     pro       value + ref [+ vis] + query + W + out          (selfocc_msda_pro_fwd: the offset / weight linears in the
               kernel prologue — off_raw / logits never exist; beside it the separate route it replaces, linears included)
-`--json`: one JSON object on the last line (bench.py's "roofline_msda")."""
+`--json`: one JSON object on the last line (bench.py's "roofline_msda").  `--case NAME`: one of the three shapes only
+(scripts/pmc_msda_rows.sh profiles each shape in its own rocprofv3 session, so that a kernel's counters belong to one shape).
+Every row also carries the texture-path view: `l1_gather_frac` (computed here) and — from profiles/pmc_msda.json, the
+TA_BUSY_avr / TA_TA_BUSY_sum / GRBM_GUI_ACTIVE counters of the row's kernels in that shape — `ta_util` per kernel."""
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -54,14 +57,44 @@ def time_bwd(make_out, g, n=10):
 L1_PEAK = 256 * 64 * 2.4          # GB/s: 256 CUs x 64 bytes / clk of vector L1 at 2.4 GHz
 
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ONLY = sys.argv[sys.argv.index("--case") + 1] if "--case" in sys.argv else None
+try:
+    PMC = json.load(open(os.path.join(ROOT, "profiles", "pmc_msda.json")))
+except OSError:
+    PMC = {}
+# row label -> the HIP kernels it launches (function names; the gathers are in the first one)
+HIP_KERNELS = (("msda_pro_fwd", ["msda_pro_fwd_kernel"]), ("linears + msda_cross_fwd", ["msda_cross_fwd_kernel"]),
+               ("linears + msda_fused_fwd", ["msda_fused_fwd_kernel"]),
+               ("msda_cross_bwd", ["msda_cross_bwd_point_kernel", "msda_bwd_band_list_kernel"]), ("msda_cross_fwd", ["msda_cross_fwd_kernel"]),
+               ("msda_fused_bwd", ["msda_fused_bwd_point_kernel", "msda_bwd_band_list_kernel"]), ("msda_fused_fwd", ["msda_fused_fwd_kernel"]),
+               ("msda_bwd", ["msda_bwd_point_kernel", "msda_bwd_band_list_kernel"]), ("msda_fwd", ["msda_fwd_kernel"]))
+
+
+def ta_view(kernel, case):
+    """TA utilisation of the row's kernels in this shape, from the committed PMC record (None when not recorded):
+    ta_util = TA_BUSY_avr / (GRBM_GUI_ACTIVE / 8 XCDs) — the average texture addresser's busy share of the kernel;
+    ta_unit_util = TA_TA_BUSY_sum / 256 TAs over the same cycles."""
+    names = next((v for k, v in HIP_KERNELS if kernel.startswith(k)), [])
+    out = {}
+    for n in names:
+        for full, c in PMC.get("cases", {}).get(case, {}).items():
+            if full.startswith(n) and c.get("gui_active"):
+                per_xcd = c["gui_active"] / 8.0
+                out[full] = dict(ta_util=round(c["ta_busy_avr"] / per_xcd, 3), ta_unit_util=round(c["ta_ta_busy_sum"] / 256.0 / per_xcd, 3),
+                                 launches=c.get("n"))
+    return out or None
+
+
 def rec(kernel, shape, alg_bytes, ms, points):
     gbps = alg_bytes / ms / 1e6
     # the texture path: a bilinear sample is 4 corners x 64 bytes of float32 channels through the CU's vector L1, whatever the
     # caches behind it do (an upper bound on the gathered bytes: samples outside the map and invisible pairs gather nothing)
     l1 = points * 256.0 / ms / 1e6
+    case = "cross_hw" if "camera loop" in shape else shape.split(":")[0]
     return dict(kernel=kernel, shape=shape, alg_MB=round(alg_bytes / 1e6, 1), ms=round(ms, 4), GBps=round(gbps, 1),
                 frac_of_8TBps=round(gbps / PEAK, 4), Gpoints_per_s=round(points / ms / 1e6, 2),
-                l1_gather_GBps=round(l1, 0), frac_of_l1_39TBps=round(l1 / L1_PEAK, 3))
+                l1_gather_GBps=round(l1, 0), l1_gather_frac=round(l1 / L1_PEAK, 3), ta=ta_view(kernel, case))
 
 
 def query_linears(nq, H, L, P):
@@ -77,6 +110,8 @@ def query_linears(nq, H, L, P):
 
 rows = []
 for name, (bs, nq, shapes, P) in CASES.items():
+    if ONLY and name != ONLY:
+        continue
     sh = torch.tensor(shapes, device=d)
     sh._so_host = [int(v) for v in sh.reshape(-1).tolist()]
     st = torch.cat([sh.new_zeros(1), (sh[:, 0] * sh[:, 1]).cumsum(0)[:-1]])
@@ -195,4 +230,6 @@ print(json.dumps({"peak_GBps": PEAK, "bound": "hbm",
                   "l1_definition": "second view, the bound these gather kernels actually sit under: points x 4 corners x 64 B through the "
                                    "vector L1 (64 B / clk / CU x 256 CUs x 2.4 GHz = 39.3 TB/s) / the same time; forward rows only read "
                                    "the corners once, backward rows read them once and scatter them once",
+                  "ta_definition": "per row, per HIP kernel: ta_util = TA_BUSY_avr / (GRBM_GUI_ACTIVE / 8 XCDs), ta_unit_util = TA_TA_BUSY_sum / "
+                                   "256 / the same cycles; RECORDED counters (" + str(PMC.get("source")) + "), not taken in this run",
                   "kernels": rows}), flush=True)

@@ -4,7 +4,7 @@
 C=$1; TAG=$2; Q=${3:-full}; R=${GRAFT_REPO_ROOT:-$(pwd)}; cd /tmp; export TMPDIR=/tmp
 passes=("SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY" \
         "SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" \
-        "GRBM_GUI_ACTIVE GRBM_TA_BUSY")
+        "GRBM_GUI_ACTIVE GRBM_TA_BUSY" "TA_BUSY_avr TA_TA_BUSY_sum GRBM_GUI_ACTIVE" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum")
 [ "$Q" = full ] && passes+=("FETCH_SIZE" "WRITE_SIZE")
 i=0; rm -rf $R/gpurun_out/pmc_$TAG
 for pass in "${passes[@]}"; do
@@ -23,7 +23,10 @@ for f in sorted(glob.glob("$R/gpurun_out/pmc_$TAG/p*/p_counter_collection.csv"))
         m = re.search(r'(render_fwd_\w+<[^>]*>|sdf_brickify_kernel)', r['Kernel_Name'])
         if m:
             agg[m.group(1)][r['Counter_Name']].append(float(r['Counter_Value']))
+    ta_pass = any('TA_BUSY_avr' in d for d in agg.values())
     for kn, d in agg.items():
         for k, v in d.items():
-            print(f"{kn:46s} {k:28s} n={len(v)} mean={sum(v)/len(v):.5g}")
+            # GRBM_GUI_ACTIVE is collected twice: the copy of the TA pass (same launches as TA_BUSY_avr) gets its own name
+            name = 'GRBM_GUI_ACTIVE_ta_pass' if (ta_pass and k == 'GRBM_GUI_ACTIVE') else k
+            print(f"{kn:46s} {name:28s} n={len(v)} mean={sum(v)/len(v):.5g}")
 PY

@@ -27,8 +27,13 @@ for c, key in ((1, "c1_f32_fast"), (4, "c4_f32_fast"), (25, "c25_f32_fast")):
                 "write_kb": round(write), "traffic_bytes_uncorrected": int((fetch + write) * 1024),
                 "valu_wave_insts": vals.get("SQ_INSTS_VALU"),
                 "gui_active_cycles": vals.get("GRBM_GUI_ACTIVE"), "ta_busy_cycles": vals.get("GRBM_TA_BUSY"),
+                # per-unit view (one pass: TA_BUSY_avr, TA_TA_BUSY_sum and the GRBM_GUI_ACTIVE of the same launches)
+                "ta_busy_avr": vals.get("TA_BUSY_avr"), "ta_ta_busy_sum": vals.get("TA_TA_BUSY_sum"),
+                "gui_active_cycles_ta_pass": vals.get("GRBM_GUI_ACTIVE_ta_pass"),
+                "tcp_total_cache_accesses": vals.get("TCP_TOTAL_CACHE_ACCESSES_sum"), "tcp_tcc_read_req": vals.get("TCP_TCC_READ_REQ_sum"),
+                "round": tag,
                 "note": (f"{kern.strip()} only: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes "
-                         f"(scripts/pmc_render.sh {c} {tag}_c{c}), mean of the launches of one run, MI355X, round 3 "
+                         f"(scripts/pmc_render.sh {c} {tag}_c{c}), mean of the launches of one run, MI355X, session {tag} "
                          f"(profiles/{tag}_render_c{c}_pmc.txt). traffic_bytes = (2 x FETCH_SIZE + WRITE_SIZE) KB: the guide's gfx950 "
                          "correction for 16-byte-per-lane loads (128-byte requests tallied at 64 bytes); WRITE_SIZE as reported. "
                          "The sdf_brickify_kernel that precedes the march is a separate kernel (its counters are in the same file).")}

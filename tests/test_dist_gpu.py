@@ -342,3 +342,25 @@ def test_bench_two_ranks_on_one_gpu(shard):
     rays = 6 * 450 * 800
     per_step = rays if shard == "rays" else 2 * rays
     assert abs(line["value"] - per_step / (line["ms_per_step"] * 1e-3)) / line["value"] < 1e-3
+
+
+def test_bench_plain_python_starts_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT torchrun (round-4 review: it silently ran one rank and printed n_gpus = 1): bench.py
+    re-executes itself under torch.distributed.run, and the one line it prints has n_gpus == --gpus."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env["SELFOCC_BENCH_SHARE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--preheat", "2",
+           "--no-cpu-baseline", "--no-extras", "--no-hotpath"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["ranks_seen"]["world_size"] == 2 and line["value"] > 0
+    # ... and a WORLD_SIZE that contradicts --gpus is an error, not a line
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--no-cpu-baseline",
+                          "--no-extras", "--no-hotpath"], cwd=root, env=dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"),
+                         capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
