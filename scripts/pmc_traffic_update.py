@@ -38,4 +38,6 @@ for c, key in ((1, "c1_f32_fast"), (4, "c4_f32_fast"), (25, "c25_f32_fast")):
                          "correction for 16-byte-per-lane loads (128-byte requests tallied at 64 bytes); WRITE_SIZE as reported. "
                          "The sdf_brickify_kernel that precedes the march is a separate kernel (its counters are in the same file).")}
 json.dump(out, open(os.path.join(ROOT, "profiles", "pmc_traffic.json"), "w"), indent=1)
+# gpurun only merges gpurun_out/ back: a copy to carry into profiles/ by hand
+json.dump(out, open(os.path.join(ROOT, "gpurun_out", f"{tag}_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps({k: (v["traffic_bytes"], v["fetch_kb"], v["write_kb"]) for k, v in out.items()}))
