@@ -783,6 +783,11 @@ extern "C" int selfocc_field_volume_fwd(const float *hw, const float *zh, const 
 }
 
 
+int so_field_volume_bwd_b3(const float *hw, const float *zh, const float *wz, int H, int W, int D, const float *w1,
+                           const float *b1, const float *w2, int out_dim, const float *g_sdf, const float *g_feat,
+                           int feat_stride, float *g_hw, float *g_zh, float *g_wz, float *g_w1, float *g_b1, float *g_w2,
+                           float *g_b2, hipStream_t st);      // field_bwd_b3.hip
+
 extern "C" int selfocc_field_volume_bwd(const float *hw, const float *zh, const float *wz, int32_t H, int32_t W,
                                         int32_t D, int32_t C, const float *w_hidden, const float *b_hidden,
                                         const float *w_out, int32_t out_dim, const float *g_sdf, const float *g_feat,
@@ -800,6 +805,12 @@ extern "C" int selfocc_field_volume_bwd(const float *hw, const float *zh, const 
     SO_REQUIRE(M < (1LL << 31) * 32, "field_volume_bwd: volume too large");
     const long long PH = (H + 3) / 4, PW = (W + 3) / 4, PD = (D + 1) / 2;
     SO_REQUIRE(PH * PW * PD < (1LL << 31), "field_volume_bwd: volume too large");
+    // round 5: the five GEMMs on the bf16 matrix pipe (field_bwd_b3.hip); SELFOCC_FIELD_BWD_B3=0 keeps the f32-MFMA kernel.
+    // (its 16-byte loads of the upstream feature gradient need rows of a multiple of four floats)
+    static const bool bwd_b3 = !(getenv("SELFOCC_FIELD_BWD_B3") && atoi(getenv("SELFOCC_FIELD_BWD_B3")) == 0);
+    if (bwd_b3 && (g_feat == nullptr || feat_stride % 4 == 0))
+        return so_field_volume_bwd_b3(hw, zh, wz, H, W, D, w_hidden, b_hidden, w_out, out_dim, g_sdf, g_feat, feat_stride, g_hw,
+                                      g_zh, g_wz, g_w_hidden, g_b_hidden, g_w_out, g_b_out, (hipStream_t)stream);
     FieldBwdArgs a{hw, zh, wz, H, W, D, w_hidden, b_hidden, w_out, out_dim, g_sdf, g_feat, feat_stride,
                    g_hw, g_zh, g_wz, g_w_hidden, g_b_hidden, g_w_out, g_b_out, M, (int)(PH * PW * PD), (int)PW, (int)PD};
     const size_t shm = ((size_t)kFB_C * kFB_LD + 32 * kFB_LD + (size_t)kFB_WAVES * 2 * 32 * kFB_TS) * sizeof(float);
