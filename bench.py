@@ -364,15 +364,17 @@ def main():
 
     hot_path = None
     if rank == 0 and world == 1 and not args.no_hotpath and not args.no_extras:
-        # the rest of the hot path at the reference's shipped shapes (no image backbone), outside the timed
-        # region and in their own processes: lifter + encoder + field volume + render of one nuscenes_depth
-        # evaluation frame, and one nuscenes_occ training iteration (forward, five losses, backward)
+        # the rest of the hot path, BUILT FROM THE SHIPPED CONFIGS through the registries (scripts/shipped_cfg/*.json =
+        # config/**/*.py dumped by scripts/dump_shipped_configs.py; no image backbone), outside the timed region and in their
+        # own processes: one nuscenes_depth evaluation frame, one nuscenes_occ occupancy frame, one kitti_novel_depth frame
+        # (BASELINE configs[3]) and one nuscenes_occ training iteration (forward, five losses, backward; clip + AdamW beside it)
         import subprocess
         torch.cuda.empty_cache()
         hot_path = {}
         here = os.path.dirname(os.path.abspath(__file__))
         for key, script in (("eval_frame_nuscenes_depth_ms", "bench_hotpath_eval.py"),
                             ("occ_eval_frame_nuscenes_occ_ms", "bench_hotpath_occ.py"),
+                            ("novel_depth_frame_kitti_ms", "bench_hotpath_kitti.py"),
                             ("train_iteration_nuscenes_occ_ms", "bench_hotpath_train.py")):
             try:
                 r = subprocess.run([sys.executable, os.path.join(here, "scripts", script)], capture_output=True,
