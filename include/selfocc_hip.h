@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SELFOCC_ABI_VERSION 29
+#define SELFOCC_ABI_VERSION 30
 
 int selfocc_abi_version(void);
 const char *selfocc_last_error(void);
@@ -83,8 +83,9 @@ enum {
                                    section 4 / tests/test_render_gpu.py (whole benchmarked frame:
                                    depth within 1e-4 relative on every ray that accumulates > 0.05). */
     SO_FLAG_NO_SKIP = 8,        /* fast path: do not skip saturated free-space samples (A/B switch) */
-    SO_FLAG_RAY_PER_LANE = 64,  /* per-sample launches through the ray-per-lane kernels instead of the sample-parallel
-                                   training kernel (A/B switch; same results to float rounding)     */
+    SO_FLAG_RAY_PER_LANE = 64,  /* accepted and IGNORED since ABI 30 (rounds 2 - 4: per-sample launches through ray-per-lane
+                                   kernels, an A/B switch nobody shipped; per-sample outputs always come from the
+                                   sample-parallel training kernel)                                  */
     SO_FLAG_NO_AHEAD = 32,      /* fast path: general march even where the code-ahead skip marcher applies (A/B) */
     SO_FLAG_NO_FACE_SAFE = 16   /* fast path: never re-derive cells near voxel faces: ~6 % faster on
                                    the SDF-only kernel, but ~1e-4 of the rays (those with a sample

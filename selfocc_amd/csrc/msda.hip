@@ -1219,27 +1219,56 @@ extern "C" int selfocc_msda_fwd(const float *value, const int32_t *shapes, const
 #define SO_LAUNCH_G(DD, LG)                                                                       \
     hipLaunchKernelGGL((msda_fwd_kernel<DD, LG>), dim3((unsigned)blocks), dim3(256), 0, st, value, \
                        shapes, starts, loc, attw, out, dm)
-#define SO_LAUNCH(DD)                                                                             \
+    // so_pick_group returns whole channel teams (G >= D / 4): 22 of the 4 x 7 combinations can be reached
+#define SO_LAUNCH(DD, LGMIN)                                                                      \
     switch (logG) {                                                                               \
-        case 0: SO_LAUNCH_G(DD, 0); break;                                                        \
-        case 1: SO_LAUNCH_G(DD, 1); break;                                                        \
-        case 2: SO_LAUNCH_G(DD, 2); break;                                                        \
+        case 0: SO_LAUNCH_G(DD, (LGMIN > 0 ? LGMIN : 0)); break;                                  \
+        case 1: SO_LAUNCH_G(DD, (LGMIN > 1 ? LGMIN : 1)); break;                                  \
+        case 2: SO_LAUNCH_G(DD, (LGMIN > 2 ? LGMIN : 2)); break;                                  \
         case 3: SO_LAUNCH_G(DD, 3); break;                                                        \
         case 4: SO_LAUNCH_G(DD, 4); break;                                                        \
         case 5: SO_LAUNCH_G(DD, 5); break;                                                        \
         default: SO_LAUNCH_G(DD, 6); break;                                                       \
     }
+    SO_REQUIRE((1 << logG) >= d / 4, "msda_fwd: group of %d lanes for %d channels", 1 << logG, d);
     switch (d) {
-        case 4: SO_LAUNCH(4); break;
-        case 8: SO_LAUNCH(8); break;
-        case 16: SO_LAUNCH(16); break;
-        default: SO_LAUNCH(32); break;
+        case 4: SO_LAUNCH(4, 0); break;
+        case 8: SO_LAUNCH(8, 1); break;
+        case 16: SO_LAUNCH(16, 2); break;
+        default: SO_LAUNCH(32, 3); break;
     }
 #undef SO_LAUNCH
 #undef SO_LAUNCH_G
     return so_launch_status();
 }
 
+
+
+// The (D, log2 G, value type) combinations of the fused / camera-loop families that can be launched: D = 8, 16, 32 channels per
+// head (the shipped lifters use 16; the plain mmcv-boundary op keeps 4), whole channel teams (G >= D / 4: so_pick_group_fused
+// never returns less), bfloat16 `value` for D = 16 only.  Round 4 instantiated all 4 x 7 x 2 = 56 per family (224 kernels, 6 MB).
+#define SO_FUSED_LG(DD, LGMIN, VT)                                                       \
+    switch (logG_) {                                                                      \
+        case 1: if (LGMIN <= 1) { SO_LAUNCH_VT(DD, (LGMIN <= 1 ? 1 : LGMIN), VT); } break; \
+        case 2: if (LGMIN <= 2) { SO_LAUNCH_VT(DD, (LGMIN <= 2 ? 2 : LGMIN), VT); } break; \
+        case 3: SO_LAUNCH_VT(DD, 3, VT); break;                                           \
+        case 4: SO_LAUNCH_VT(DD, 4, VT); break;                                           \
+        case 5: SO_LAUNCH_VT(DD, 5, VT); break;                                           \
+        default: SO_LAUNCH_VT(DD, 6, VT); break;                                          \
+    }
+#define SO_FUSED_DISPATCH(d_, lg_, bf_)                                                  \
+    do {                                                                                  \
+        const int logG_ = (lg_);                                                          \
+        if ((d_) == 16) {                                                                 \
+            SO_REQUIRE(logG_ >= 2, "msda: group of %d lanes for 16 channels", 1 << logG_);  \
+            if (bf_) { SO_FUSED_LG(16, 2, uint16_t) } else { SO_FUSED_LG(16, 2, float) }  \
+        } else {                                                                          \
+            SO_REQUIRE(!(bf_), "msda: bfloat16 value is built for 16 channels per head only (got %d)", (int)(d_)); \
+            if ((d_) == 8) { SO_REQUIRE(logG_ >= 1, "msda: bad group"); SO_FUSED_LG(8, 1, float) }          \
+            else if ((d_) == 32) { SO_REQUIRE(logG_ >= 3, "msda: bad group"); SO_FUSED_LG(32, 3, float) }   \
+            else SO_REQUIRE(false, "msda fused / camera-loop ops: channels per head must be 8, 16 or 32 (got %d); the plain op takes 4", (int)(d_)); \
+        }                                                                                 \
+    } while (0)
 
 extern "C" int selfocc_msda_fused_fwd(const void *value, const int32_t *shapes, const int32_t *starts,
                                       const float *ref, int32_t ref_kind, const float *off_raw, const float *logits,
@@ -1263,31 +1292,11 @@ extern "C" int selfocc_msda_fused_fwd(const void *value, const int32_t *shapes, 
     SO_REQUIRE(blocks < (1LL << 31), "msda_fused_fwd: grid too large");
     MsdaDims dm{bs, nv, nq, heads, L, P, 0, 0, value_layout};
     hipStream_t st = (hipStream_t)stream;
-#define SO_LAUNCH_G(DD, LG)                                                                             \
-    if (value_dtype == SO_DTYPE_BF16)                                                                   \
-        hipLaunchKernelGGL((msda_fused_fwd_kernel<DD, LG, uint16_t>), dim3((unsigned)blocks), dim3(256), 0, st,   \
-                           (const uint16_t *)value, shapes, starts, ref, ref_kind, off_raw, logits, out, dm);      \
-    else                                                                                                \
-        hipLaunchKernelGGL((msda_fused_fwd_kernel<DD, LG, float>), dim3((unsigned)blocks), dim3(256), 0, st,       \
-                           (const float *)value, shapes, starts, ref, ref_kind, off_raw, logits, out, dm)
-#define SO_LAUNCH(DD)                                                                                   \
-    switch (logG) {                                                                                     \
-        case 0: SO_LAUNCH_G(DD, 0); break;                                                              \
-        case 1: SO_LAUNCH_G(DD, 1); break;                                                              \
-        case 2: SO_LAUNCH_G(DD, 2); break;                                                              \
-        case 3: SO_LAUNCH_G(DD, 3); break;                                                              \
-        case 4: SO_LAUNCH_G(DD, 4); break;                                                              \
-        case 5: SO_LAUNCH_G(DD, 5); break;                                                              \
-        default: SO_LAUNCH_G(DD, 6); break;                                                             \
-    }
-    switch (d) {
-        case 4: SO_LAUNCH(4); break;
-        case 8: SO_LAUNCH(8); break;
-        case 16: SO_LAUNCH(16); break;
-        default: SO_LAUNCH(32); break;
-    }
-#undef SO_LAUNCH
-#undef SO_LAUNCH_G
+#define SO_LAUNCH_VT(DD, LG, VT) \
+        hipLaunchKernelGGL((msda_fused_fwd_kernel<DD, LG, VT>), dim3((unsigned)blocks), dim3(256), 0, st, \
+                           (const VT *)value, shapes, starts, ref, ref_kind, off_raw, logits, out, dm)
+    SO_FUSED_DISPATCH(d, logG, value_dtype == SO_DTYPE_BF16);
+#undef SO_LAUNCH_VT
     return so_launch_status();
 }
 
@@ -1319,31 +1328,11 @@ extern "C" int selfocc_msda_cross_fwd(const void *value, const int32_t *shapes, 
     SO_REQUIRE(blocks < (1LL << 31), "msda_cross_fwd: grid too large");
     MsdaDims dm{1, nv, nq, heads, L, P, 0, value_stride, value_layout};
     hipStream_t st = (hipStream_t)stream;
-#define SO_LAUNCH_G(DD, LG)                                                                             \
-    if (value_dtype == SO_DTYPE_BF16)                                                                   \
-        hipLaunchKernelGGL((msda_cross_fwd_kernel<DD, LG, uint16_t>), dim3((unsigned)blocks), dim3(256), 0, st,   \
-                           (const uint16_t *)value, shapes, starts, ref, vis, off_raw, logits, out, cams, dm);     \
-    else                                                                                                \
-        hipLaunchKernelGGL((msda_cross_fwd_kernel<DD, LG, float>), dim3((unsigned)blocks), dim3(256), 0, st,       \
-                           (const float *)value, shapes, starts, ref, vis, off_raw, logits, out, cams, dm)
-#define SO_LAUNCH(DD)                                                                                   \
-    switch (logG) {                                                                                     \
-        case 0: SO_LAUNCH_G(DD, 0); break;                                                              \
-        case 1: SO_LAUNCH_G(DD, 1); break;                                                              \
-        case 2: SO_LAUNCH_G(DD, 2); break;                                                              \
-        case 3: SO_LAUNCH_G(DD, 3); break;                                                              \
-        case 4: SO_LAUNCH_G(DD, 4); break;                                                              \
-        case 5: SO_LAUNCH_G(DD, 5); break;                                                              \
-        default: SO_LAUNCH_G(DD, 6); break;                                                             \
-    }
-    switch (d) {
-        case 4: SO_LAUNCH(4); break;
-        case 8: SO_LAUNCH(8); break;
-        case 16: SO_LAUNCH(16); break;
-        default: SO_LAUNCH(32); break;
-    }
-#undef SO_LAUNCH
-#undef SO_LAUNCH_G
+#define SO_LAUNCH_VT(DD, LG, VT) \
+        hipLaunchKernelGGL((msda_cross_fwd_kernel<DD, LG, VT>), dim3((unsigned)blocks), dim3(256), 0, st, \
+                           (const VT *)value, shapes, starts, ref, vis, off_raw, logits, out, cams, dm)
+    SO_FUSED_DISPATCH(d, logG, value_dtype == SO_DTYPE_BF16);
+#undef SO_LAUNCH_VT
     return so_launch_status();
 }
 
@@ -1595,33 +1584,12 @@ extern "C" int selfocc_msda_fused_bwd(const void *value, const int32_t *shapes, 
     SO_REQUIRE(blocks < (1LL << 31), "msda_fused_bwd: grid too large");
     // (counting the sort's buckets inside this kernel, as selfocc_msda_cross_bwd does, measured slower here: 454 -> 570 us for
     // 58 us of msda_bin_kernel<false>: 32 groups per block contend for the few buckets of one plane)
-#define SO_LAUNCH_G(DD, LG)                                                                                  \
-    if (value_dtype == SO_DTYPE_BF16)                                                                        \
-        hipLaunchKernelGGL((msda_fused_bwd_point_kernel<DD, LG, uint16_t>), dim3((unsigned)blocks), dim3(256), 0, st,  \
-                           (const uint16_t *)value, shapes, starts, ref, ref_kind, off_raw, logits, g_out, g_off,      \
-                           g_logits, w.keys, w.recs, dm);                                                    \
-    else                                                                                                     \
-        hipLaunchKernelGGL((msda_fused_bwd_point_kernel<DD, LG, float>), dim3((unsigned)blocks), dim3(256), 0, st,     \
-                           (const float *)value, shapes, starts, ref, ref_kind, off_raw, logits, g_out, g_off,         \
+#define SO_LAUNCH_VT(DD, LG, VT) \
+        hipLaunchKernelGGL((msda_fused_bwd_point_kernel<DD, LG, VT>), dim3((unsigned)blocks), dim3(256), 0, st, \
+                           (const VT *)value, shapes, starts, ref, ref_kind, off_raw, logits, g_out, g_off, \
                            g_logits, w.keys, w.recs, dm)
-#define SO_LAUNCH(DD)                                                                                        \
-    switch (logG) {                                                                                          \
-        case 0: SO_LAUNCH_G(DD, 0); break;                                                                   \
-        case 1: SO_LAUNCH_G(DD, 1); break;                                                                   \
-        case 2: SO_LAUNCH_G(DD, 2); break;                                                                   \
-        case 3: SO_LAUNCH_G(DD, 3); break;                                                                   \
-        case 4: SO_LAUNCH_G(DD, 4); break;                                                                   \
-        case 5: SO_LAUNCH_G(DD, 5); break;                                                                   \
-        default: SO_LAUNCH_G(DD, 6); break;                                                                  \
-    }
-    switch (d) {
-        case 4: SO_LAUNCH(4); break;
-        case 8: SO_LAUNCH(8); break;
-        case 16: SO_LAUNCH(16); break;
-        default: SO_LAUNCH(32); break;
-    }
-#undef SO_LAUNCH
-#undef SO_LAUNCH_G
+    SO_FUSED_DISPATCH(d, logG, value_dtype == SO_DTYPE_BF16);
+#undef SO_LAUNCH_VT
     return so_band_scatter(shapes, starts, g_out, g_value, w, bsu, dm, d, nullptr, st);
 }
 
@@ -1678,32 +1646,11 @@ extern "C" int selfocc_msda_cross_bwd(const void *value, const int32_t *shapes, 
         const size_t nb_all = (size_t)cams * heads * bsu.bin.nbands;
         (void)hipMemsetAsync(w.counters, 0, nb_all * 4 * sizeof(int32_t), st);      // cnt and cursor, before the counting kernel
     }
-#define SO_LAUNCH_G(DD, LG)                                                                                  \
-    if (value_dtype == SO_DTYPE_BF16)                                                                        \
-        hipLaunchKernelGGL((msda_cross_bwd_point_kernel<DD, LG, uint16_t>), dim3((unsigned)blocks), dim3(256), hist_bytes, st,  \
-                           (const uint16_t *)value, shapes, starts, ref, vis, off_raw, logits, g_out, g_off, g_logits, \
-                           w.keys, w.recs, cams, dm, count_here ? w.counters : nullptr, bsu.bin);            \
-    else                                                                                                     \
-        hipLaunchKernelGGL((msda_cross_bwd_point_kernel<DD, LG, float>), dim3((unsigned)blocks), dim3(256), hist_bytes, st,     \
-                           (const float *)value, shapes, starts, ref, vis, off_raw, logits, g_out, g_off, g_logits,    \
+#define SO_LAUNCH_VT(DD, LG, VT) \
+        hipLaunchKernelGGL((msda_cross_bwd_point_kernel<DD, LG, VT>), dim3((unsigned)blocks), dim3(256), hist_bytes, st, \
+                           (const VT *)value, shapes, starts, ref, vis, off_raw, logits, g_out, g_off, g_logits, \
                            w.keys, w.recs, cams, dm, count_here ? w.counters : nullptr, bsu.bin)
-#define SO_LAUNCH(DD)                                                                                        \
-    switch (logG) {                                                                                          \
-        case 0: SO_LAUNCH_G(DD, 0); break;                                                                   \
-        case 1: SO_LAUNCH_G(DD, 1); break;                                                                   \
-        case 2: SO_LAUNCH_G(DD, 2); break;                                                                   \
-        case 3: SO_LAUNCH_G(DD, 3); break;                                                                   \
-        case 4: SO_LAUNCH_G(DD, 4); break;                                                                   \
-        case 5: SO_LAUNCH_G(DD, 5); break;                                                                   \
-        default: SO_LAUNCH_G(DD, 6); break;                                                                  \
-    }
-    switch (d) {
-        case 4: SO_LAUNCH(4); break;
-        case 8: SO_LAUNCH(8); break;
-        case 16: SO_LAUNCH(16); break;
-        default: SO_LAUNCH(32); break;
-    }
-#undef SO_LAUNCH
-#undef SO_LAUNCH_G
+    SO_FUSED_DISPATCH(d, logG, value_dtype == SO_DTYPE_BF16);
+#undef SO_LAUNCH_VT
     return so_band_scatter(shapes, starts, g_out, g_value, w, bsu, dm, d, bin_vis, st, count_here);
 }

@@ -900,7 +900,6 @@ inline int rb_env_int(const char *name, int dflt) {
     return (e && *e) ? atoi(e) : dflt;
 }
 inline int rb_chunk() { static const int c = max(256, rb_env_int("SELFOCC_RB_CHUNK", 4096)); return c; }
-inline int rb_threads() { static const int t = rb_env_int("SELFOCC_RB_THREADS", 512); return t; }
 
 inline bool rb_in_range(const so_render_args &a) {
     return a.map.h.tot_len <= 1021 && a.map.w.tot_len <= 1021 && a.map.d.tot_len <= 1021 &&
@@ -948,19 +947,12 @@ int launch_m(const so_render_bwd_args &ba, hipStream_t st) {
     if (int rc = launch_ray<NF, BF16, true>(ba, bin, st)) return rc;
     const int H = a.map.h.tot_len, W = a.map.w.tot_len, D = a.map.d.tot_len;
     const size_t lds = (size_t)kTileVox * RbRec<NF>::RW * 8;
-    const int nt = rb_threads();
-#define SO_B(NT)                                                                                                          \
-    do {                                                                                                                  \
-        static const hipError_t attr = hipFuncSetAttribute((const void *)rb_brick_kernel<NF, NT>,                         \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);         \
-        (void)attr;                                                                                                       \
-        hipLaunchKernelGGL((rb_brick_kernel<NF, NT>), dim3(max_items), dim3(NT), lds, st, bin, ba.g_sdf_vol,              \
-                           ba.g_feat_vol, ba.g_inv_s, H, W, D);                                                           \
-    } while (0)
-    if (nt >= 1024) SO_B(1024);
-    else if (nt >= 512) SO_B(512);
-    else SO_B(256);
-#undef SO_B
+    // 512 threads per item (SELFOCC_RB_THREADS chose among 256 / 512 / 1024 while the kernel was tuned: 512 won at every shape)
+    static const hipError_t attr = hipFuncSetAttribute((const void *)rb_brick_kernel<NF, 512>,
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)attr;
+    hipLaunchKernelGGL((rb_brick_kernel<NF, 512>), dim3(max_items), dim3(512), lds, st, bin, ba.g_sdf_vol, ba.g_feat_vol,
+                       ba.g_inv_s, H, W, D);
     return so_launch_status();
 }
 
@@ -976,7 +968,6 @@ extern "C" size_t selfocc_render_bwd_ws_bytes(const so_render_bwd_args *args) {
         case 0: return rb_layout<0>(a, rb_chunk(), nullptr, nullptr, nullptr);
         case 4: return rb_layout<4>(a, rb_chunk(), nullptr, nullptr, nullptr);
         case 8: return rb_layout<8>(a, rb_chunk(), nullptr, nullptr, nullptr);
-        case 20: return rb_layout<20>(a, rb_chunk(), nullptr, nullptr, nullptr);
         case 24: return rb_layout<24>(a, rb_chunk(), nullptr, nullptr, nullptr);
         default: return 0;
     }
@@ -999,11 +990,12 @@ extern "C" int selfocc_render_bwd(const so_render_bwd_args *args, void *stream) 
     }
     SO_REQUIRE(a.feat_stride == nf, "semantic volumes require feat_stride == n_rgb + n_sem");
     switch (nf) {
-        case 8: return bf ? launch_m<8, true>(ba, st) : launch_m<8, false>(ba, st);
-        case 20: return bf ? launch_m<20, true>(ba, st) : launch_m<20, false>(ba, st);
+        case 8:
+            SO_REQUIRE(!bf, "render_bwd: bfloat16 feature volumes: n_rgb + n_sem must be 3 or 24 (got 8)");
+            return launch_m<8, false>(ba, st);
         case 24: return bf ? launch_m<24, true>(ba, st) : launch_m<24, false>(ba, st);
         default: break;
     }
-    SO_REQUIRE(false, "unsupported n_rgb + n_sem = %d (built: 3, 8, 20, 24)", nf);
+    SO_REQUIRE(false, "unsupported n_rgb + n_sem = %d (built: 3, 8, 24)", nf);
     return -1;
 }

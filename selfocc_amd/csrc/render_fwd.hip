@@ -1146,7 +1146,9 @@ template <int NF, bool BF16>
 int dispatch_ps(const so_render_args &a, hipStream_t st) {
     bool per_sample = a.weights || a.ts || a.deltas || a.sdf || a.grad;
     // training API: the sample-parallel kernel of render_train.hip (a lane per sample, canonical arithmetic)
-    if (per_sample && !(a.flags & SO_FLAG_RAY_PER_LANE)) return so_render_fwd_samples<NF, BF16>(a, st);
+    // (SO_FLAG_RAY_PER_LANE, the A/B route of rounds 2 - 4 through ray-per-lane per-sample kernels, is accepted and ignored
+    // since ABI v30: 48 instantiations nobody shipped)
+    if (per_sample) return so_render_fwd_samples<NF, BF16>(a, st);
     // the fast path needs g(t) affine in t: no jitter, single-segment axes
     bool fast = !(a.flags & SO_FLAG_EXACT) && a.jitter_mode == SO_JITTER_NONE &&
                 a.map.h.size1 == 0.0f && a.map.w.size1 == 0.0f && a.map.d.size1 == 0.0f &&
@@ -1162,11 +1164,10 @@ int dispatch_ps(const so_render_args &a, hipStream_t st) {
             if (!per_sample && a.sdf_brick && !(a.flags & (SO_FLAG_NO_SKIP | SO_FLAG_NO_AHEAD)))
                 return (a.flags & SO_FLAG_NO_FACE_SAFE) ? launch_fwd<0, false, false, 3>(a, st) : launch_fwd<0, false, false, 4>(a, st);
         }
-        if (!(a.flags & SO_FLAG_NO_FACE_SAFE))
-            return per_sample ? launch_fwd<NF, BF16, true, 2>(a, st) : launch_fwd<NF, BF16, false, 2>(a, st);
-        return per_sample ? launch_fwd<NF, BF16, true, 1>(a, st) : launch_fwd<NF, BF16, false, 1>(a, st);
+        if (!(a.flags & SO_FLAG_NO_FACE_SAFE)) return launch_fwd<NF, BF16, false, 2>(a, st);
+        return launch_fwd<NF, BF16, false, 1>(a, st);
     }
-    return per_sample ? launch_fwd<NF, BF16, true, 0>(a, st) : launch_fwd<NF, BF16, false, 0>(a, st);
+    return launch_fwd<NF, BF16, false, 0>(a, st);
 }
 
 }  // namespace
@@ -1225,11 +1226,12 @@ extern "C" int selfocc_render_fwd(const so_render_args *args, void *stream) {
     }
     SO_REQUIRE(a.feat_stride == nf, "semantic volumes require feat_stride == n_rgb + n_sem");
     switch (nf) {
-        case 8: return bf ? dispatch_ps<8, true>(a, st) : dispatch_ps<8, false>(a, st);
-        case 20: return bf ? dispatch_ps<20, true>(a, st) : dispatch_ps<20, false>(a, st);
+        case 8:      // (bfloat16 storage is built for the shipped widths 4 and 24 only)
+            SO_REQUIRE(!bf, "bfloat16 feature volumes: n_rgb + n_sem must be 3 or 24 (got 8)");
+            return dispatch_ps<8, false>(a, st);
         case 24: return bf ? dispatch_ps<24, true>(a, st) : dispatch_ps<24, false>(a, st);
         default: break;
     }
-    SO_REQUIRE(false, "unsupported n_rgb + n_sem = %d (built: 3, 8, 20, 24)", nf);
+    SO_REQUIRE(false, "unsupported n_rgb + n_sem = %d (built: 3, 8, 24)", nf);
     return -1;
 }

@@ -343,8 +343,5 @@ template int so_render_fwd_samples<0, false>(const so_render_args &, hipStream_t
 template int so_render_fwd_samples<4, false>(const so_render_args &, hipStream_t);
 template int so_render_fwd_samples<4, true>(const so_render_args &, hipStream_t);
 template int so_render_fwd_samples<8, false>(const so_render_args &, hipStream_t);
-template int so_render_fwd_samples<8, true>(const so_render_args &, hipStream_t);
-template int so_render_fwd_samples<20, false>(const so_render_args &, hipStream_t);
-template int so_render_fwd_samples<20, true>(const so_render_args &, hipStream_t);
 template int so_render_fwd_samples<24, false>(const so_render_args &, hipStream_t);
 template int so_render_fwd_samples<24, true>(const so_render_args &, hipStream_t);

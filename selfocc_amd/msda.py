@@ -323,7 +323,7 @@ class MSDAFusedFunction(torch.autograd.Function):
 def msda_fused_supported(host_shapes, bs, nq, heads, d, L, P):
     """True when the fused training op applies (banded scatter possible, L * P <= 256)."""
     import ctypes
-    if L * P > 256 or L > 8 or d not in (4, 8, 16, 32):
+    if L * P > 256 or L > 8 or d not in (8, 16, 32):          # the fused / camera-loop kernels are built for 8, 16, 32 channels per head
         return False
     arr = (ctypes.c_int32 * len(host_shapes))(*host_shapes)
     return lib().selfocc_msda_banded_supported(ctypes.cast(arr, ctypes.c_void_p), bs, nq, heads, d, L, P) == 1

@@ -119,7 +119,7 @@ class RenderConfig:
     skip: bool = True                 # fast path + brick: composite saturated free-space samples without interpolating
     face_safe: bool = True            # fast path: canonical cell selection within a few ulp of a voxel face (~6 % slower)
     ahead: bool = True                # SDF-only per-ray launches with brick + skip: code-ahead skip marcher (A/B)
-    ray_per_lane: bool = False        # per-sample launches through the ray-per-lane kernels (A/B; default: sample-parallel)
+    ray_per_lane: bool = False        # ignored since ABI 30 (was: per-sample launches through ray-per-lane kernels, an A/B switch)
     bwd_scatter: str = 'auto'         # backward: 'binned' = brick-binned LDS scatter of the volume gradients (needs a scratch
                                       # of ~(record + 8) bytes per sample), 'atomic' = per-sample row atomics, 'auto' = binned
                                       # from 2^19 samples per launch — measured cross-over 0.4 - 0.5 M samples at 25 channels, scripts/time_render_bwd_sizes.py

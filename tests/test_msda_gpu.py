@@ -355,7 +355,7 @@ def test_msda_head_major_value_layout(hip, P, L, D):
         assert torch.allclose(x, y, rtol=1e-5, atol=1e-5 * y.abs().max().item())
 
 
-@pytest.mark.parametrize("P,L,D", [(8, 4, 16), (48, 4, 16), (5, 2, 8), (3, 1, 32)])
+@pytest.mark.parametrize("P,L,D", [(8, 4, 16), (48, 4, 16), (12, 3, 16)])     # bf16 `value` is built for 16 channels per head (the shipped lifters)
 def test_msda_bf16_value_storage(hip, P, L, D):
     """value_dtype = SO_DTYPE_BF16 (bfloat16 STORAGE of value, float32 arithmetic): the fused and camera-loop ops give
     exactly what the float32 kernels give on bf16-rounded values (forward: same bits; backward: same gradients, g_value

@@ -21,7 +21,7 @@ def _rel_l2(a, b):
 @pytest.mark.parametrize("scatter", ["atomic", "binned"])
 @pytest.mark.parametrize("n_rgb,n_sem,jitter,sample_pos,S", [
     (0, 0, abi.JITTER_NONE, 0, 32), (3, 0, abi.JITTER_SINGLE, 1, 32), (3, 5, abi.JITTER_PER_BIN, 0, 32),
-    (3, 21, abi.JITTER_NONE, 0, 100), (3, 0, abi.JITTER_NONE, 0, 256), (3, 17, abi.JITTER_SINGLE, 0, 300)])
+    (3, 21, abi.JITTER_NONE, 0, 100), (3, 0, abi.JITTER_NONE, 0, 256), (3, 21, abi.JITTER_SINGLE, 0, 300)])
 def test_render_backward_vs_float64_autograd(hip, n_rgb, n_sem, jitter, sample_pos, S, scatter):
     vol = sy.make_volume("cfg1", n_rgb=n_rgb, n_sem=n_sem, seed=11, noise=0.02)
     ex = sy.explicit_rays(sy.make_rays("cfg1", seed=11))
@@ -243,10 +243,10 @@ def test_render_backward_binned_vs_atomic_at_training_shape(hip, n_rgb, n_sem):
     assert abs(b[2].item() - a[2].item()) <= 1e-3 * abs(a[2].item()) + 1e-6
 
 
-@pytest.mark.parametrize("n_sem,S", [(0, 32), (5, 100), (21, 300)])
+@pytest.mark.parametrize("n_sem,S", [(0, 32), (21, 100), (21, 300)])
 def test_render_backward_binned_vs_atomic_bf16_features(hip, n_sem, S):
     """bfloat16 STORAGE of the feature volume (gradients stay float32): the brick-binned scatter and the per-sample atomics
-    agree at every instantiation the bf16 launch table holds (4 / 8 / 24 channels; one and four waves per ray, M = 1 / 2)."""
+    agree at every instantiation the bf16 launch table holds (4 / 24 channels; one and four waves per ray, M = 1 / 2)."""
     vol = sy.make_volume("cfg1", n_rgb=3, n_sem=n_sem, feat_dtype=torch.bfloat16, seed=5, noise=0.02).to(D0)
     ex = sy.explicit_rays(sy.make_rays("cfg1", seed=5))
     rg = RaySet(origins=ex.origins.to(D0), dirs=ex.dirs.to(D0), dir_norm=ex.dir_norm.to(D0))

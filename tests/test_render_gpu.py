@@ -148,10 +148,10 @@ def test_cfg1_pixel_grid_vs_oracle(hip, n_rgb, n_sem, feat_dtype, sample_pos, ex
     else:
         loose = {} if exact is False else dict(max_rel=1.0, acc_abs=1.0, depth_abs_over_far=1.0)
         parity_report(got_e, ref, label=f"cfg1 eval launch {exact}", strict=(exact is False), **loose)
-        # A/B switch: per-sample outputs through the ray-per-lane kernels of this mode
+        # SO_FLAG_RAY_PER_LANE is accepted and ignored since ABI 30: the launch still returns the sample-parallel kernel's outputs
         from dataclasses import replace
         got_l = render_rays(vol.to(d), rg, replace(cfg, ray_per_lane=True), per_sample=True, want_grad_samples=True)
-        _cmp_fast(got_l, ref, vol, rays, cfg, same_cells=(exact is False))
+        assert torch.equal(got_l['weights'], got['weights']) and torch.equal(got_l['sdf'], got['sdf'])
 
 
 def test_explicit_rays_and_jitter(hip):
