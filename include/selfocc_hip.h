@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SELFOCC_ABI_VERSION 30
+#define SELFOCC_ABI_VERSION 31
 
 int selfocc_abi_version(void);
 const char *selfocc_last_error(void);
@@ -249,37 +249,6 @@ int selfocc_msda_cross_fwd(const void *value, const int32_t *shapes, const int32
                            float *out, int32_t cams, int32_t nv, int32_t nq, int32_t heads, int32_t d,
                            int32_t L, int32_t P, int32_t value_stride, int32_t value_layout, int32_t value_dtype,
                            void *stream);
-
-/* Deformable attention with its two query linears in the prologue (inference; csrc/msda_pro.hip): computes
- *     off = x W_off^T + b_off, logits = x W_aw^T + b_aw     (the reference's sampling_offsets / attention_weights Linears,
- *     model/encoder/bevformer/attention/image_cross_attention.py:296-312, tpvformer/attention/cross_view_hybrid_attention.py:78-92)
- * for the 16 queries of a wave tile with f32 MFMA inside the sampling kernel and feeds them to the fused sampling stage
- * of selfocc_msda_fused_fwd (vis == NULL: ref / ref_kind as there, `cams` ignored) or selfocc_msda_cross_fwd (vis != NULL:
- * ref (cams, nq, P, 2), vis (cams, nq), bs must be 1) without writing them to memory.
- *   x (bs * nq, K) float32 row-major; W_off (heads*L*P*2, K), b_off, W_aw (heads*L*P, K), b_aw: nn.Linear layout.
- * Supported (selfocc_msda_pro_supported): d = 16, K = 96 and 80 < 3 L P <= 112 — one head's weight slice must sit in
- * LDS next to 16 result tiles (the hw-plane cross-attention and the cross-view self-attention of the shipped configs).
- * value / value_stride / value_layout / value_dtype as for selfocc_msda_cross_fwd.  out (bs * nq, heads * d). */
-int selfocc_msda_pro_supported(int32_t heads, int32_t d, int32_t L, int32_t P, int32_t K);
-int selfocc_msda_pro_fwd(const void *value, const int32_t *shapes, const int32_t *starts, const float *ref,
-                         int32_t ref_kind, const uint8_t *vis, const float *x, const float *w_off, const float *b_off,
-                         const float *w_aw, const float *b_aw, float *out, int32_t cams, int32_t bs, int32_t nv,
-                         int32_t nq, int32_t heads, int32_t d, int32_t L, int32_t P, int32_t K, int32_t value_stride,
-                         int32_t value_layout, int32_t value_dtype, void *stream);
-
-/* selfocc_msda_cross_fwd for head-major float32 `value` with the coarse FPN levels staged in LDS (csrc/msda_lds.hip): the
- * work is cut per (camera, head) pair, a block keeps the pair's levels >= l0 (the largest tail of levels that fits
- * 128 KB: 24x50 + 12x25 pixels at the shipped size) in LDS and gathers those levels with ds_read_b128, the fine levels
- * from global memory as before; per-camera results go to `workspace` (selfocc_msda_cross_lds_workspace bytes) and are
- * summed in camera order / divided by the visible-camera count by a second kernel.  Same results as
- * selfocc_msda_cross_fwd up to the association of the camera sum.  Supported: d = 16, L <= 4, 33 <= P <= 64 (one
- * (query, head) group per wavefront: the zh / wz planes).  host_shapes: HOST copy of `shapes`. */
-int selfocc_msda_cross_lds_supported(const int32_t *host_shapes, int32_t heads, int32_t d, int32_t L, int32_t P);
-size_t selfocc_msda_cross_lds_workspace(int32_t cams, int32_t nq, int32_t heads, int32_t d);
-int selfocc_msda_cross_lds_fwd(const float *value, const int32_t *shapes, const int32_t *starts, const int32_t *host_shapes,
-                               const float *ref, const uint8_t *vis, const float *off_raw, const float *logits, float *out,
-                               int32_t cams, int32_t nv, int32_t nq, int32_t heads, int32_t d, int32_t L, int32_t P,
-                               void *workspace, size_t workspace_bytes, void *stream);
 
 /* Training counterpart of selfocc_msda_cross_fwd: g_out (nq, heads*d) is the gradient of the camera MEAN;
  * returns g_value (cams,nv,heads,d; zero-initialised by the caller), g_off (nq,heads,L,P,2) and

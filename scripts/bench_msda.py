@@ -7,8 +7,7 @@ API-visible output byte once — against the 8 TB/s HBM peak.
     plain     value + loc + attw + out                       (selfocc_msda_fwd / _bwd_banded)
     fused     value + ref + off_raw + logits + out           (selfocc_msda_fused_fwd / _fused_bwd)
     cross     value + ref + vis + off_raw + logits + out     (selfocc_msda_cross_fwd / _cross_bwd, camera loop)
-    pro       value + ref [+ vis] + query + W + out          (selfocc_msda_pro_fwd: the offset / weight linears in the
-              kernel prologue — off_raw / logits never exist; beside it the separate route it replaces, linears included)
+    linears + kernel: the route the eval encoder takes (the two query Linears through selfocc_linear_fwd, then the kernel)
 `--json`: one JSON object on the last line (bench.py's "roofline_msda").  `--case NAME`: one of the three shapes only
 (scripts/pmc_msda_rows.sh profiles each shape in its own rocprofv3 session, so that a kernel's counters belong to one shape).
 Every row also carries the texture-path view: `l1_gather_frac` (computed here) and — from profiles/pmc_msda.json, the
@@ -17,7 +16,7 @@ import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from selfocc_amd.msda import (MultiScaleDeformableAttnFunction as F, MSDAFusedFunction, MSDACrossFunction,
-                              msda_fused_inference, msda_cross_inference, to_head_major, msda_pro_inference, msda_pro_supported)
+                              msda_fused_inference, msda_cross_inference, to_head_major)
 from selfocc_amd.linear import linear_fwd
 
 PEAK = 8000.0
@@ -64,7 +63,7 @@ try:
 except OSError:
     PMC = {}
 # row label -> the HIP kernels it launches (function names; the gathers are in the first one)
-HIP_KERNELS = (("msda_pro_fwd", ["msda_pro_fwd_kernel"]), ("linears + msda_cross_fwd", ["msda_cross_fwd_kernel"]),
+HIP_KERNELS = (("linears + msda_cross_fwd", ["msda_cross_fwd_kernel"]),
                ("linears + msda_fused_fwd", ["msda_fused_fwd_kernel"]),
                ("msda_cross_bwd", ["msda_cross_bwd_point_kernel", "msda_bwd_band_list_kernel"]), ("msda_cross_fwd", ["msda_cross_fwd_kernel"]),
                ("msda_fused_bwd", ["msda_fused_bwd_point_kernel", "msda_bwd_band_list_kernel"]), ("msda_fused_fwd", ["msda_fused_fwd_kernel"]),
@@ -159,8 +158,8 @@ for name, (bs, nq, shapes, P) in CASES.items():
         rows.append(rec("msda_fused_fwd head-major", tag, alg_ff, fh_ms, pts))
         fhb_ms = time_bwd(lambda: MSDAFusedFunction.apply(val_h, sh, st, ref, 0, off_d, lg_d, sh._so_host, True), g)
         rows.append(rec("msda_fused_bwd head-major point+band (incl. grad_value memset)", tag, alg_fb, fhb_ms, pts))
-        if bs == 1 and msda_pro_supported(H, D, L, P, 96):
-            # ---- the two query linears in the kernel prologue vs the separate route (linears + fused kernel) ----
+        if bs == 1 and 80 < 3 * L * P <= 112:
+            # ---- the eval encoder's route: the two query linears + the fused kernel ----
             xq, lo, la = query_linears(nq, H, L, P)
             with torch.no_grad():
                 def separate():
@@ -168,12 +167,9 @@ for name, (bs, nq, shapes, P) in CASES.items():
                     lgt = linear_fwd(xq, la.weight, la.bias).view(1, nq, H, L * P)
                     return msda_fused_inference(val_h, sh, st, ref, 0, o, lgt, True)
                 sep_ms = timeit(separate)
-                pro_ms = timeit(lambda: msda_pro_inference(val_h, sh, st, ref, 0, xq[None], lo, la, L, P, True))
             wbytes = 4 * (lo.weight.numel() + la.weight.numel() + lo.bias.numel() + la.bias.numel())
             alg_sep = alg_ff + 4 * xq.numel() + wbytes + 4 * (off_raw.numel() + logits.numel())   # off / logits written once more
-            alg_pro = 4 * (value.numel() + ref.numel() + xq.numel() + out.numel()) + wbytes
             rows.append(rec("linears + msda_fused_fwd head-major (separate route)", tag, alg_sep, sep_ms, pts))
-            rows.append(rec("msda_pro_fwd head-major (linears in the prologue)", tag, alg_pro, pro_ms, pts))
     except Exception as e:   # a shape the fused / banded path does not take: keep the other rows
         rows.append(dict(kernel="msda_fused", shape=tag, error=repr(e)[:200]))
     if name == "cross_hw":
@@ -207,7 +203,7 @@ for name, (bs, nq, shapes, P) in CASES.items():
         rows.append(rec("msda_cross_fwd head-major", tagc, alg_c, ch_ms, ptsc))
         chb_ms = time_bwd(lambda: MSDACrossFunction.apply(val_h, sh, st, refc, vis, offc, lgc, sh._so_host, True), gc)
         rows.append(rec("msda_cross_bwd head-major point+band (incl. grad_value memset)", tagc, alg_cb, chb_ms, ptsc))
-        if msda_pro_supported(H, D, L, P, 96):
+        if True:
             xq, lo, la = query_linears(nq_full, H, L, P)
             with torch.no_grad():
                 def separate_c():
@@ -215,12 +211,9 @@ for name, (bs, nq, shapes, P) in CASES.items():
                     lgt = linear_fwd(xq, la.weight, la.bias).view(nq_full, H, L * P)
                     return msda_cross_inference(val_h, sh, st, refc, vis, o, lgt, True)
                 sepc_ms = timeit(separate_c)
-                proc_ms = timeit(lambda: msda_pro_inference(val_h, sh, st, refc, 1, xq, lo, la, L, P, True, visible=vis))
             wbytes = 4 * (lo.weight.numel() + la.weight.numel() + lo.bias.numel() + la.bias.numel())
             alg_sepc = alg_c + 4 * xq.numel() + wbytes + 4 * (offc.numel() + lgc.numel())
-            alg_proc = 4 * (value.numel() + refc.numel() + xq.numel() + outc) + vis.numel() + wbytes
             rows.append(rec("linears + msda_cross_fwd head-major (separate route)", tagc, alg_sepc, sepc_ms, ptsc))
-            rows.append(rec("msda_pro_fwd camera loop head-major (linears in the prologue)", tagc, alg_proc, proc_ms, ptsc))
     for r in rows[-16:]:
         if name in r["shape"] or "camera loop" in r["shape"]:
             print(json.dumps(r), flush=True)

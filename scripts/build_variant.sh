@@ -6,7 +6,7 @@ name=$1; src=$2; shift 2
 cd "$(dirname "$0")/../selfocc_amd/csrc"
 bash build.sh > /dev/null
 mkdir -p _obj/_$name
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fno-vectorize -Wall -Wno-unused-function \
   "$@" -c "$src" -o _obj/_$name/${src%.hip}.o
 objs=$(ls _obj/*.o | grep -v "/${src%.hip}.o")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs _obj/_$name/${src%.hip}.o -o ../libselfocc_hip_$name.so

@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage (GPU box): scripts/pmc_msda_l1.sh [tag]  -> vector-L1 (TCP) / TA counters of the MSDA forward kernels inside the eval encoder
-#   (env SELFOCC_MSDA_PROLOGUE=0 / SELFOCC_MSDA_LDS=1 select the variants)
+#   (the prologue-fused and LDS-staged variants this script once compared were removed in round 5)
 R=${GRAFT_REPO_ROOT:-$(pwd)}; TAG=${1:-l1}; cd /tmp; export TMPDIR=/tmp; rm -rf $R/gpurun_out/pmc_$TAG
 i=0
 for pass in "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "TCP_TOTAL_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum" \
@@ -15,7 +15,7 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob("$R/gpurun_out/pmc_$TAG/p*/p_counter_collection.csv")):
     for r in csv.DictReader(open(f)):
         n = r['Kernel_Name']
-        m = re.search(r'(msda_\w+_kernel<[^>]*>|msda_pro_fwd_kernel<[^>]*>|render_fwd_pixgrid<[^>]*>|linear_fwd16_kernel<[^>]*>)', n)
+        m = re.search(r'(msda_\w+_kernel<[^>]*>|render_fwd_pixgrid<[^>]*>|linear_fwd16_kernel<[^>]*>)', n)
         if m:
             agg[m.group(1)][r['Counter_Name']].append(float(r['Counter_Value']))
 for k, d in sorted(agg.items()):

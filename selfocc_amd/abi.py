@@ -6,7 +6,7 @@ its exported symbols being callable with these layouts.
 """
 import ctypes as C
 
-ABI_VERSION = 30
+ABI_VERSION = 31
 
 # enums ---------------------------------------------------------------------------
 RAYS_EXPLICIT, RAYS_PIXEL_GRID = 0, 1
@@ -110,11 +110,6 @@ SYMBOLS = {
     "selfocc_msda_fwd": (C.c_int, [_p, _p, _p, _p, _p, _p] + [_i] * 7 + [_p]),
     "selfocc_msda_fused_fwd": (C.c_int, [_p, _p, _p, _p, _i, _p, _p, _p] + [_i] * 9 + [_p]),
     "selfocc_msda_cross_fwd": (C.c_int, [_p] * 8 + [_i] * 10 + [_p]),
-    "selfocc_msda_pro_supported": (C.c_int, [_i] * 5),
-    "selfocc_msda_pro_fwd": (C.c_int, [_p] * 4 + [_i] + [_p] * 7 + [_i] * 12 + [_p]),
-    "selfocc_msda_cross_lds_supported": (C.c_int, [_p] + [_i] * 4),
-    "selfocc_msda_cross_lds_workspace": (C.c_size_t, [_i] * 4),
-    "selfocc_msda_cross_lds_fwd": (C.c_int, [_p] * 9 + [_i] * 7 + [_p, C.c_size_t, _p]),
     "selfocc_msda_cross_bwd": (C.c_int, [_p] * 12 + [_i] * 9 + [_p, C.c_size_t, _p]),
     "selfocc_msda_bwd": (C.c_int, [_p] * 9 + [_i] * 7 + [_p]),
     "selfocc_msda_banded_supported": (C.c_int, [_p] + [_i] * 6),

@@ -1,4 +1,4 @@
-// msda_device.h — device-side building blocks shared by msda.hip and msda_pro.hip (included inside an anonymous
+// msda_device.h — device-side building blocks of msda.hip (included inside an anonymous
 // namespace by each translation unit): value addressing, the bilinear point set-up, channel-team gathers,
 // inside-point compaction and the group reduce-scatter.  See the header of msda.hip for the hardware mapping.
 #pragma once
@@ -191,24 +191,32 @@ SO_DEVFN float4 so_ld4(const uint16_t *p) {
                        __uint_as_float(t.y & 0xffff0000u));
 }
 
-// the team adds the point owned by its sub-lane I: acc[0..3] are this lane's 4 channels
+// the team adds the point owned by its sub-lane I: acc[0..3] are this lane's 4 channels.
+// The 4-channel FMAs are written as two explicit 2-wide ones (v_pk_fma_f32 with the scalar weight broadcast from the low half,
+// op_sel_hi:[0,1,1]): the library is built WITHOUT the compiler's vectorizers (csrc/build.sh: the half-swapping op_sel forms
+// they produce are not safe beside bf16 MFMA waves on gfx950), and this loop is the one place where the packed rate is worth
+// having back (msda_cross_fwd 0.52 -> 0.45 ms at the shipped hw-plane size).  Only the broadcast / straight forms are used
+// here; tests/test_isa_lint.py checks the built library for any other.
+typedef float so_f32x2 __attribute__((ext_vector_type(2)));
 template <int D, int I, typename VT>
 SO_DEVFN void so_team_step(const VT *vb, const MsdaPoint &mp, float (&acc)[4]) {
     constexpr int QL = D / 4;
     const float aw = so_team_bcastf<QL, I>(mp.aw);
-    float val[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    so_f32x2 v01 = {0.0f, 0.0f}, v23 = {0.0f, 0.0f};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int off = so_team_bcast<QL, I>(mp.off[k]);
         const float w = so_team_bcastf<QL, I>(mp.w[k]);
         const float4 t = so_ld4(vb + off);
-        val[0] = fmaf(w, t.x, val[0]);
-        val[1] = fmaf(w, t.y, val[1]);
-        val[2] = fmaf(w, t.z, val[2]);
-        val[3] = fmaf(w, t.w, val[3]);
+        const so_f32x2 ww = {w, w}, t01 = {t.x, t.y}, t23 = {t.z, t.w};
+        v01 = __builtin_elementwise_fma(ww, t01, v01);
+        v23 = __builtin_elementwise_fma(ww, t23, v23);
     }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[c] = fmaf(aw, val[c], acc[c]);
+    const so_f32x2 aa = {aw, aw};
+    so_f32x2 a01 = {acc[0], acc[1]}, a23 = {acc[2], acc[3]};
+    a01 = __builtin_elementwise_fma(aa, v01, a01);
+    a23 = __builtin_elementwise_fma(aa, v23, a23);
+    acc[0] = a01[0]; acc[1] = a01[1]; acc[2] = a23[0]; acc[3] = a23[1];
 }
 
 // Whole-wave / half-wave groups: move the points that touch the map to the front of their group, dealt round-robin over
@@ -299,6 +307,7 @@ SO_DEVFN void so_team_gather(const VT *vb, const MsdaPoint &mp, float (&acc)[4])
 // Sum acc[4] over the 2^NJ teams of a group (team index j = lane bits SHIFT .. SHIFT + NJ - 1) and
 // store: a reduce-scatter (the first two exchanges halve the vector, bit i of j choosing the half a
 // lane keeps), then plain butterflies.  Lanes with (j >> STEPS) == 0 end up with 4 >> STEPS channels.
+
 template <int NJ, int SHIFT>
 SO_DEVFN void so_group_reduce_store(float (&acc)[4], int j, bool live, float *o4) {
     constexpr int STEPS = NJ < 2 ? NJ : 2;

@@ -22,6 +22,8 @@ with NO data-path collective:
 ``NeuSHead(ray_shard=True)`` (or SELFOCC_RAY_SHARD=1) switches the head to this mode; bench.py
 ``--shard rays`` times it.  The reference itself only has frame-per-GPU DDP (train.py:86-91).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -322,18 +324,48 @@ def gather_plane_rows(loc, shard, reduce_grad=True):
     return _gather_plane_rows(loc, shard)
 
 
+_PENDING = []          # all-reduces of parameter gradients launched during the running backward pass
+OVERLAP_STATS = {'deferred': 0, 'synchronous': 0}
+
+
+def _flush_pending():
+    """end-of-backward callback: the compute stream waits for every deferred all-reduce (a stream dependency, no host block
+    on RCCL), so the optimiser / clip_grad_norm_ that follows sees reduced gradients"""
+    while _PENDING:
+        _PENDING.pop().wait()
+
+
 class _GroupGradSum(torch.autograd.Function):
     """Identity on a group of (parameter) tensors; backward = ONE coalesced all-reduce(sum) of all their gradients: under
-    row sharding a rank's parameter gradients cover its own rows only."""
+    row sharding a rank's parameter gradients cover its own rows only.
+
+    Overlap (round 5): nothing reads a layer's parameter gradients before the backward pass is over, so the all-reduce is
+    launched ``async_op=True`` and only waited for in an end-of-backward callback — it runs on the collective stream beside
+    the previous layers' backward kernels (59 MB per iteration at the shipped size: 4 layers x 1.83 M parameters x 4 B + the
+    lifter / positional tensors).  Deferred only when no parameter of the group already holds a ``.grad`` (gradient
+    accumulation would add into a tensor that is still being reduced) and the backend reduces device memory itself.
+    The all-gather of a layer's rows and the all-reduce of the gathered planes' gradients (``gather_plane_rows``) stay
+    synchronous: the next layer's first op (cross-view self-attention over the FULL planes) / the previous layer's backward
+    consume them immediately."""
 
     @staticmethod
     def forward(ctx, *ts):
+        ctx.defer = all(t.grad is None for t in ts)
         return tuple(t.view_as(t) for t in ts)
 
     @staticmethod
     def backward(ctx, *gs):
         flat = torch.cat([g.reshape(-1).float() for g in gs])
-        _all_reduce_(flat)
+        staged = flat.is_cuda and dist.get_backend() == 'gloo'          # test rigs: gloo cannot reduce device memory
+        if ctx.defer and not staged and os.environ.get('SELFOCC_DIST_OVERLAP', '1') != '0':
+            work = dist.all_reduce(flat, async_op=True)
+            if not _PENDING:
+                torch.autograd.Variable._execution_engine.queue_callback(_flush_pending)
+            _PENDING.append(work)
+            OVERLAP_STATS['deferred'] += 1
+        else:
+            _all_reduce_(flat)
+            OVERLAP_STATS['synchronous'] += 1
         out, off = [], 0
         for g in gs:
             n = g.numel()

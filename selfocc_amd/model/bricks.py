@@ -14,7 +14,6 @@ from ..dropout import dropout_add
 from ..linear import (linear_wgrad, wgrad_supported, linear_fwd, linear_fwd_supported, linear_fwd_heads, linear_dgrad, dgrad_supported,
                       linear_fwd_heads_supported)
 from ..msda import (MultiScaleDeformableAttnFunction, msda_fused_inference, MSDAFusedFunction, to_head_major,
-                    msda_pro_supported, msda_pro_inference,
                     msda_fused_supported)
 
 
@@ -439,10 +438,6 @@ FUSED_FFN_RELU = os.environ.get('SELFOCC_FUSED_FFN_RELU', '1') == '1'
 FUSED_DROPOUT_ADD = os.environ.get('SELFOCC_FUSED_DROPOUT', '1') == '1'
 # training path of deformable_sampling: fused prologue + MSDA in both directions (msda.MSDAFusedFunction)
 FUSED_TRAINING = True
-# inference: the sampling_offsets / attention_weights Linears inside the sampling kernel's prologue (csrc/msda_pro.hip)
-# where a head's weight slice fits LDS (hw-plane cross-attention, cross-view self-attention); env SELFOCC_MSDA_PROLOGUE=0
-PROLOGUE_FUSED = os.environ.get('SELFOCC_MSDA_PROLOGUE', '1') == '1'
-PROLOGUE_MIN_ROWS = 1024
 # True: the fused / camera-loop kernels gather from a head-major copy of the projected value, (bs, heads, nv, d), where a
 # cache line holds x-neighbours of one head.  Measured: camera-loop forward 0.87 -> 0.73 ms, fused
 # forward 0.50 -> 0.47 ms, but the transposing copy per call costs more than that (eval encoder 12.5 -> 12.9 ms), so
@@ -485,24 +480,6 @@ def deformable_sampling(module, query, value, reference_points, spatial_shapes, 
         raise ValueError('Last dim of reference_points must be 2 on the SelfOcc path, '
                          f'got {reference_points.shape[-1]}')
     LP = module.num_levels * module.num_points
-    if (PROLOGUE_FUSED and not torch.is_grad_enabled() and query.is_cuda and query.dtype == torch.float32
-            and not torch.is_autocast_enabled() and bs * num_query >= PROLOGUE_MIN_ROWS
-            and isinstance(module.sampling_offsets, nn.Linear) and module.sampling_offsets.bias is not None
-            and module.attention_weights.bias is not None):
-        d_head = (v_hm[0].shape[-1] if v_hm is not None else value.shape[-1])
-        if msda_pro_supported(module.num_heads, d_head, module.num_levels, module.num_points, query.shape[-1]):
-            # inference, shipped self-attention / hw-plane shapes: the two linears run inside the sampling kernel
-            kind = {'level': 0, 'point': 1, 'level_point': 2}[per_level_reference]
-            hm = HEAD_MAJOR_VALUE
-            if v_hm is not None:
-                value, hm = v_hm.view(v_hm.shape[1:]), True      # G = 1: a view (select's backward is a zero fill + a copy)
-            elif HEAD_MAJOR_VALUE:
-                value = to_head_major(value)
-            if VALUE_BF16:
-                value = value.to(torch.bfloat16)
-            return msda_pro_inference(value, spatial_shapes, level_start_index, reference_points, kind, query,
-                                      module.sampling_offsets, module.attention_weights, module.num_levels,
-                                      module.num_points, hm)
     off = module.sampling_offsets(query).view(bs, num_query, module.num_heads, module.num_levels,
                                               module.num_points, 2)
     if not torch.is_grad_enabled() and LP <= 256:

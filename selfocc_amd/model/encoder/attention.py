@@ -16,8 +16,7 @@ import torch.nn as nn
 from ...registry import MODELS, build_attention
 from ..bricks import (BaseModule, MultiScaleDeformableAttention, TallLinear, constant_init, xavier_init,
                       deformable_sampling, fused_linear)
-from ...msda import (msda_cross_inference, MSDACrossFunction, msda_fused_supported, to_head_major, msda_pro_supported,
-                     msda_pro_inference)
+from ...msda import msda_cross_inference, MSDACrossFunction, msda_fused_supported, to_head_major
 from .. import bricks
 
 
@@ -190,22 +189,15 @@ class BEVCrossAttention(BaseModule):
         visible = vis_all[:, 0] if vis_all is not None else bev_masks[:, 0].any(-1)   # (cams, Q), batch element 0 as the reference
         if bricks.VALUE_BF16 and host_shapes is None and v.dtype != torch.bfloat16:
             v = v.to(torch.bfloat16)
-        if (host_shapes is None and bricks.PROLOGUE_FUSED and query.dtype == torch.float32 and not torch.is_autocast_enabled()
-                and query.shape[1] >= bricks.PROLOGUE_MIN_ROWS and da.sampling_offsets.bias is not None
-                and da.attention_weights.bias is not None and msda_pro_supported(heads, v.shape[-1], L, P, query.shape[-1])):
-            # hw plane: the offset / weight linears run in the camera-loop kernel's prologue (csrc/msda_pro.hip)
-            slots = msda_pro_inference(v, spatial_shapes, level_start_index, reference_points_cams[:, 0], 1, query[0],
-                                       da.sampling_offsets, da.attention_weights, L, P, hm, visible=visible)[None]
+        q2 = query.reshape(-1, query.shape[-1])   # bs == 1; a view, not query[0]: select's backward is a zero fill + a copy
+        off = da.sampling_offsets(q2).view(-1, heads, L, P, 2)
+        logits = da.attention_weights(q2).view(-1, heads, L * P)
+        if host_shapes is None:
+            slots = msda_cross_inference(v, spatial_shapes, level_start_index, reference_points_cams[:, 0], visible,
+                                         off, logits, hm)[None]
         else:
-            q2 = query.reshape(-1, query.shape[-1])   # bs == 1; a view, not query[0]: select's backward is a zero fill + a copy
-            off = da.sampling_offsets(q2).view(-1, heads, L, P, 2)
-            logits = da.attention_weights(q2).view(-1, heads, L * P)
-            if host_shapes is None:
-                slots = msda_cross_inference(v, spatial_shapes, level_start_index, reference_points_cams[:, 0], visible,
-                                             off, logits, hm)[None]
-            else:
-                slots = MSDACrossFunction.apply(v, spatial_shapes, level_start_index, reference_points_cams[:, 0], visible,
-                                                off, logits, host_shapes, hm, bricks.VALUE_BF16)[None]
+            slots = MSDACrossFunction.apply(v, spatial_shapes, level_start_index, reference_points_cams[:, 0], visible,
+                                            off, logits, host_shapes, hm, bricks.VALUE_BF16)[None]
         if not self.training and not torch.is_grad_enabled():
             # eval: dropout is the identity; output_proj + residual (+ the layer's next norm) in one launch, written
             # straight into the caller's slice of the concatenated plane buffer (`out`)

@@ -514,6 +514,9 @@ class TPVFormerEncoder(_EncoderBase):
         from torch.func import functional_call
         H, W, Z = self.tpv_size
         sizes = [H * W, Z * H, W * Z]
+        if tpv_query[0].shape[0] != 1:
+            raise NotImplementedError("row_shard=True splits ONE frame over the ranks: batch size must be 1 (got "
+                                      f"{tpv_query[0].shape[0]}), as everywhere in the reference's head (neus_head.py:523)")
         shard = self._row_shard_plan_for(sizes)
         grad = torch.is_grad_enabled()
         q_full = _as_cat(tpv_query)
@@ -609,6 +612,8 @@ class BEVFormerEncoder(_EncoderBase):
         per layer; gradients of the unsharded encoder on every rank."""
         from ... import dist as sdist
         from torch.func import functional_call
+        if bev_query.shape[0] != 1:
+            raise NotImplementedError(f"row_shard=True splits ONE frame over the ranks: batch size must be 1 (got {bev_query.shape[0]})")
         shard = self._row_shard_plan_for([self.bev_size[0] * self.bev_size[1]])
         grad = torch.is_grad_enabled()
         q_full = bev_query

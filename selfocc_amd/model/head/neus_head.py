@@ -432,33 +432,48 @@ class NeuSHead(BaseModule):
             raise NotImplementedError("ray_shard needs a lattice ray mode ('fixed' / 'cellular')")
         return True
 
-    def _agree_on_lattice(self, rays, pix, vol=None):
-        """'cellular' lattices are drawn with numpy's generator on every rank: rank 0's draw wins.  The same
-        broadcast carries a fingerprint of rank 0's frame — the camera matrices themselves, compared EXACTLY (they are
-        rank-invariant inputs: the same numpy metas uploaded on every rank; a float sum of the SDF volume is not — the ranks'
-        encoders may differ in the last bit, and a signed sum cancels towards zero): ray sharding splits ONE frame over the
-        ranks, so a launch that feeds every rank its own frame (the reference's DistributedSampler,
-        dataset/__init__.py:86-87) would stitch row blocks of different scenes together and sum gradients of unrelated
-        volumes; that raises here instead.  The comparison (one more all-reduce and a host read) runs on the first call and
-        then every SELFOCC_RAY_SHARD_CHECK_EVERY-th (default 64; 1 = always, 0 = first call only)."""
+    @staticmethod
+    def _frame_token(metas):
+        """Rank-invariant identity of the frame in the metas, as exact float64 pieces: the dataset's sample `token`
+        (dataset_one_frame_sweeps_dist.py:270-271) / `timestamp` when present, and the ego pose `ego2lidar` (:369)."""
+        import hashlib
+        m = metas[0] if metas else {}
+        parts = []
+        for k in ('token', 'timestamp', 'sample_idx', 'frame_id'):
+            if k in m:
+                hsh = int.from_bytes(hashlib.sha1(str(m[k]).encode()).digest()[:12], 'little')
+                parts += [float(hsh & 0xffffffff), float((hsh >> 32) & 0xffffffff), float((hsh >> 64) & 0xffffffff)]
+        if 'ego2lidar' in m:
+            parts += [float(v) for v in np.asarray(m['ego2lidar'], dtype=np.float64).reshape(-1)]
+        return parts
+
+    def _agree_on_lattice(self, rays, pix, vol=None, metas=None):
+        """'cellular' lattices are drawn with numpy's generator on every rank: rank 0's draw wins.  The same broadcast
+        carries a fingerprint of rank 0's frame, compared EXACTLY on EVERY call: the camera matrices themselves (rank-invariant
+        inputs: the same numpy metas uploaded on every rank; a float sum of the SDF volume is not — the ranks' encoders may
+        differ in the last bit) AND a per-frame token from the metas (sample token / timestamp hash, ego pose: a dataset whose
+        calibration is constant across frames — KITTI, a static rig — fed through a DistributedSampler would pass a
+        matrices-only check).  Ray sharding splits ONE frame over the ranks, so a launch that feeds
+        every rank its own frame (the reference's DistributedSampler, dataset/__init__.py:86-87) would stitch row blocks of
+        different scenes together and sum gradients of unrelated volumes; that raises here instead, on every rank together
+        (a 4-byte all-reduce(MIN) of the verdict; the host read it needs is the one the lattice read-back does anyway)."""
         dev = pix.device if dist.get_backend() == 'nccl' else 'cpu'                         # RCCL moves device memory only
-        mine = torch.cat([torch.tensor([rays.sx, rays.sy, rays.ox, rays.oy], dtype=torch.float64, device=pix.device),
+        tok = self._frame_token(metas)
+        mine = torch.cat([torch.tensor([rays.sx, rays.sy, rays.ox, rays.oy] + tok, dtype=torch.float64, device=pix.device),
                           rays.img2lidar.detach().double().reshape(-1)]).to(dev)
         lat = mine.clone()
         dist.broadcast(lat, 0)
-        every = int(os.environ.get('SELFOCC_RAY_SHARD_CHECK_EVERY', '64'))
-        n = self._shard_calls = getattr(self, '_shard_calls', -1) + 1
-        if n == 0 or (every > 0 and n % every == 0):
-            same = (lat[4:] == mine[4:]).all().to(torch.int32).reshape(1)
-            dist.all_reduce(same, op=dist.ReduceOp.MIN)          # every rank learns of a mismatch anywhere, so all raise together
-            if int(same.item()) == 0:
-                raise RuntimeError("NeuSHead(ray_shard=True): the ranks hold DIFFERENT frames (camera matrices differ from rank "
-                                   "0's). Ray sharding splits one frame over the ranks; feed every rank the same batch "
-                                   "(no DistributedSampler) or turn ray_shard off for frame-per-GPU data parallelism.")
-        sx, sy, ox, oy = (float(np.float32(v)) for v in lat[:4].tolist())
+        same = (lat[4:] == mine[4:]).all().to(torch.int32).reshape(1)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)          # every rank learns of a mismatch anywhere, so all raise together
+        head = torch.cat([lat[:4], same.to(lat.dtype)]).tolist()        # ONE host read: the lattice and the verdict
+        if int(head[4]) == 0:
+            raise RuntimeError("NeuSHead(ray_shard=True): the ranks hold DIFFERENT frames (camera matrices / frame token differ "
+                               "from rank 0's). Ray sharding splits one frame over the ranks; feed every rank the same batch "
+                               "(no DistributedSampler) or turn ray_shard off for frame-per-GPU data parallelism.")
+        sx, sy, ox, oy = (float(np.float32(v)) for v in head[:4])
         if (sx, sy, ox, oy) != (rays.sx, rays.sy, rays.ox, rays.oy):
             rays = RaySet(img2lidar=rays.img2lidar, nx=rays.nx, ny=rays.ny, sx=sx, sy=sy, ox=ox, oy=oy)
-            pix = RaySampler.pixels(rays.ny, rays.nx, *lat[:4].tolist(), pix.device)
+            pix = RaySampler.pixels(rays.ny, rays.nx, *head[:4], pix.device)
         return rays, pix
 
     # ---- reference API -----------------------------------------------------------------
@@ -570,7 +585,7 @@ class NeuSHead(BaseModule):
             # the volume is replicated, the rays are split.  Each rank renders (and later
             # back-propagates) its row block; dL/d(volume) is summed over the ranks by ONE all-reduce.
             from ... import dist as sdist
-            rays, pix = self._agree_on_lattice(rays, pix, vol)
+            rays, pix = self._agree_on_lattice(rays, pix, vol, metas)
             full_rays, rays = rays, sdist.shard_rays(rays)
             vol = SDFVolume(vol.mapping, sdist.replicate_grad_sum(vol.sdf), sdist.replicate_grad_sum(vol.feat),
                             vol.n_rgb, vol.n_sem)

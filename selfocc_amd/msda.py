@@ -168,22 +168,6 @@ def msda_fused_inference(value, spatial_shapes, level_start_index, reference_poi
     return out
 
 
-# inference camera loop of the P >= 33 planes (zh / wz) re-cut per (camera, head) with the coarse FPN levels of `value` staged in
-# LDS (csrc/msda_lds.hip).  OFF by default: measured 312 vs 204 us per call on the zh plane — the
-# staging itself gains 5 %, the (camera, head)-stationary block structure it needs costs 60 %.  env SELFOCC_MSDA_LDS=1 for the A/B.
-CROSS_LDS = os.environ.get('SELFOCC_MSDA_LDS', '0') == '1'
-_CROSS_LDS_WS = {}
-
-
-def _cross_lds_workspace(device, nbytes):
-    """per (device, stream) scratch for the per-camera partial results (rewritten by every launch on that stream)"""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    ws = _CROSS_LDS_WS.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = _CROSS_LDS_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
-    return ws
-
-
 def msda_cross_inference(value, spatial_shapes, level_start_index, reference_points_cam, visible,
                          sampling_offsets, attention_logits, head_major=False):
     """Inference-only camera-loop op (no autograd): the sampling stage of BEVCrossAttention
@@ -210,70 +194,10 @@ def msda_cross_inference(value, spatial_shapes, level_start_index, reference_poi
     assert ref.shape == (cams, nq, P, 2) and vis.shape == (cams, nq)
     sh, st = _i32(spatial_shapes, value.device), _i32(level_start_index, value.device)
     out = torch.empty(nq, heads * d, device=value.device, dtype=torch.float32)
-    host = getattr(spatial_shapes, '_so_host', None)
-    if (CROSS_LDS and head_major and vdt == abi.DTYPE_F32 and vstride == 0 and host is not None and nq > 0):
-        hs = (C.c_int32 * len(host))(*host)
-        if lib().selfocc_msda_cross_lds_supported(hs, heads, d, L, P):
-            # zh / wz planes: per (camera, head) blocks with the coarse FPN levels in LDS (csrc/msda_lds.hip)
-            ws = _cross_lds_workspace(value.device, int(lib().selfocc_msda_cross_lds_workspace(cams, nq, heads, d)))
-            check(lib().selfocc_msda_cross_lds_fwd(ptr(value), ptr(sh), ptr(st), hs, ptr(ref), ptr(vis), ptr(off), ptr(lg),
-                                                   ptr(out), cams, nv, nq, heads, d, L, P, ptr(ws), ws.numel(),
-                                                   current_stream(value.device)), "selfocc_msda_cross_lds_fwd")
-            return out
     check(lib().selfocc_msda_cross_fwd(ptr(value), ptr(sh), ptr(st), ptr(ref), ptr(vis), ptr(off), ptr(lg),
                                        ptr(out), cams, nv, nq, heads, d, L, P, vstride, int(bool(head_major)), vdt,
                                        current_stream(value.device)),
           "selfocc_msda_cross_fwd")
-    return out
-
-
-def msda_pro_supported(heads, d, L, P, K):
-    """True when selfocc_msda_pro_fwd serves this shape (d = 16, K = 96, 80 < 3 L P <= 112)."""
-    return bool(lib().selfocc_msda_pro_supported(int(heads), int(d), int(L), int(P), int(K)))
-
-
-def msda_pro_inference(value, spatial_shapes, level_start_index, reference_points, ref_kind, query, offsets_linear,
-                       weights_linear, num_levels, num_points, head_major=False, visible=None):
-    """Inference-only: deformable sampling with the ``sampling_offsets`` / ``attention_weights`` Linears evaluated inside
-    the kernel (f32 MFMA prologue, csrc/msda_pro.hip) — their outputs never reach memory.
-    ``visible`` None: the plain form (value (bs,nv,h,d) / head-major (bs,h,nv,d); reference_points per ``ref_kind`` as in
-    msda_fused_inference; query (bs, nq, K)) -> (bs, nq, h*d).
-    ``visible`` (cams, nq): the camera loop (value (cams, ...); reference_points (cams,nq,P,2); query (nq, K)) -> (nq, h*d)."""
-    if not value.is_cuda:
-        raise RuntimeError("msda_pro_inference needs CUDA(HIP) tensors: selfocc_amd has no CPU fallback")
-    bsv, nv, heads, d = _value_dims(value, head_major)
-    L, P = int(num_levels), int(num_points)
-    K = query.shape[-1]
-    x = query.reshape(-1, K).contiguous().float()
-    vstride = 0
-    vdt = abi.DTYPE_BF16 if value.dtype == torch.bfloat16 else abi.DTYPE_F32
-    if (not head_major and value.dtype in (torch.float32, torch.bfloat16) and not value.is_contiguous()
-            and value.stride(3) == 1 and value.stride(2) == d
-            and value.stride(1) % 4 == 0 and value.stride(0) == nv * value.stride(1)):
-        vstride = value.stride(1)
-    else:
-        value, vdt = _value_arg(value)
-    ref = reference_points.contiguous().float()
-    sh, st = _i32(spatial_shapes, value.device), _i32(level_start_index, value.device)
-    w_off, b_off = offsets_linear.weight.detach(), offsets_linear.bias.detach()
-    w_aw, b_aw = weights_linear.weight.detach(), weights_linear.bias.detach()
-    assert w_off.shape == (heads * L * P * 2, K) and w_aw.shape == (heads * L * P, K)
-    for t in (w_off, b_off, w_aw, b_aw):
-        assert t.is_contiguous() and t.dtype == torch.float32 and t.device == value.device
-    if visible is None:
-        bs = bsv
-        nq = x.shape[0] // bs
-        vis, cams = None, 0
-        out = torch.empty(bs, nq, heads * d, device=value.device, dtype=torch.float32)
-    else:
-        bs, cams, nq = 1, bsv, x.shape[0]
-        vis = _u8(visible)
-        assert ref.shape == (cams, nq, P, 2) and vis.shape == (cams, nq)
-        out = torch.empty(nq, heads * d, device=value.device, dtype=torch.float32)
-    check(lib().selfocc_msda_pro_fwd(ptr(value), ptr(sh), ptr(st), ptr(ref), int(ref_kind), ptr(vis), ptr(x), ptr(w_off),
-                                     ptr(b_off), ptr(w_aw), ptr(b_aw), ptr(out), cams, bs, nv, nq, heads, d, L, P, K, vstride,
-                                     int(bool(head_major)), vdt, current_stream(value.device)),
-          "selfocc_msda_pro_fwd")
     return out
 
 

@@ -239,17 +239,12 @@ def _brick_workspace(sdf):
     return ws
 
 
-_SCATTER_WS = {}
-
-
 def _scatter_workspace(device, nbytes):
-    """Grow-only scratch of the binned backward scatter per (device, stream): used inside one selfocc_render_bwd
-    call only (stream-ordered), so consecutive calls on a stream share it."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    ws = _SCATTER_WS.get(key)
-    if ws is None or ws.numel() < nbytes:
-        ws = _SCATTER_WS[key] = torch.empty(nbytes, dtype=torch.uint8, device=device)
-    return ws
+    """Scratch of the binned backward scatter (~(record + 8) bytes per sample: 0.95 GB at the nuscenes_occ training shape,
+    28 800 rays x 256 samples x 128-byte records).  Taken from torch's caching allocator for the duration of ONE backward
+    call — stream-ordered, returned to the pool when the call ends, so that the forward pass of the next iteration can
+    reuse the memory (until round 4 it was a grow-only, process-lifetime buffer per (device, stream): +0.95 GB of peak)."""
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
 
 
 class _RenderFunction(torch.autograd.Function):

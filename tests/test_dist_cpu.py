@@ -233,6 +233,14 @@ def _worker_rows(rank, ws, port, ret):
         ok = torch.allclose(got, ref, atol=1e-6)
         for p, q in ((xa, xb), (a0, a1), (b0, b1)):
             ok = ok and torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-6)
+        # the two parameter-gradient all-reduces were launched async and waited for in the end-of-backward callback ...
+        from selfocc_amd import dist as sdist
+        ok = ok and sdist.OVERLAP_STATS == {'deferred': 2, 'synchronous': 0} and not sdist._PENDING
+        # ... unless a parameter already holds a gradient (accumulation would add into a tensor still being reduced):
+        got2 = layers(replicate_grad_sum(xb), a1, b1, PlaneRowShard(sizes))
+        (got2 * coef).sum().backward()
+        ok = ok and sdist.OVERLAP_STATS == {'deferred': 2, 'synchronous': 2}
+        ok = ok and torch.allclose(a1.grad, 2 * a0.grad, rtol=1e-5, atol=1e-6) and torch.allclose(b1.grad, 2 * b0.grad, rtol=1e-5, atol=1e-6)
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()

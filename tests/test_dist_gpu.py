@@ -95,6 +95,20 @@ def _worker(rank, ws, port, ret):
         except RuntimeError as e:
             if "DIFFERENT frames" not in str(e):
                 raise
+        # ... also when the calibration is the SAME on every rank (KITTI, a static rig) and only the frame differs — on a
+        # LATER call (round-4 advisor finding: the guard compared matrices only, and only every 64th call)
+        h = build(True).eval()
+        rep, metas, imgs = th.make_inputs()
+        metas[0]['token'] = 'frame-0'
+        h(rep, metas, global_iter=0)
+        h(rep, metas, global_iter=1)
+        metas[0]['token'] = 'frame-0' if rank == 0 else 'frame-7'
+        try:
+            h(rep, metas, global_iter=2)
+            msgs.append("different frame tokens (same calibration) on the third call did not raise")
+        except RuntimeError as e:
+            if "DIFFERENT frames" not in str(e):
+                raise
         ret[rank] = msgs
     except Exception as e:   # surface the failure in the parent
         import traceback
@@ -364,3 +378,98 @@ def test_bench_plain_python_starts_its_own_ranks():
                           "--no-extras", "--no-hotpath"], cwd=root, env=dict(env, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"),
                          capture_output=True, text=True, timeout=600)
     assert bad.returncode != 0 and not [l for l in bad.stdout.splitlines() if l.startswith("{")]
+
+
+def _enc_shipped_worker(rank, ws, port, ret):
+    """TPVFormerEncoder(row_shard=True) built from the SHIPPED nuscenes_occ config at its full size (257 x 257 x 25, 6 cameras,
+    78 899 queries): the fast paths run with local-row query counts (camera-loop kernels, fused self-attention, banded
+    scatter), first in eval mode against the unsharded encoder, then one TRAINING-mode step (dropout 0.1: the fused
+    dropout + residual path under sharding) whose outputs and gradients must be finite and identical in shape."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=ws)
+    try:
+        import sys
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        sys.path.insert(0, os.path.join(root, "scripts"))
+        import hotpath_common as hc
+        d = torch.device("cuda:0")
+        msgs = []
+        torch.manual_seed(0)
+        cfg = hc.shipped("nuscenes_occ")
+        lifter, enc, _head, _ = hc.build(cfg, d)
+        img = tuple(cfg['img_size'])
+        c2w, l2i, K = hc.ring_cameras(6, img, 1266.0)
+        metas = [dict(lidar2img=l2i, img2lidar=c2w, img_shape=img)]
+        g = torch.Generator().manual_seed(5)
+        feats = [torch.randn(1, 6, 96, -(-img[0] // s_), -(-img[1] // s_), generator=g).to(d) for s_ in (8, 16, 32, 64)]
+        enc.eval()
+        with torch.no_grad():
+            base = [o.clone() for o in enc(lifter(feats)['representation'], ms_img_feats=feats, metas=metas)['representation']]
+            enc.row_shard = True
+            got = enc(lifter(feats)['representation'], ms_img_feats=feats, metas=metas)['representation']
+        plan = enc._row_shard_plan
+        if plan.world_size != ws or plan.n_local >= sum(plan.sizes):
+            msgs.append(f"no sharding happened: {plan.local_sizes} of {plan.sizes}")
+        chk = torch.tensor([float(b.double().abs().sum()) for b in base]
+                           + [float(sum(p.detach().double().abs().sum() for p in enc.parameters()))], dtype=torch.float64)
+        both = [torch.empty_like(chk) for _ in range(ws)]
+        dist.all_gather(both, chk)
+        if not all(torch.equal(both[0], o) for o in both):
+            msgs.append(f"the ranks' UNSHARDED encoders differ (not the same weights / inputs?): {[o.tolist() for o in both]}")
+        for i, (a, b) in enumerate(zip(base, got)):
+            lo, hi = plan.local[i]
+            mine = torch.zeros(a.shape[1], dtype=torch.bool, device=a.device)
+            mine[lo:hi] = True
+            sc = max(1.0, a.abs().max().item())
+            e_own = (a - b)[:, mine].abs().max().item() / sc
+            e_rem = (a - b)[:, ~mine].abs().max().item() / sc
+            if max(e_own, e_rem) > 1e-5:
+                msgs.append(f"shipped-size inference plane {i}: own rows {e_own:.3e}, rows gathered from the other rank {e_rem:.3e}")
+        # one training-mode step under sharding (dropout on).  init_weights() zeroes the sampling_offsets / attention_weights
+        # Linears, the only consumers of the positional encodings: their gradient would be exactly 0 — perturb every
+        # parameter (same draw on both ranks) so that "zero gradient" means "not reached"
+        gen = torch.Generator().manual_seed(17)
+        with torch.no_grad():
+            for p_ in enc.parameters():
+                p_.add_((0.02 * torch.randn(p_.shape, generator=gen)).to(p_.device))
+        enc.train()
+        fs = [f.detach().clone().requires_grad_(True) for f in feats]
+        out = enc(lifter(fs)['representation'], ms_img_feats=fs, metas=metas)['representation']
+        sum((o * o).mean() for o in out).backward()
+        torch.cuda.synchronize()
+        if [tuple(o.shape) for o in out] != [tuple(b.shape) for b in base]:
+            msgs.append("training-mode output shapes differ")
+        bad = [n for n, p in list(enc.named_parameters()) + list(lifter.named_parameters())
+               if p.grad is None or not torch.isfinite(p.grad).all() or p.grad.abs().max() == 0]
+        if bad:
+            msgs.append(f"missing / non-finite / zero gradients: {bad[:6]}")
+        if not all(torch.isfinite(f.grad).all() and f.grad.abs().max() > 0 for f in fs):
+            msgs.append("feature gradients missing")
+        try:        # batch size 2 must raise a readable error, not an opaque reshape failure
+            enc([torch.cat([q, q]) for q in lifter(feats)['representation']], ms_img_feats=[torch.cat([f, f]) for f in feats],
+                metas=metas * 2)
+            msgs.append("bs = 2 under row_shard did not raise")
+        except NotImplementedError:
+            pass
+        ret[rank] = msgs
+    except Exception as e:   # surface the failure in the parent
+        import traceback
+        ret[rank] = [f"exception: {e!r}\n{traceback.format_exc()}"]
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_sharded_encoder_at_the_shipped_size_and_in_training_mode(hip):
+    ws = 2
+    ctx = mp.get_context("spawn")
+    ret = ctx.Manager().dict()
+    port = _free_port()
+    procs = [ctx.Process(target=_enc_shipped_worker, args=(r, ws, port, ret)) for r in range(ws)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(600)
+        assert p.exitcode == 0
+    for r in range(ws):
+        assert ret.get(r) == [], f"rank {r}: {ret.get(r)}"

@@ -130,30 +130,18 @@ def test_encoder_full_structure_forward_and_gradients_vs_reference(hip, variant)
 
 @pytest.mark.parametrize("min_rows", [None, 1])
 def test_encoder_full_structure_inference_vs_reference(hip, min_rows):
-    """no_grad: camera-loop kernel, fused prologue, (min_rows = 1) every projection / residual / norm through
-    selfocc_linear_fwd, the head-major value projection and the prologue-fused sampling kernels (selfocc_msda_pro_fwd) —
-    the eval encoder of eval_depth.py / eval_iou.py"""
+    """no_grad: camera-loop kernel, in-kernel softmax / sampling locations, (min_rows = 1) every projection / residual / norm
+    through selfocc_linear_fwd and the head-major value projection — the eval encoder of eval_depth.py / eval_iou.py"""
     from selfocc_amd.model import bricks
     z, enc, lifter, feats, metas, loss_dirs = _setup()
-    old = (bricks.LINEAR_FWD_MIN_ROWS, bricks.PROLOGUE_MIN_ROWS)
-    calls = {'n': 0}
-    import selfocc_amd.model.encoder.attention as att
-    real = bricks.msda_pro_inference
-
-    def counting(*a, **k):
-        calls['n'] += 1
-        return real(*a, **k)
+    old = bricks.LINEAR_FWD_MIN_ROWS
     try:
         if min_rows is not None:
-            bricks.LINEAR_FWD_MIN_ROWS = bricks.PROLOGUE_MIN_ROWS = min_rows
-        bricks.msda_pro_inference = att.msda_pro_inference = counting
+            bricks.LINEAR_FWD_MIN_ROWS = min_rows
         with torch.no_grad():
             out = enc(lifter(feats)['representation'], ms_img_feats=feats, metas=metas)['representation']
     finally:
-        bricks.LINEAR_FWD_MIN_ROWS, bricks.PROLOGUE_MIN_ROWS = old
-        bricks.msda_pro_inference = att.msda_pro_inference = real
-    if min_rows is not None:     # the prologue-fused kernel served the self-attention and the hw-plane cross-attention of both layers
-        assert calls['n'] == 2 * len(enc.layers), calls
+        bricks.LINEAR_FWD_MIN_ROWS = old
     for got, key in zip(out, ('out_hw', 'out_zh', 'out_wz')):
         ref = torch.tensor(z[key])
         assert torch.allclose(got.cpu(), ref, rtol=OUT_TOL, atol=OUT_TOL), (key, (got.cpu() - ref).abs().max().item())
