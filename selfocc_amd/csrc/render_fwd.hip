@@ -97,20 +97,16 @@ SO_DEVFN void so_gather_feat(const void *__restrict__ vol, int H, int W, int D, 
 #pragma unroll
             for (int q = 0; q < NF / 4; ++q) {
                 float4 t = p[q];
-                f[4 * q + 0] = fmaf(t.x, wgt, f[4 * q + 0]);
-                f[4 * q + 1] = fmaf(t.y, wgt, f[4 * q + 1]);
-                f[4 * q + 2] = fmaf(t.z, wgt, f[4 * q + 2]);
-                f[4 * q + 3] = fmaf(t.w, wgt, f[4 * q + 3]);
+                so_fma4_bcast(f[4 * q + 0], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3], t.x, t.y,
+                              t.z, t.w, wgt);
             }
         } else {
             const uint2 *p = (const uint2 *)((const uint16_t *)vol + vox * NF);
 #pragma unroll
             for (int q = 0; q < NF / 4; ++q) {
                 uint2 t = p[q];
-                f[4 * q + 0] = fmaf(__uint_as_float(t.x << 16), wgt, f[4 * q + 0]);
-                f[4 * q + 1] = fmaf(__uint_as_float(t.x & 0xffff0000u), wgt, f[4 * q + 1]);
-                f[4 * q + 2] = fmaf(__uint_as_float(t.y << 16), wgt, f[4 * q + 2]);
-                f[4 * q + 3] = fmaf(__uint_as_float(t.y & 0xffff0000u), wgt, f[4 * q + 3]);
+                so_fma4_bcast(f[4 * q + 0], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3], __uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u),
+                              __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u), wgt);
             }
         }
     }
@@ -169,19 +165,15 @@ SO_DEVFN void so_gather_feat_interior(__amdgpu_buffer_rsrc_t rf, int W, int D, u
 #pragma unroll
             for (int q = 0; q < NF / 4; ++q) {
                 const so_f4v t = so_bload4(rf, off + q * 16u, corner);
-                f[4 * q + 0] = fmaf(t.x, wgt, f[4 * q + 0]);
-                f[4 * q + 1] = fmaf(t.y, wgt, f[4 * q + 1]);
-                f[4 * q + 2] = fmaf(t.z, wgt, f[4 * q + 2]);
-                f[4 * q + 3] = fmaf(t.w, wgt, f[4 * q + 3]);
+                so_fma4_bcast(f[4 * q + 0], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3], t.x, t.y,
+                              t.z, t.w, wgt);
             }
         } else {
 #pragma unroll
             for (int q = 0; q < NF / 4; ++q) {
                 const so_u2v t = so_bload2u(rf, off + q * 8u, corner);
-                f[4 * q + 0] = fmaf(__uint_as_float(t.x << 16), wgt, f[4 * q + 0]);
-                f[4 * q + 1] = fmaf(__uint_as_float(t.x & 0xffff0000u), wgt, f[4 * q + 1]);
-                f[4 * q + 2] = fmaf(__uint_as_float(t.y << 16), wgt, f[4 * q + 2]);
-                f[4 * q + 3] = fmaf(__uint_as_float(t.y & 0xffff0000u), wgt, f[4 * q + 3]);
+                so_fma4_bcast(f[4 * q + 0], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3], __uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u),
+                              __uint_as_float(t.y << 16), __uint_as_float(t.y & 0xffff0000u), wgt);
             }
         }
     }
@@ -456,10 +448,8 @@ SO_DEVFN void so_gather_feat_staged(__amdgpu_buffer_rsrc_t rf, const void *__res
 #pragma unroll
             for (int q = 0; q < NF / 4; ++q) {
                 const float4 t = p[q];
-                f[4 * q + 0] = fmaf(t.x, wgt, f[4 * q + 0]);
-                f[4 * q + 1] = fmaf(t.y, wgt, f[4 * q + 1]);
-                f[4 * q + 2] = fmaf(t.z, wgt, f[4 * q + 2]);
-                f[4 * q + 3] = fmaf(t.w, wgt, f[4 * q + 3]);
+                so_fma4_bcast(f[4 * q + 0], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3], t.x, t.y,
+                              t.z, t.w, wgt);
             }
 #ifdef SO_STAGE_SCHED
             // keep at most SO_STAGE_SCHED corners' reads in flight: without this the scheduler hoists
@@ -479,10 +469,8 @@ SO_DEVFN void so_gather_feat_staged(__amdgpu_buffer_rsrc_t rf, const void *__res
 #pragma unroll
             for (int q = 0; q < NF / 4; ++q) {
                 const float4 t = p[q];
-                f[4 * q + 0] = fmaf(t.x, wgt, f[4 * q + 0]);
-                f[4 * q + 1] = fmaf(t.y, wgt, f[4 * q + 1]);
-                f[4 * q + 2] = fmaf(t.z, wgt, f[4 * q + 2]);
-                f[4 * q + 3] = fmaf(t.w, wgt, f[4 * q + 3]);
+                so_fma4_bcast(f[4 * q + 0], f[4 * q + 1], f[4 * q + 2], f[4 * q + 3], t.x, t.y,
+                              t.z, t.w, wgt);
             }
         }
     }
@@ -508,8 +496,12 @@ struct FastStep {
 // fallback, so that origin / direction / far need not stay in registers across the march loop.
 template <int NF, bool BF16, bool PER_SAMPLE, bool STAGED = false, bool FACE_SAFE = false, class GeomFn>
 SO_DEVFN void so_march_fast(const so_render_args &a, int ray, GeomFn geom, bool store = true,
-                             float *lds = nullptr, int lane = 0) {
+                             float *lds = nullptr, int lane = 0, float *sem_lds = nullptr) {
     constexpr int NSEM = NF > 4 ? NF - 3 : 0;
+    // The staged 24-channel float32 kernel keeps its 21 semantic accumulators in LDS (sem_lds[k * 256 + thread];
+    // read-modify-write of a lane-private slot; ds_add_f32 measured 5 x slower) instead of registers: at 2 waves / SIMD the 256-VGPR budget was 14 - 19 registers short and the spills
+    // went through the texture path the march is bound by (32 scratch accesses per sample beside 9 real loads).
+    constexpr bool SEM_LDS = STAGED && NSEM >= 16;
     const RayGeom g = geom(a);
     const int H = a.map.h.tot_len, W = a.map.w.tot_len, D = a.map.d.tot_len;
     const int S = a.n_samples;
@@ -531,9 +523,14 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, GeomFn geom, bool 
 
     float T = 1.0f, acc = 0.0f, dsum = 0.0f;
     float rgb[3] = {0.0f, 0.0f, 0.0f};
-    float sem[NSEM > 0 ? NSEM : 1];
+    float sem[(NSEM > 0 && !SEM_LDS) ? NSEM : 1];
+    if constexpr (SEM_LDS) {
 #pragma unroll
-    for (int k = 0; k < NSEM; ++k) sem[k] = 0.0f;
+        for (int k = 0; k < NSEM; ++k) sem_lds[k * 256] = 0.0f;
+    } else {
+#pragma unroll
+        for (int k = 0; k < NSEM; ++k) sem[k] = 0.0f;
+    }
     float best_w = -1.0f, best_t = 0.0f;
     const float *__restrict__ vol = a.sdf_vol;
     const __amdgpu_buffer_rsrc_t rs = so_make_rsrc(vol, (size_t)H * W * D * 4);
@@ -765,8 +762,13 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, GeomFn geom, bool 
                     den = den + e[k];
                 }
                 const float wd = w * so_fast_rcp(den);
+                if constexpr (SEM_LDS) {
 #pragma unroll
-                for (int k = 0; k < NSEM; ++k) sem[k] = fmaf(wd, e[k], sem[k]);
+                    for (int k = 0; k < NSEM; ++k) sem_lds[k * 256] = fmaf(wd, e[k], sem_lds[k * 256]);      // lane-private slot
+                } else {
+#pragma unroll
+                    for (int k = 0; k < NSEM; ++k) sem[k] = fmaf(wd, e[k], sem[k]);
+                }
             }
         }
         if constexpr (PER_SAMPLE) {
@@ -833,7 +835,7 @@ SO_DEVFN void so_march_fast(const so_render_args &a, int ray, GeomFn geom, bool 
         if constexpr (NSEM > 0) {
             if (a.sem) {
 #pragma unroll
-                for (int k = 0; k < NSEM; ++k) a.sem[(size_t)ray * NSEM + k] = sem[k];
+                for (int k = 0; k < NSEM; ++k) a.sem[(size_t)ray * NSEM + k] = SEM_LDS ? sem_lds[k * 256] : sem[k];
             }
         }
     }
@@ -1106,7 +1108,10 @@ __global__ __launch_bounds__(256, (NF >= 8 ? SO_WAVES_FEAT : 1)) void render_fwd
         ix = min(ix, a.nx - 1); iy = min(iy, a.ny - 1);
         int ray = (cam * a.ny + iy) * a.nx + ix;
         auto geom = [&](const so_render_args &a) __attribute__((always_inline)) { return so_pixel_ray(a, cam, ix, iy); };
-        so_march_fast<NF, BF16, PER_SAMPLE, true, MODE == 2>(a, ray, geom, real, s_stage + wave * StageGeom<NF>::kWaveDwords, lane);
+        constexpr int NSEM_LDS = NF - 3 >= 16 ? NF - 3 : 0;          // so_march_fast::SEM_LDS
+        __shared__ float s_sem[NSEM_LDS > 0 ? NSEM_LDS * 256 : 1];
+        so_march_fast<NF, BF16, PER_SAMPLE, true, MODE == 2>(a, ray, geom, real, s_stage + wave * StageGeom<NF>::kWaveDwords, lane,
+                                                             s_sem + threadIdx.x);
     } else {
 #ifdef SO_AHEAD_LDS
         if constexpr (MODE >= 3) {

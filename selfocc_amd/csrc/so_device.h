@@ -169,3 +169,17 @@ SO_DEVFN void so_trilerp_grad(const so_cell &c, const float v[8], float &gx, flo
     gy = gh * c.sh;  // metre y <-> grid h
     gz = gd * c.sd;  // metre z <-> grid d
 }
+
+// Explicit 2-wide FMAs.  The library is built without the compiler's vectorizers (csrc/build.sh: their half-swapping op_sel
+// forms of v_pk_*_f32 are not safe beside bf16 MFMA waves on gfx950); where the packed rate matters the sources spell the
+// low-half-BROADCAST form themselves (v_pk_fma_f32 ... op_sel_hi:[0,1,1], measured clean; tests/test_isa_lint.py).
+typedef float so_f32x2 __attribute__((ext_vector_type(2)));
+// f[0..3] += w * (t0, t1, t2, t3)
+__device__ __forceinline__ void so_fma4_bcast(float &f0, float &f1, float &f2, float &f3, float t0, float t1, float t2, float t3,
+                                              float w) {
+    const so_f32x2 ww = {w, w};
+    so_f32x2 a = {f0, f1}, b = {f2, f3};
+    a = __builtin_elementwise_fma(so_f32x2{t0, t1}, ww, a);
+    b = __builtin_elementwise_fma(so_f32x2{t2, t3}, ww, b);
+    f0 = a[0]; f1 = a[1]; f2 = b[0]; f3 = b[1];
+}
