@@ -422,12 +422,13 @@ def main():
                "field_volume_bwd": (257 * 257 + 2 * 25 * 257) * 96 * 4,     # the three plane gradients
                "msda_bwd_band_list": 6 * 25500 * 96 * 4}                    # d L / d value of one cross-attention call
         groups = {"render_bwd": ("render_bwd_kernel", "rb_brick_kernel", "rb_count_kernel"),
-                  "field_volume_bwd": ("field_volume_bwd_kernel",), "msda_bwd_band_list": ("msda_bwd_band_list_kernel",)}
+                  "field_volume_bwd": ("field_volume_bwd",), "msda_bwd_band_list": ("msda_bwd_band_list_kernel",)}
         roofline_bwd = {"source": "profiles/pmc_bwd.json (scripts/pmc_train_bwd.sh, training iteration at nuscenes_occ shapes)",
                         "measured_in_this_run": False,      # RECORDED counters + durations of that PMC session, not of this process
                         "recorded_round": rec.get("_round")}
         for name, pats in groups.items():
-            ks = {k: v for k, v in rec.items() if any(k.startswith(p) for p in pats) and v.get("write_kb") is not None}
+            ks = {k: v for k, v in rec.items()
+                  if isinstance(v, dict) and any(k.startswith(p) for p in pats) and v.get("write_kb") is not None}
             if not ks:
                 continue
             per_it = max(v["calls"] for v in ks.values()) or 1

@@ -38,6 +38,7 @@ with open("$R/gpurun_out/${TAG}_train_bwd_pmc.txt", "w") as fo:
             fo.write(f"   {cn:28s} n={len(v)} mean={sum(v)/len(v):.5g}\n")
         g = lambda cn: (sum(agg[k][cn]) / len(agg[k][cn])) if agg[k].get(cn) else None
         out[k] = dict(calls=c, avg_us=round(us, 1), fetch_kb=g('FETCH_SIZE'), write_kb=g('WRITE_SIZE'))
+out["_round"] = "$TAG"
 json.dump(out, open("$R/gpurun_out/${TAG}_pmc_bwd.json", "w"), indent=1)
 print(open("$R/gpurun_out/${TAG}_train_bwd_pmc.txt").read())
 PY
