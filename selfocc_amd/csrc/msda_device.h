@@ -195,27 +195,47 @@ SO_DEVFN float4 so_ld4(const uint16_t *p) {
 // The 4-channel FMAs are written as two explicit 2-wide ones (v_pk_fma_f32 with the scalar weight broadcast from the low half,
 // op_sel_hi:[0,1,1]): the library is built WITHOUT the compiler's vectorizers (csrc/build.sh: the half-swapping op_sel forms
 // they produce are not safe beside bf16 MFMA waves on gfx950), and this loop is the one place where the packed rate is worth
-// having back (msda_cross_fwd 0.52 -> 0.45 ms at the shipped hw-plane size).  Only the broadcast / straight forms are used
+// having back (msda_cross_fwd 0.52 -> 0.41 ms at the shipped hw-plane size).  Only the broadcast / straight forms are used
 // here; tests/test_isa_lint.py checks the built library for any other.
-template <int D, int I, typename VT>
+#ifndef SO_TEAM_PK_PLAIN
+#define SO_TEAM_PK_PLAIN 0      // 2-wide FMAs also in the plain / fused kernels (so_team_gather)?  Measured neutral (fused <16,3>
+                                // 0.266 vs 0.259 ms, eval frame 7.98 vs 7.97): off; the camera-loop kernels always have them (0.52 -> 0.41 ms)
+#endif
+template <int D, int I, bool PK = true, typename VT>
 SO_DEVFN void so_team_step(const VT *vb, const MsdaPoint &mp, float (&acc)[4]) {
     constexpr int QL = D / 4;
     const float aw = so_team_bcastf<QL, I>(mp.aw);
-    so_f32x2 v01 = {0.0f, 0.0f}, v23 = {0.0f, 0.0f};
+    if constexpr (PK) {
+        so_f32x2 v01 = {0.0f, 0.0f}, v23 = {0.0f, 0.0f};
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int off = so_team_bcast<QL, I>(mp.off[k]);
-        const float w = so_team_bcastf<QL, I>(mp.w[k]);
-        const float4 t = so_ld4(vb + off);
-        const so_f32x2 ww = {w, w}, t01 = {t.x, t.y}, t23 = {t.z, t.w};
-        v01 = __builtin_elementwise_fma(ww, t01, v01);
-        v23 = __builtin_elementwise_fma(ww, t23, v23);
+        for (int k = 0; k < 4; ++k) {
+            const int off = so_team_bcast<QL, I>(mp.off[k]);
+            const float w = so_team_bcastf<QL, I>(mp.w[k]);
+            const float4 t = so_ld4(vb + off);
+            const so_f32x2 ww = {w, w}, t01 = {t.x, t.y}, t23 = {t.z, t.w};
+            v01 = __builtin_elementwise_fma(ww, t01, v01);
+            v23 = __builtin_elementwise_fma(ww, t23, v23);
+        }
+        const so_f32x2 aa = {aw, aw};
+        so_f32x2 a01 = {acc[0], acc[1]}, a23 = {acc[2], acc[3]};
+        a01 = __builtin_elementwise_fma(aa, v01, a01);
+        a23 = __builtin_elementwise_fma(aa, v23, a23);
+        acc[0] = a01[0]; acc[1] = a01[1]; acc[2] = a23[0]; acc[3] = a23[1];
+    } else {
+        float val[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int off = so_team_bcast<QL, I>(mp.off[k]);
+            const float w = so_team_bcastf<QL, I>(mp.w[k]);
+            const float4 t = so_ld4(vb + off);
+            val[0] = fmaf(w, t.x, val[0]);
+            val[1] = fmaf(w, t.y, val[1]);
+            val[2] = fmaf(w, t.z, val[2]);
+            val[3] = fmaf(w, t.w, val[3]);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = fmaf(aw, val[c], acc[c]);
     }
-    const so_f32x2 aa = {aw, aw};
-    so_f32x2 a01 = {acc[0], acc[1]}, a23 = {acc[2], acc[3]};
-    a01 = __builtin_elementwise_fma(aa, v01, a01);
-    a23 = __builtin_elementwise_fma(aa, v23, a23);
-    acc[0] = a01[0]; acc[1] = a01[1]; acc[2] = a23[0]; acc[3] = a23[1];
 }
 
 // Whole-wave / half-wave groups: move the points that touch the map to the front of their group, dealt round-robin over
@@ -289,17 +309,17 @@ SO_DEVFN void so_team_gather_steps(const VT *vb, const MsdaPoint &mp, float (&ac
 template <int D, typename VT>
 SO_DEVFN void so_team_gather(const VT *vb, const MsdaPoint &mp, float (&acc)[4]) {
     constexpr int QL = D / 4;
-    so_team_step<D, 0>(vb, mp, acc);
-    if constexpr (QL > 1) so_team_step<D, 1>(vb, mp, acc);
+    so_team_step<D, 0, SO_TEAM_PK_PLAIN != 0>(vb, mp, acc);
+    if constexpr (QL > 1) so_team_step<D, 1, SO_TEAM_PK_PLAIN != 0>(vb, mp, acc);
     if constexpr (QL > 2) {
-        so_team_step<D, 2>(vb, mp, acc);
-        so_team_step<D, 3>(vb, mp, acc);
+        so_team_step<D, 2, SO_TEAM_PK_PLAIN != 0>(vb, mp, acc);
+        so_team_step<D, 3, SO_TEAM_PK_PLAIN != 0>(vb, mp, acc);
     }
     if constexpr (QL > 4) {
-        so_team_step<D, 4>(vb, mp, acc);
-        so_team_step<D, 5>(vb, mp, acc);
-        so_team_step<D, 6>(vb, mp, acc);
-        so_team_step<D, 7>(vb, mp, acc);
+        so_team_step<D, 4, SO_TEAM_PK_PLAIN != 0>(vb, mp, acc);
+        so_team_step<D, 5, SO_TEAM_PK_PLAIN != 0>(vb, mp, acc);
+        so_team_step<D, 6, SO_TEAM_PK_PLAIN != 0>(vb, mp, acc);
+        so_team_step<D, 7, SO_TEAM_PK_PLAIN != 0>(vb, mp, acc);
     }
 }
 
