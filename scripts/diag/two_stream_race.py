@@ -118,9 +118,10 @@ with torch.no_grad():
         probe.probe_fill_table(C.c_void_p(torch.cuda.current_stream().cuda_stream), C.c_void_p(table.data_ptr()), 1 << 22)
         torch.cuda.synchronize()
         names = ["dpp", "ds_bpermute/permute", "gather dwordx4", "exp/rcp", "v_pk_fma_f32", "f32 division", "64-bit address math", "16 gathers in flight", "32 gathers in flight", "pk_mul swizzled fresh-cvt", "pk_mul plain fresh-cvt",
-                 "pk_mul swizzled old regs", "pk_fma broadcast", "pk_add inline const"]
+                 "pk_mul swizzled old regs", "pk_fma broadcast", "pk_add inline const", "pk_fma op_sel_hi:[1,0,1]",
+                 "pk_fma op_sel_hi:[0,1,0] const", "pk_fma op_sel_hi:[1,0,0] const"]
         for dn in want:
-            cnt = torch.zeros(16, dtype=torch.int64, device=d)
+            cnt = torch.zeros(24, dtype=torch.int64, device=d)
             for it in range(int(os.environ.get("DIAG_REPEAT", "200"))):
                 if disturbers[dn] is not None:
                     with torch.cuda.stream(sa):
@@ -128,7 +129,7 @@ with torch.no_grad():
                 with torch.cuda.stream(sb):
                     probe.probe_victims(C.c_void_p(sb.cuda_stream), C.c_void_p(cnt.data_ptr()), it * 7919, C.c_void_p(table.data_ptr()), 1 << 20)
             torch.cuda.synchronize()
-            print(f"disturber {dn:28s} micro victims, wrong results:", dict(zip(names, cnt[:14].tolist())), flush=True)
+            print(f"disturber {dn:28s} micro victims, wrong results:", dict(zip(names, cnt[:17].tolist())), flush=True)
         sys.exit(0)
     n = int(os.environ.get("DIAG_REPEAT", "200"))
     for dn in want:

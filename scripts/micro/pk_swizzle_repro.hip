@@ -20,7 +20,7 @@ int main(int argc, char **argv) {
     uint4 *table;
     const unsigned n_rows = 1u << 20;
     const int rows = 78896;
-    (void)hipMalloc(&count, 16 * 8);
+    (void)hipMalloc(&count, 24 * 8);
     (void)hipMalloc(&sink, 64);
     (void)hipMalloc(&table, (size_t)n_rows * 64);
     (void)hipMalloc(&x, (size_t)rows * 96 * 4);
@@ -28,16 +28,17 @@ int main(int argc, char **argv) {
     (void)hipMemset(x, 0x3c, (size_t)rows * 96 * 4);
     probe_fill_table(nullptr, table, n_rows * 4);
     (void)hipDeviceSynchronize();
-    const char *names[14] = {"dpp", "ds_bpermute/ds_permute", "gather dwordx4", "exp/rcp", "v_pk_fma_f32 plain", "f32 division",
+    const char *names[17] = {"dpp", "ds_bpermute/ds_permute", "gather dwordx4", "exp/rcp", "v_pk_fma_f32 plain", "f32 division",
                              "64-bit address math", "16 gathers in flight", "32 gathers in flight",
                              "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0] (fresh cvt)", "v_pk_mul_f32 straight (fresh cvt)",
                              "v_pk_mul_f32 op_sel:[0,1] op_sel_hi:[1,0] (old regs)", "v_pk_fma_f32 op_sel_hi:[0,1,1] (broadcast)",
-                             "v_pk_add_f32 inline constant"};
+                             "v_pk_add_f32 inline constant", "v_pk_fma_f32 op_sel_hi:[1,0,1]", "v_pk_fma_f32 .., 0 op_sel_hi:[0,1,0]",
+                             "v_pk_fma_f32 .., 0 op_sel_hi:[1,0,0]"};
     struct Dist { const char *name; int kind, iters; };
     const Dist dists[] = {{"none", 0, 0}, {"v_mfma_f32_16x16x32_bf16 loop", 1, 40000}, {"v_mfma_f32_16x16x4_f32 loop", 2, 20000},
                           {"bf16x3 GEMM-shaped kernel (LDS planes + bf16 MFMA + global loads / stores), 30 passes", 5, 30}};
     for (const Dist &d : dists) {
-        (void)hipMemset(count, 0, 16 * 8);
+        (void)hipMemset(count, 0, 24 * 8);
         const auto t0 = std::chrono::steady_clock::now();
         long rounds = 0;
         while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < secs) {
@@ -48,10 +49,10 @@ int main(int argc, char **argv) {
             (void)hipDeviceSynchronize();
             ++rounds;
         }
-        unsigned long long h[16];
-        (void)hipMemcpy(h, count, 16 * 8, hipMemcpyDeviceToHost);
+        unsigned long long h[24];
+        (void)hipMemcpy(h, count, 24 * 8, hipMemcpyDeviceToHost);
         printf("disturber: %s   (%ld victim launches of each kind)\n", d.name, rounds * 4);
-        for (int i = 0; i < 14; ++i)
+        for (int i = 0; i < 17; ++i)
             if (h[i] || i >= 9) printf("    %-58s wrong results: %llu\n", names[i], h[i]);
     }
     return 0;

@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void d_b3like(const float *__restrict__ x, flo
     }
 }
 
-// packed-FP32 forms (the form that went wrong in the MSDA bilinear setup is pkmul_swz_fresh: two v_cvt_f32_i32 into a register
+// packed-FP32 forms, slots 9..16 of count[] (the form that went wrong in the MSDA bilinear setup is pkmul_swz_fresh: two v_cvt_f32_i32 into a register
 // pair, then v_pk_mul_f32 with op_sel:[0,1] op_sel_hi:[1,0]).  slots 9..13 of count[]
 template <int FORM>
 __global__ __launch_bounds__(256) void v_pkforms(unsigned long long *count, int iters, unsigned seed, const int2 *__restrict__ tab) {
@@ -284,6 +284,22 @@ __global__ __launch_bounds__(256) void v_pkforms(unsigned long long *count, int 
             float wx = w[0], ax = a[0], ay = a[1];
             asm volatile("" : "+v"(wx), "+v"(ax), "+v"(ay));
             e0 = __builtin_fmaf(wx, ax, 0.25f); e1 = __builtin_fmaf(wx, ay, -0.5f);
+        } else if constexpr (FORM >= 5) {     // the other low-half-broadcast forms the library contains
+            f32x2 acc = {0.25f, -0.5f};
+            f32x2 w = {(float)wl * 0.01f, 123.0f};
+            if constexpr (FORM == 5) {        // multiplier broadcast from src1: op_sel_hi:[1,0,1]
+                asm volatile("v_pk_fma_f32 %0, %2, %1, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(w), "v"(a));
+            } else if constexpr (FORM == 6) { // src0 broadcast, addend = inline 0: op_sel_hi:[0,1,0]
+                asm volatile("v_pk_fma_f32 %0, %1, %2, 0 op_sel_hi:[0,1,0]" : "=v"(acc) : "v"(w), "v"(a));
+            } else {                          // src1 broadcast, addend = inline 0: op_sel_hi:[1,0,0]
+                asm volatile("v_pk_fma_f32 %0, %2, %1, 0 op_sel_hi:[1,0,0]" : "=v"(acc) : "v"(w), "v"(a));
+            }
+            r = acc;
+            float wx = w[0], ax = a[0], ay = a[1];
+            asm volatile("" : "+v"(wx), "+v"(ax), "+v"(ay));
+            if constexpr (FORM == 5) { e0 = __builtin_fmaf(ax, wx, 0.25f); e1 = __builtin_fmaf(ay, wx, -0.5f); }
+            else if constexpr (FORM == 6) { e0 = __builtin_fmaf(wx, ax, 0.0f); e1 = __builtin_fmaf(wx, ay, 0.0f); }
+            else { e0 = __builtin_fmaf(ax, wx, 0.0f); e1 = __builtin_fmaf(ay, wx, 0.0f); }
         } else {                              // v_pk_add_f32 with an inline constant
             f32x2 b = {(float)hl, (float)wl};
             f32x2 t = a * b;
@@ -294,7 +310,7 @@ __global__ __launch_bounds__(256) void v_pkforms(unsigned long long *count, int 
         }
         bad += (__float_as_uint(r[0]) != __float_as_uint(e0)) + (__float_as_uint(r[1]) != __float_as_uint(e1));
     }
-    if (bad) atomicAdd(&count[9 + FORM], bad);
+    if (bad) atomicAdd(&count[FORM <= 4 ? 9 + FORM : 9 + FORM], bad);
 }
 
 // many gathers in flight per wave (the msda kernels keep up to 64 dwordx4 loads outstanding): NL independent loads issued
@@ -337,6 +353,9 @@ extern "C" int probe_victims(void *stream, unsigned long long *count, unsigned s
     v_pkforms<2><<<4096, 256, 0, sb>>>(count, 400, seed, (const int2 *)table);
     v_pkforms<3><<<4096, 256, 0, sb>>>(count, 400, seed, (const int2 *)table);
     v_pkforms<4><<<4096, 256, 0, sb>>>(count, 400, seed, (const int2 *)table);
+    v_pkforms<5><<<4096, 256, 0, sb>>>(count, 400, seed, (const int2 *)table);
+    v_pkforms<6><<<4096, 256, 0, sb>>>(count, 400, seed, (const int2 *)table);
+    v_pkforms<7><<<4096, 256, 0, sb>>>(count, 400, seed, (const int2 *)table);
     return (int)hipGetLastError();
 }
 extern "C" int probe_fill_table(void *stream, void *table, unsigned n_words4) {
