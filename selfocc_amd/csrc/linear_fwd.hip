@@ -687,8 +687,7 @@ static int so_linear_fwd_launch(const float *x, const float *w, const float *bia
                 case 32: SO_B3_3(1); break;
                 case 64: SO_B3_3(2); break;
                 case 96: SO_B3_3(3); break;
-                case 128: SO_B3_3(4); break;
-                default: SO_B3_3(6); break;
+                default: SO_B3_3(4); break;      // K = 128 (use_b3 excludes 192: its three planes would take 115 KB)
             }
 #undef SO_B3_3
 #undef SO_B3_2
