@@ -133,7 +133,9 @@ struct RbBin {
     int2 *blk_tot;     // [ceil(n_bricks / 1024)] (samples, items) per scan block
     int4 *items;       // [max_items] {brick, begin, end, -}
     int nbh, nbw, nbd, chunk;
-    int dbg;           // dev switches (SELFOCC_RB_DBG): 1 = no accumulation, 2 = no flush, 4 = no run merging
+    int dbg;           // dev switches (SELFOCC_RB_DBG): 1 = no accumulation, 2 = no flush, 4 = no run merging, 8 = the ray kernel
+                       // does not write the feature part of its records, 16 = the brick kernel does not read it (timing only:
+                       // 8 + 16 = the traffic of a 32-byte record, profiles/r5_c_render_bwd_record_bound.txt)
 };
 
 SO_DEVFN int rb_key(const RbBin &b, const so_cell &c, int H, int W, int D) {
@@ -421,7 +423,7 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba, 
             }
             if constexpr (BIN) {
                 const int slot = __shfl(slot_base[j], slot_head[j], 64) + (lane - slot_head[j]);
-                if (live[j]) {   // the feature part of the sample's record, 16 bytes at a time
+                if (live[j] && !(bin.dbg & 8)) {   // the feature part of the sample's record, 16 bytes at a time
                     float4 *dst = (float4 *)(bin.rec + (size_t)slot * RECF);
 #pragma unroll
                     for (int q = 0; q < (RECF - 8) / 4; ++q) {
@@ -801,7 +803,7 @@ __global__ __launch_bounds__(NT) void rb_brick_kernel(RbBin b, float *__restrict
             ok[u] = i < ge;
             if (ok[u]) {
                 const float *r = b.rec + (size_t)i * RECF;
-                v[u] = r[sub];
+                v[u] = (b.dbg & 16) ? 0.0f : r[sub];
                 ta[u] = *(const float4 *)(r + (RECF - 8));
                 tb[u] = *(const float4 *)(r + (RECF - 4));
             }
