@@ -144,6 +144,7 @@ struct FieldBwdB3Args {
     float *g_w1, *g_b1, *g_w2, *g_b2;
     int n_tiles;                    // PH * PW * PD patches of 4 x 4 x 2 voxels
     int PW, PD;
+    int dbg;                        // dev switch SELFOCC_FIELD_BWD_DBG: 1 = no zh / wz plane-gradient atomics (timing only)
 };
 
 constexpr int kB3_C = 96, kB3_WAVES = 4;
@@ -567,12 +568,14 @@ __global__ __launch_bounds__(kB3_WAVES * 64) void field_volume_bwd_b3_kernel(Fie
                 ((float4 *)hwa)[2 * ct + 1] = hi;
             }
             // g_wz[w][d] += sum over h: registers v, v + 4, v + 8, v + 12
+            if (!(a.dbg & 1))
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const bool ok = FULL ? true : ((w_b + 2 * half + (q >> 1) < a.W) & (d_b + (q & 1) < a.D));
                 if (ok) unsafeAtomicAdd(gwz + ((q >> 1) * a.D + (q & 1)) * C + 32 * ct, (dx[q] + dx[q + 4]) + (dx[q + 8] + dx[q + 12]));
             }
             // g_zh[d][h] += sum over w: registers v, v ^ 2 and the partner half; half 0 issues d = d_b, half 1 d = d_b + 1
+            if (!(a.dbg & 1))
 #pragma unroll
             for (int hq = 0; hq < 4; ++hq) {
                 const float s0 = dx[4 * hq] + dx[4 * hq + 2], s1 = dx[4 * hq + 1] + dx[4 * hq + 3];
@@ -633,7 +636,8 @@ int so_field_volume_bwd_b3(const float *hw, const float *zh, const float *wz, in
                            float *g_b2, hipStream_t st) {
     const long long PH = (H + 3) / 4, PW = (W + 3) / 4, PD = (D + 1) / 2;
     FieldBwdB3Args a{hw, zh, wz, H, W, D, w1, b1, w2, out_dim, g_sdf, g_feat, feat_stride,
-                     g_hw, g_zh, g_wz, g_w1, g_b1, g_w2, g_b2, (int)(PH * PW * PD), (int)PW, (int)PD};
+                     g_hw, g_zh, g_wz, g_w1, g_b1, g_w2, g_b2, (int)(PH * PW * PD), (int)PW, (int)PD,
+                     getenv("SELFOCC_FIELD_BWD_DBG") ? atoi(getenv("SELFOCC_FIELD_BWD_DBG")) : 0};
     (void)hipFuncSetAttribute((const void *)field_volume_bwd_b3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024 - 256);
     const int blocks = std::min((a.n_tiles + kB3_WAVES - 1) / kB3_WAVES, 256);
