@@ -808,7 +808,8 @@ extern "C" int selfocc_field_volume_bwd(const float *hw, const float *zh, const 
     // round 5: the five GEMMs on the bf16 matrix pipe (field_bwd_b3.hip); SELFOCC_FIELD_BWD_B3=0 keeps the f32-MFMA kernel.
     // (its 16-byte loads of the upstream feature gradient need rows of a multiple of four floats)
     static const bool bwd_b3 = !(getenv("SELFOCC_FIELD_BWD_B3") && atoi(getenv("SELFOCC_FIELD_BWD_B3")) == 0);
-    if (bwd_b3 && (g_feat == nullptr || feat_stride % 4 == 0))
+    // (and it indexes voxels / feature rows in 32 bits: larger volumes stay on the 64-bit-indexed f32 kernel)
+    if (bwd_b3 && (g_feat == nullptr || feat_stride % 4 == 0) && M * std::max(feat_stride, 1) < (1LL << 31))
         return so_field_volume_bwd_b3(hw, zh, wz, H, W, D, w_hidden, b_hidden, w_out, out_dim, g_sdf, g_feat, feat_stride, g_hw,
                                       g_zh, g_wz, g_w_hidden, g_b_hidden, g_w_out, g_b_out, (hipStream_t)stream);
     FieldBwdArgs a{hw, zh, wz, H, W, D, w_hidden, b_hidden, w_out, out_dim, g_sdf, g_feat, feat_stride,

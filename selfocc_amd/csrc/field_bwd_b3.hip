@@ -29,6 +29,7 @@
 // mapping measured with scripts/micro/tr16_map.hip).  A second [input][unit] copy (60 KB) would not fit next to the tiles.
 #include "so_device.h"
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -638,8 +639,17 @@ int so_field_volume_bwd_b3(const float *hw, const float *zh, const float *wz, in
     FieldBwdB3Args a{hw, zh, wz, H, W, D, w1, b1, w2, out_dim, g_sdf, g_feat, feat_stride,
                      g_hw, g_zh, g_wz, g_w1, g_b1, g_w2, g_b2, (int)(PH * PW * PD), (int)PW, (int)PD,
                      getenv("SELFOCC_FIELD_BWD_DBG") ? atoi(getenv("SELFOCC_FIELD_BWD_DBG")) : 0};
-    (void)hipFuncSetAttribute((const void *)field_volume_bwd_b3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              160 * 1024 - 256);
+    // the attribute is per device: set once per device, and a failure (LDS carve-out refused) is an error, not a silent launch failure
+    static std::atomic<unsigned long long> done_mask{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(done_mask.load(std::memory_order_relaxed) & bit)) {
+        const hipError_t e = hipFuncSetAttribute((const void *)field_volume_bwd_b3_kernel,
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+        SO_REQUIRE(e == hipSuccess, "field_volume_bwd: cannot reserve %d bytes of LDS (%s)", 160 * 1024 - 256, hipGetErrorString(e));
+        done_mask.fetch_or(bit, std::memory_order_relaxed);
+    }
     const int blocks = std::min((a.n_tiles + kB3_WAVES - 1) / kB3_WAVES, 256);
     hipLaunchKernelGGL(field_volume_bwd_b3_kernel, dim3(blocks), dim3(kB3_WAVES * 64), kB3_LDS, st, a);
     return so_launch_status();

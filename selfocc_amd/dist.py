@@ -324,52 +324,101 @@ def gather_plane_rows(loc, shard, reduce_grad=True):
     return _gather_plane_rows(loc, shard)
 
 
-_PENDING = []          # all-reduces of parameter gradients launched during the running backward pass
+_PENDING = []          # (work, flat, params) of the all-reduces launched during the running backward pass
+_CALLBACK_QUEUED = [-1]     # id of the backward pass (graph task) whose end-of-backward callback is registered
+_OVERLAP = [os.environ.get('SELFOCC_DIST_OVERLAP', '0') == '1']
 OVERLAP_STATS = {'deferred': 0, 'synchronous': 0}
 
 
-def _flush_pending():
-    """end-of-backward callback: the compute stream waits for every deferred all-reduce (a stream dependency, no host block
-    on RCCL), so the optimiser / clip_grad_norm_ that follows sees reduced gradients"""
-    while _PENDING:
-        _PENDING.pop().wait()
+def enable_overlap(on=True):
+    """Opt in to (out of) the deferred parameter-gradient all-reduce of ``group_grad_sum``.  OFF by default: the deferred
+    route hands the gradients to ``.grad`` itself at the end of ``backward()`` instead of through autograd's AccumulateGrad,
+    so a ``DistributedDataParallel`` wrapper (the reference always wraps the model when distributed, train.py:85-91), a
+    ``register_post_accumulate_grad_hook`` or ``torch.autograd.grad(inputs=parameters)`` would not see them.  The caller
+    that owns the training loop and knows none of those is in use switches it on (SELFOCC_DIST_OVERLAP=1 does the same)."""
+    _OVERLAP[0] = bool(on)
+    return _OVERLAP[0]
+
+
+def _flush_pending(apply=True):
+    """end-of-backward callback: wait for every deferred all-reduce (a stream dependency on RCCL, no host block), THEN cast
+    and add the reduced pieces into ``.grad`` on the compute stream — nothing ever reads a buffer that is still being
+    reduced, whatever the parameter's dtype, whether a ``.grad`` already exists, and however many backward passes
+    contributed to this flush.  ``apply=False``: the work of a backward pass that raised (the engine dropped its callbacks)
+    is waited for and DISCARDED, like the gradients autograd itself had not accumulated yet."""
+    _CALLBACK_QUEUED[0] = -1
+    pending, _PENDING[:] = list(_PENDING), []
+    for work, flat, params in pending:
+        work.wait()
+        if not apply:
+            continue
+        off = 0
+        for p in params:
+            n = p.numel()
+            if p.requires_grad:
+                g = flat[off:off + n].view(p.shape).to(p.dtype)           # after the wait: a window into reduced memory
+                if p.grad is None:
+                    p.grad = g
+                else:
+                    p.grad.add_(g)
+            off += n
+
+
+def _readers_attached(ts):
+    """python-visible hooks that would read a gradient at accumulate time"""
+    return any(getattr(t, '_post_accumulate_grad_hooks', None) or getattr(t, '_backward_hooks', None) for t in ts)
 
 
 class _GroupGradSum(torch.autograd.Function):
     """Identity on a group of (parameter) tensors; backward = ONE coalesced all-reduce(sum) of all their gradients: under
     row sharding a rank's parameter gradients cover its own rows only.
 
-    Overlap (round 5): nothing reads a layer's parameter gradients before the backward pass is over, so the all-reduce is
-    launched ``async_op=True`` and only waited for in an end-of-backward callback — it runs on the collective stream beside
-    the previous layers' backward kernels (59 MB per iteration at the shipped size: 4 layers x 1.83 M parameters x 4 B + the
-    lifter / positional tensors).  Deferred only when no parameter of the group already holds a ``.grad`` (gradient
-    accumulation would add into a tensor that is still being reduced) and the backend reduces device memory itself.
-    The all-gather of a layer's rows and the all-reduce of the gathered planes' gradients (``gather_plane_rows``) stay
-    synchronous: the next layer's first op (cross-view self-attention over the FULL planes) / the previous layer's backward
-    consume them immediately."""
+    Default (round 6): SYNCHRONOUS — the gradients autograd hands on (to AccumulateGrad, its hooks, a DDP reducer) are
+    already reduced.  Round 5 launched the all-reduce ``async_op=True`` and returned views of the buffer being reduced;
+    ``.grad`` came out right only because AccumulateGrad aliased the view, and anything reading at accumulate time — a
+    post-accumulate hook, DDP's bucket hook, a second backward adding into an existing ``.grad``, a bf16 cast — saw the
+    rank-local partial (reproduced on two gloo ranks by the round-5 review; ``tests/test_dist_cpu.py`` now holds those cases).
+
+    Opt-in overlap (``enable_overlap()``): the all-reduce is launched async on the collective stream beside the previous
+    layers' backward kernels (59 MB per iteration at the shipped size), autograd receives NO gradient for the group, and the
+    end-of-backward callback ``_flush_pending`` waits and then writes / accumulates ``.grad`` itself.  Decided at BACKWARD
+    time; refused (synchronous) when a python hook is attached to a tensor of the group, when the tensors are not leaves,
+    or when the backend cannot reduce device memory (the gloo-on-CUDA test rigs).
+    The all-gather of a layer's rows and the all-reduce of the gathered planes' gradients (``gather_plane_rows``) are
+    always synchronous: the next layer's first op / the previous layer's backward consume them immediately."""
 
     @staticmethod
     def forward(ctx, *ts):
-        ctx.defer = all(t.grad is None for t in ts)
+        if _PENDING and torch._C._current_graph_task_id() == -1:
+            _flush_pending(apply=False)     # left behind by a backward pass that raised after queueing work
+        ctx.params = ts
         return tuple(t.view_as(t) for t in ts)
 
     @staticmethod
     def backward(ctx, *gs):
-        flat = torch.cat([g.reshape(-1).float() for g in gs])
+        ts = ctx.params
+        ref = next(g for g in gs if g is not None)
+        parts = [(g if g is not None else torch.zeros_like(t)).reshape(-1).float() for g, t in zip(gs, ts)]
+        flat = torch.cat(parts) if len(parts) > 1 else parts[0].clone()
         staged = flat.is_cuda and dist.get_backend() == 'gloo'          # test rigs: gloo cannot reduce device memory
-        if ctx.defer and not staged and os.environ.get('SELFOCC_DIST_OVERLAP', '1') != '0':
+        defer = _OVERLAP[0] and not staged and all(t.is_leaf for t in ts) and not _readers_attached(ts)
+        if defer:
             work = dist.all_reduce(flat, async_op=True)
-            if not _PENDING:
+            task = torch._C._current_graph_task_id()
+            if _CALLBACK_QUEUED[0] != task:      # registered per backward pass, not "while the list is empty"
+                if _PENDING:
+                    _flush_pending(apply=False)  # a previous pass raised: its callback never ran
                 torch.autograd.Variable._execution_engine.queue_callback(_flush_pending)
-            _PENDING.append(work)
+                _CALLBACK_QUEUED[0] = task
+            _PENDING.append((work, flat, ts))
             OVERLAP_STATS['deferred'] += 1
-        else:
-            _all_reduce_(flat)
-            OVERLAP_STATS['synchronous'] += 1
+            return tuple(None for _ in ts)
+        _all_reduce_(flat)
+        OVERLAP_STATS['synchronous'] += 1
         out, off = [], 0
-        for g in gs:
-            n = g.numel()
-            out.append(flat[off:off + n].view_as(g).to(g.dtype))
+        for g, t in zip(gs, ts):
+            n = t.numel()
+            out.append(flat[off:off + n].view(t.shape).to(ref.dtype if g is None else g.dtype))
             off += n
         return tuple(out)
 

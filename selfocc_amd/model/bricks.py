@@ -14,7 +14,7 @@ from ..dropout import dropout_add
 from ..linear import (linear_wgrad, wgrad_supported, linear_fwd, linear_fwd_supported, linear_fwd_heads, linear_dgrad, dgrad_supported,
                       linear_fwd_heads_supported)
 from ..msda import (MultiScaleDeformableAttnFunction, msda_fused_inference, MSDAFusedFunction, to_head_major,
-                    msda_fused_supported)
+                    msda_fused_supported, msda_fused_kernels_built)
 
 
 class BaseModule(nn.Module):
@@ -482,7 +482,9 @@ def deformable_sampling(module, query, value, reference_points, spatial_shapes, 
     LP = module.num_levels * module.num_points
     off = module.sampling_offsets(query).view(bs, num_query, module.num_heads, module.num_levels,
                                               module.num_points, 2)
-    if not torch.is_grad_enabled() and LP <= 256:
+    d_head = module.value_proj.weight.shape[0] // module.num_heads
+    use_bf16 = VALUE_BF16 and d_head == 16          # the bfloat16 gathers are built for 16 channels per head only
+    if not torch.is_grad_enabled() and LP <= 256 and msda_fused_kernels_built(d_head):
         # inference: softmax + sampling-location prologue fused into the HIP kernel (no loc / weight tensors)
         logits = module.attention_weights(query).view(bs, num_query, module.num_heads, LP)
         kind = {'level': 0, 'point': 1, 'level_point': 2}[per_level_reference]
@@ -491,7 +493,7 @@ def deformable_sampling(module, query, value, reference_points, spatial_shapes, 
             value, hm = v_hm.view(v_hm.shape[1:]), True      # G = 1: a view (select's backward is a zero fill + a copy)
         elif HEAD_MAJOR_VALUE:
             value = to_head_major(value)
-        if VALUE_BF16:
+        if use_bf16:
             value = value.to(torch.bfloat16)
         return msda_fused_inference(value, spatial_shapes, level_start_index, reference_points, kind, off, logits, hm)
     if FUSED_TRAINING and value.is_cuda and LP <= 256:
@@ -499,7 +501,6 @@ def deformable_sampling(module, query, value, reference_points, spatial_shapes, 
         host = getattr(spatial_shapes, '_so_host', None)
         if host is None:
             host = [int(v) for v in spatial_shapes.reshape(-1).tolist()]
-        d_head = module.value_proj.weight.shape[0] // module.num_heads if v_hm is not None else value.shape[-1]
         if msda_fused_supported(host, bs, num_query, module.num_heads, d_head, module.num_levels, module.num_points):
             logits = module.attention_weights(query).view(bs, num_query, module.num_heads, LP)
             kind = {'level': 0, 'point': 1, 'level_point': 2}[per_level_reference]
@@ -509,7 +510,7 @@ def deformable_sampling(module, query, value, reference_points, spatial_shapes, 
             elif HEAD_MAJOR_VALUE:
                 value = to_head_major(value)
             return MSDAFusedFunction.apply(value, spatial_shapes, level_start_index, reference_points, kind, off,
-                                           logits, host, hm, VALUE_BF16)
+                                           logits, host, hm, use_bf16)
     if v_hm is not None:      # (the unfused fallback below wants the mmcv layout)
         value = v_hm.view(v_hm.shape[1:]).permute(0, 2, 1, 3).contiguous()
     aw = module.attention_weights(query).view(bs, num_query, module.num_heads,
@@ -540,7 +541,8 @@ class MultiScaleDeformableAttention(BaseModule):
             raise ValueError(f'embed_dims must be divisible by num_heads, but got {embed_dims} and {num_heads}')
         dim_per_head = embed_dims // num_heads
         if dim_per_head & (dim_per_head - 1):
-            warnings.warn("the HIP MSDA kernel needs a power-of-two dim per head (4, 8, 16, 32)")
+            warnings.warn("the HIP MSDA kernels need a power-of-two dim per head: 8, 16 or 32 for the fused / camera-loop ops, "
+                          "4 on the plain op only")
         self.norm_cfg, self.batch_first = norm_cfg, batch_first
         self.dropout = nn.Dropout(dropout)
         self.im2col_step, self.embed_dims = im2col_step, embed_dims

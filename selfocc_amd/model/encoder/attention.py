@@ -16,7 +16,8 @@ import torch.nn as nn
 from ...registry import MODELS, build_attention
 from ..bricks import (BaseModule, MultiScaleDeformableAttention, TallLinear, constant_init, xavier_init,
                       deformable_sampling, fused_linear)
-from ...msda import msda_cross_inference, MSDACrossFunction, msda_fused_supported, to_head_major
+from ...msda import (msda_cross_inference, MSDACrossFunction, msda_fused_supported, msda_fused_kernels_built,
+                     to_head_major)
 from .. import bricks
 
 
@@ -117,7 +118,8 @@ class BEVCrossAttention(BaseModule):
         D = reference_points_cams.size(3)
         da = self.deformable_attention
         if (self.camera_loop and bs == 1 and query.is_cuda and isinstance(da, BEVDeformableAttention)
-                and da.batch_first and da.num_levels * da.num_points <= 256):
+                and da.batch_first and da.num_levels * da.num_points <= 256
+                and msda_fused_kernels_built(self.embed_dims // da.num_heads)):
             host = None
             if torch.is_grad_enabled():
                 host = getattr(spatial_shapes, '_so_host', None)
@@ -187,7 +189,8 @@ class BEVCrossAttention(BaseModule):
                     v = to_head_major(v)
         vis_all = getattr(bev_masks, '_so_visible', None)                   # left by the HIP point_sampling
         visible = vis_all[:, 0] if vis_all is not None else bev_masks[:, 0].any(-1)   # (cams, Q), batch element 0 as the reference
-        if bricks.VALUE_BF16 and host_shapes is None and v.dtype != torch.bfloat16:
+        bf16 = bricks.VALUE_BF16 and self.embed_dims // heads == 16     # the bfloat16 gathers exist for d = 16 only
+        if bf16 and host_shapes is None and v.dtype != torch.bfloat16:
             v = v.to(torch.bfloat16)
         q2 = query.reshape(-1, query.shape[-1])   # bs == 1; a view, not query[0]: select's backward is a zero fill + a copy
         off = da.sampling_offsets(q2).view(-1, heads, L, P, 2)
@@ -197,7 +200,7 @@ class BEVCrossAttention(BaseModule):
                                          off, logits, hm)[None]
         else:
             slots = MSDACrossFunction.apply(v, spatial_shapes, level_start_index, reference_points_cams[:, 0], visible,
-                                            off, logits, host_shapes, hm, bricks.VALUE_BF16)[None]
+                                            off, logits, host_shapes, hm, bf16)[None]
         if not self.training and not torch.is_grad_enabled():
             # eval: dropout is the identity; output_proj + residual (+ the layer's next norm) in one launch, written
             # straight into the caller's slice of the concatenated plane buffer (`out`)
@@ -254,7 +257,7 @@ class TPVCrossAttention(BaseModule):
                 v_hm = bricks.value_proj_head_major(w, b, vin, l, heads0) if C == 96 else None
                 if v_hm is not None:
                     # (3, cams, heads, l, d): each plane's head-major value, written by the projection kernel itself
-                    if bricks.VALUE_BF16:
+                    if bricks.VALUE_BF16 and C // heads0 == 16:
                         v_hm = v_hm.to(torch.bfloat16)
                     vpre = list(v_hm)
                     return [self.attns[i](query[i], key, value, residual[i] if residual is not None else None,
@@ -266,7 +269,7 @@ class TPVCrossAttention(BaseModule):
                     v_all = bricks.linear_fwd(vin, w, b).view(cams, l, 3 * C)
                 else:
                     v_all = torch.addmm(b, vin, w.t()).view(cams, l, 3 * C)
-                if bricks.VALUE_BF16:
+                if bricks.VALUE_BF16 and C // heads0 == 16:
                     v_all = v_all.to(torch.bfloat16)       # one cast for the three planes
                 if bricks.HEAD_MAJOR_VALUE:
                     # one transposing copy for the three planes: (plane, cams, heads, l, d), each plane dense

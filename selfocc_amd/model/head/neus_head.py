@@ -439,12 +439,21 @@ class NeuSHead(BaseModule):
         import hashlib
         m = metas[0] if metas else {}
         parts = []
+        # FIXED length (4 keys x (present flag + 3 hash words) + present flag + 16 pose entries = 33), zero-filled slots for
+        # missing keys: ranks whose metas carry different key sets must still broadcast same-sized tensors, so that the
+        # mismatch reaches the all-reduce(MIN) verdict instead of hanging / erroring inside the collective
         for k in ('token', 'timestamp', 'sample_idx', 'frame_id'):
             if k in m:
                 hsh = int.from_bytes(hashlib.sha1(str(m[k]).encode()).digest()[:12], 'little')
-                parts += [float(hsh & 0xffffffff), float((hsh >> 32) & 0xffffffff), float((hsh >> 64) & 0xffffffff)]
-        if 'ego2lidar' in m:
-            parts += [float(v) for v in np.asarray(m['ego2lidar'], dtype=np.float64).reshape(-1)]
+                parts += [1.0, float(hsh & 0xffffffff), float((hsh >> 32) & 0xffffffff), float((hsh >> 64) & 0xffffffff)]
+            else:
+                parts += [0.0, 0.0, 0.0, 0.0]
+        pose = np.asarray(m['ego2lidar'], dtype=np.float64).reshape(-1) if 'ego2lidar' in m else np.zeros(0)
+        if pose.size == 16:
+            parts += [1.0] + [float(v) for v in pose]
+        else:               # absent (flag 0) or an unexpected shape (flag 2 + a hash of its bytes): still 17 slots
+            hsh = int.from_bytes(hashlib.sha1(pose.tobytes()).digest()[:4], 'little') if pose.size else 0
+            parts += [2.0 if pose.size else 0.0, float(hsh)] + [0.0] * 15
         return parts
 
     def _agree_on_lattice(self, rays, pix, vol=None, metas=None):

@@ -244,10 +244,16 @@ class MSDAFusedFunction(torch.autograd.Function):
         return g_value, None, None, None, None, g_off, g_lg, None, None, None
 
 
-def msda_fused_supported(host_shapes, bs, nq, heads, d, L, P):
+def msda_fused_kernels_built(d, value_bf16=False):
+    """The fused / camera-loop kernels exist for 8, 16, 32 channels per head; a bfloat16 ``value`` for 16 only
+    (csrc/msda.hip: SO_FUSED_DISPATCH).  Everything else goes through the plain op (4, 8, 16, 32; float32)."""
+    return d in (8, 16, 32) and (not value_bf16 or d == 16)
+
+
+def msda_fused_supported(host_shapes, bs, nq, heads, d, L, P, value_bf16=False):
     """True when the fused training op applies (banded scatter possible, L * P <= 256)."""
     import ctypes
-    if L * P > 256 or L > 8 or d not in (8, 16, 32):          # the fused / camera-loop kernels are built for 8, 16, 32 channels per head
+    if L * P > 256 or L > 8 or not msda_fused_kernels_built(d, value_bf16):
         return False
     arr = (ctypes.c_int32 * len(host_shapes))(*host_shapes)
     return lib().selfocc_msda_banded_supported(ctypes.cast(arr, ctypes.c_void_p), bs, nq, heads, d, L, P) == 1

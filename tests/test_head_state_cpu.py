@@ -46,3 +46,18 @@ def test_alias_is_mapped_and_foreign_keys_are_named():
     assert 'head.model.field.glin0.weight' in msg and 'head.model.field.variance' in msg and 'NOT loaded' in msg
     k = 'head.model.field.density_net.1.weight'
     assert torch.equal(m.state_dict()[k], sd['head.model.field.net.density_net.1.weight'])
+
+
+def test_frame_token_has_one_length_whatever_keys_the_metas_carry():
+    """ranks whose metas carry different key sets must broadcast same-sized fingerprints (advisor, round 5): the mismatch
+    has to reach the all-reduce(MIN) verdict, not hang the collective"""
+    import numpy as np
+    from selfocc_amd.model.head.neus_head import NeuSHead
+    tok = NeuSHead._frame_token
+    cases = [None, [], [{}], [{'token': 'abc'}], [{'timestamp': 17, 'ego2lidar': np.eye(4)}],
+             [{'token': 'abc', 'timestamp': 1, 'sample_idx': 2, 'frame_id': 3, 'ego2lidar': np.eye(4) * 2}],
+             [{'ego2lidar': np.zeros((3, 4))}]]
+    toks = [tok(c) for c in cases]
+    assert len({len(t) for t in toks}) == 1 and len(toks[0]) == 33
+    assert toks[3] != toks[2] and toks[4] != toks[2] and toks[6] != toks[2]
+    assert tok([{'token': 'abc'}]) == toks[3] and tok([{'token': 'abd'}]) != toks[3]
