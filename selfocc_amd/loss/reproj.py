@@ -65,6 +65,16 @@ class SSIM(nn.Module):
 
 # a transform that maps every point behind the camera: disables one temporal frame in the kernel
 _INVALID = torch.diag(torch.tensor([1.0, 1.0, -1.0, 1.0]))
+_INVALID_DEV = {}
+
+
+def _invalid_on(device):
+    """the constant on ``device``, uploaded once (a per-call ``.to(device)`` of a pageable host tensor is a blocking copy:
+    found by tests/test_shipped_configs_gpu.py under set_sync_debug_mode("error") on the KITTI configs)"""
+    key = str(device)
+    if key not in _INVALID_DEV:
+        _INVALID_DEV[key] = upload(_INVALID.numpy(), device, torch.float32)
+    return _INVALID_DEV[key]
 
 
 class _ReprojBase(BaseLoss):
@@ -211,7 +221,7 @@ class ReprojLossMonoMultiNew(_ReprojBase):
         T_prev = self._transforms(metas, 'img2prevImg', ts[0], num_cams)[0]
         T_next = self._transforms(metas, 'img2nextImg', ts[0], num_cams)[0]
         pix = ms_rays.float().contiguous()
-        invalid = _INVALID.to(pix.device)
+        invalid = _invalid_on(pix.device)
         from ..dist import shard_of
         shard = shard_of(weights)        # ray-sharded head: per-sample inputs are this rank's rows (see the Combine loss)
         rays_k = num_rays if shard is None else shard.rays_per_cam_local

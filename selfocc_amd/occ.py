@@ -109,6 +109,7 @@ def field_query_autograd(vol, xyz, want_logits=False):
 
 
 _LATTICES = {}
+_LUTS = {}
 
 
 def uniform_lattice(aabb, resolution, device, shift=False):
@@ -162,7 +163,14 @@ def occ_resample(grid, coords, thresh, *, logits=None, lut=None, crop=(0, 0, 0, 
         logits = logits.contiguous().float()
         a.logits, a.C = ptr(logits), logits.shape[3]
         if lut is not None:
-            lut_t = torch.as_tensor(lut, dtype=torch.int32, device=grid.device)
+            if torch.is_tensor(lut):
+                lut_t = lut.to(device=grid.device, dtype=torch.int32)
+            else:      # a python list (OPENSEED2NUSCENES): uploaded once per device, not once per frame (a blocking pageable copy)
+                key = (tuple(int(v) for v in lut), str(grid.device))
+                lut_t = _LUTS.get(key)
+                if lut_t is None:
+                    from ._lib import upload
+                    lut_t = _LUTS[key] = upload(np.asarray(key[0], dtype=np.int32), grid.device, torch.int32)
             assert lut_t.numel() == a.C
             a.lut = ptr(lut_t)
             keep.append(lut_t)
