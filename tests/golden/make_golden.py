@@ -1122,6 +1122,257 @@ def golden_train_step(REG, LOSS_REG):
           {n: float(p.grad.abs().max()) for n, p in head.named_parameters()}, {k: v.tolist() for k, v in term_digest.items()})
 
 
+# ---- the two shipped loss COMPOSITIONS no fixture covered until round 6 (review item 1) -----------------------------------
+# Head and loss dictionaries are read from the shipped config files themselves (executed: plain Python); only the grids, the
+# lattice and the dense-query resolution are reduced for a CPU fixture — everything else is the shipped value, key for key.
+VARIANTS = {
+    # config/nuscenes/nuscenes_occ_bev.py: BEV field (tpv=False: the MLP emits (1 + color_dims) * Z outputs per BEV cell),
+    # SemLossMS (binary cross-entropy on clamped probabilities) + SoftSparsityLoss on the shifted uniform SDF lattice
+    'occ_bev': dict(config='config/nuscenes/nuscenes_occ_bev.py',
+                    head_over=dict(mapping_args=dict(nonlinear_mode='linear', h_size=[16, 0], h_range=[40.0, 0], h_half=False,
+                                                     w_size=[16, 0], w_range=[40.0, 0], w_half=False, d_size=[8, 0],
+                                                     d_range=[-1.0, 5.4, 5.4]),
+                                   ray_number=[6, 10], resolution=1.6, use_compact_2nd_grad=True),
+                    spec=dict(n_cams=6, img=(768, 1600), focal=1266.0, n_sem=21, seed_params=123, seed_rep=105, seed_imgs=141,
+                              seed_np=177, seed_torch=200, global_iter=11), shift_y=0.0, sdf_bias=0.4),
+    # config/kitti_raw/kitti_raw_depth.py: one camera, SDF-only field (color_dims=0), ReprojLossMonoMultiNew (two temporal
+    # candidates) + EdgeLoss3DMS on the mean-normalised depth lattice, half-form h axis (the box lies in front of the rig)
+    'kitti_raw': dict(config='config/kitti_raw/kitti_raw_depth.py',
+                      head_over=dict(mapping_args=dict(nonlinear_mode='linear', h_size=[64, 0], h_range=[51.2, 0], h_half=True,
+                                                       w_size=[16, 0], w_range=[25.6, 0], w_half=False, d_size=[8, 0],
+                                                       d_range=[-2.0, 4.4, 4.4]),
+                                     ray_number=[6, 10]),
+                      spec=dict(n_cams=1, img=(370, 1216), focal=707.0, n_sem=2, seed_params=223, seed_rep=205, seed_imgs=241,
+                                seed_np=277, seed_torch=300, global_iter=3), shift_y=8.0, sdf_bias=0.4),
+}
+
+
+def shipped_config_ns(rel):
+    path = os.path.join(REF, rel)
+    ns = {}
+    exec(compile(open(path).read(), path, 'exec'), ns)
+    return ns
+
+
+def _variant_setup(tag, LOSS_REG):
+    """(head, rep (leaf tensors), metas, images, loss_func, head cfg, loss cfg, conversion, spec) of a VARIANTS entry"""
+    import copy
+    v = VARIANTS[tag]
+    nh, DRAWS = _head_env()
+    namespace('loss')
+    sys.modules['loss'].OPENOCC_LOSS = LOSS_REG
+    for m in ('base_loss', 'reproj_loss_mono_multi_new_combine', 'reproj_loss_mono_multi_new', 'rgb_loss_ms', 'eikonal_loss',
+              'second_grad_loss', 'edge_loss_3d_ms', 'sparsity_loss', 'multi_loss'):
+        ref_import('loss.' + m)
+    ns = shipped_config_ns(v['config'])
+    cfg = copy.deepcopy(ns['model']['head'])
+    assert cfg.pop('type') == 'NeuSHead'
+    cfg.update(copy.deepcopy(v['head_over']))
+    loss_cfg = copy.deepcopy(ns['loss'])
+    for c in loss_cfg['loss_cfgs']:
+        if 'ray_resize' in c:
+            c['ray_resize'] = list(cfg['ray_number'])
+    conv = dict(ns['loss_input_convertion'])
+    spec = dict(v['spec'])
+    torch.manual_seed(spec['seed_params'])
+    head = nh.NeuSHead(**copy.deepcopy(cfg))
+    head.model.differentiable = True
+    f = head.model.field
+    with torch.no_grad():
+        f.net.density_net[-1].bias[0] = v['sdf_bias']          # surfaces inside the box
+    H, W, D, C = f.mapping.size_h, f.mapping.size_w, f.mapping.size_d, cfg['embed_dims']
+    g = torch.Generator().manual_seed(spec['seed_rep'])
+    if cfg['tpv']:
+        rep = [torch.randn(1, H * W, C, generator=g).requires_grad_(True), torch.randn(1, D * H, C, generator=g).requires_grad_(True),
+               torch.randn(1, W * D, C, generator=g).requires_grad_(True)]
+    else:
+        rep = [torch.randn(1, H * W, C, generator=g).requires_grad_(True)]
+    img = tuple(cfg['ray_img_size'])
+    assert img == tuple(spec['img'])
+    c0, c1 = _cams(spec['n_cams'], 1, img, spec['focal']), _cams(spec['n_cams'], 2, img, spec['focal'])
+    c0[:, 1, 3] += v['shift_y']; c1[:, 1, 3] += v['shift_y']
+    imgs, sem, prev, nxt = train_step_inputs(spec)
+    metas = [dict(img2lidar=list(c0), temImg2lidar=list(c1), img2prevImg=prev, img2nextImg=nxt, sem=sem)]
+    loss_func = LOSS_REG.build(copy.deepcopy(loss_cfg))
+    return nh, DRAWS, head, rep, metas, imgs, sem, (c0, c1, prev, nxt), loss_func, cfg, loss_cfg, conv, spec
+
+
+class _RecordRandLike:
+    """records every torch.rand_like draw of the wrapped region (the lattice shift of get_uniform_sdf(shift=True),
+    neus_head.py:283-285)"""
+
+    def __enter__(self):
+        self.draws, self._orig = [], torch.rand_like
+        torch.rand_like = lambda t, **k: self.draws.append(self._orig(t, **k)) or self.draws[-1]
+        return self
+
+    def __exit__(self, *a):
+        torch.rand_like = self._orig
+
+
+def golden_train_step_variants(REG, LOSS_REG):
+    """golden_train_step for the compositions of VARIANTS: REAL NeuSHead.forward -> the config's loss_input_convertion -> REAL
+    MultiLoss over the config's own loss list -> backward (train.py:219-239); train_step_<tag>.npz + _cfg.json."""
+    import json
+    for tag in VARIANTS:
+        nh, DRAWS, head, rep, metas, imgs, sem, (c0, c1, prev, nxt), loss_func, cfg, loss_cfg, conv, spec = _variant_setup(tag, LOSS_REG)
+        f = head.model.field
+        os.environ['eval'] = 'false'
+        head.train()
+        DRAWS.clear()
+        np.random.seed(spec['seed_np'])
+        torch.manual_seed(spec['seed_torch'])
+        with _RecordRandLike() as rl:
+            result_dict = head(rep if cfg['tpv'] else rep[0], metas, global_iter=spec['global_iter'])
+        vol = f.net.density_color
+        vol.retain_grad()
+        loss_input = {'curr_imgs': imgs['curr_imgs'], 'prev_imgs': imgs['prev_imgs'], 'next_imgs': imgs['next_imgs'],
+                      'curr_feats': imgs['curr_imgs'], 'prev_feats': imgs['prev_imgs'], 'next_feats': imgs['next_imgs'],
+                      'metas': metas, 'color_imgs': imgs['color_imgs']}
+        for k, val in conv.items():
+            loss_input[k] = result_dict[val]
+        term_digest = {}
+        for lf in loss_func.losses:
+            gv, = torch.autograd.grad(lf(loss_input), vol, retain_graph=True)
+            term_digest[lf.__class__.__name__] = np.array([float(gv.double().abs().sum()), float(gv.double().sum()), float(gv.abs().max())])
+        vol.grad = None
+        loss, loss_dict = loss_func(loss_input)
+        loss.backward()
+        arrs = {f'sd.{k}': val for k, val in to_np(head.state_dict()).items()}
+        for k, val in term_digest.items():
+            arrs[f'termgrad.{k}'] = val
+        for i, r in enumerate(rep):
+            arrs[f'rep{i}'] = r.detach().numpy()
+            arrs[f'grad.rep{i}'] = r.grad.numpy()
+        for n, p in head.named_parameters():
+            assert p.grad is not None, n
+            arrs[f'grad.sd.{n}'] = p.grad.numpy()
+        arrs['grad.volume'] = vol.grad[0].numpy()
+        arrs['img2lidar'], arrs['temImg2lidar'], arrs['img2prevImg'], arrs['img2nextImg'] = c0, c1, prev, nxt
+        arrs['draw.t_rand'] = DRAWS['t_rand'].numpy()
+        arrs['draw.bkgd'] = DRAWS['bkgd'][0].numpy()
+        if cfg.get('return_uniform_sdf'):
+            assert len(rl.draws) == 1
+            arrs['draw.shift'] = rl.draws[0].numpy()
+        arrs['loss.total'] = loss.detach().numpy()
+        for k, val in loss_dict.items():
+            arrs[f'loss.{k}'] = np.float64(val)
+        keys = [k for k in ('ms_depths', 'ms_colors', 'ms_accs', 'ms_rays', 'sem', 'second_grad', 'uniform_sdf') if result_dict.get(k) is not None]
+        _flatten_out('out', {k: result_dict[k] for k in keys}, arrs)
+        for k, val in imgs.items():
+            arrs[f'digest.{k}'] = np.array([float(val.double().sum()), float(val[0, :, :, ::97, ::101].double().sum())])
+        arrs['digest.sem'] = np.array([int(sem.sum()), int(sem[:, ::97, ::101].sum())])
+        save(f'train_step_{tag}.npz', **arrs)
+        with open(os.path.join(HERE, f'train_step_{tag}_cfg.json'), 'w') as fjs:
+            json.dump(dict(head=cfg, loss=loss_cfg, loss_input_convertion=conv, spec=spec, source=VARIANTS[tag]['config']), fjs, indent=1)
+        print(f'train_step_{tag}: total', float(loss), loss_dict, '|g_vol|', float(vol.grad.abs().max()),
+              {k: val.tolist() for k, val in term_digest.items()})
+
+
+# ---- K optimiser steps, not one (review item 4) ------------------------------------------------------------------------------
+# train.py:219-254 driven for K iterations with gradient accumulation: loss / grad_accumulation, backward, and every
+# grad_accumulation-th iteration clip_grad_norm_(grad_max_norm) + AdamW.step() + zero_grad(); a fresh cellular lattice
+# (numpy RNG), jitter and random background (torch RNG) per iteration, global_iter advancing.  Two trajectories: the SHIPPED
+# optimizer dict (config/_base_/optimizer.py: AdamW lr 2e-5, weight_decay 1e-4 — at that rate two steps move the losses by
+# ~1e-5, i.e. a skipped or stale update would hide inside any tolerance) and the same with lr x 100, where stale state
+# (cached lattice, inv_s, workspaces, gradients not zeroed) shows up in the next iteration's losses.
+TRAIN_STEPS_K = dict(K=4, grad_accumulation=2, lr_mults=[1.0, 100.0], seed_np=377, seed_torch=400, first_iter=52,
+                     head_over=dict(mapping_args=dict(nonlinear_mode='linear', h_size=[16, 0], h_range=[40.0, 0], h_half=False,
+                                                      w_size=[16, 0], w_range=[40.0, 0], w_half=False, d_size=[8, 0],
+                                                      d_range=[-1.0, 5.4, 5.4])))
+
+
+def golden_train_steps(REG, LOSS_REG):
+    import copy
+    import json
+    nh, DRAWS = _head_env()
+    namespace('loss')
+    sys.modules['loss'].OPENOCC_LOSS = LOSS_REG
+    for m in ('base_loss', 'reproj_loss_mono_multi_new_combine', 'rgb_loss_ms', 'eikonal_loss', 'second_grad_loss', 'multi_loss'):
+        ref_import('loss.' + m)
+    spec, ks = TRAIN_STEP, TRAIN_STEPS_K
+    cfg = copy.deepcopy(OCC_HEAD_CFG)
+    cfg.update(copy.deepcopy(ks['head_over']))
+    opt_ns = shipped_config_ns('config/_base_/optimizer.py')
+    opt_cfg = dict(opt_ns['optimizer']['optimizer'])
+    assert opt_cfg.pop('type') == 'AdamW'
+    grad_max_norm = opt_ns['grad_max_norm']
+    img = tuple(cfg['ray_img_size'])
+    c0, c1 = _cams(spec['n_cams'], 1, img, spec['focal']), _cams(spec['n_cams'], 2, img, spec['focal'])
+    imgs, sem, prev, nxt = train_step_inputs(spec)            # the images of train_step.npz (the GPU test shares its cache)
+    metas = [dict(img2lidar=list(c0), temImg2lidar=list(c1), img2prevImg=prev, img2nextImg=nxt, sem=sem)]
+    loss_cfg, conv = shipped_loss_cfg(cfg['ray_number'])
+    arrs = {'img2lidar': c0, 'temImg2lidar': c1, 'img2prevImg': prev, 'img2nextImg': nxt}
+    for k, v in imgs.items():
+        arrs[f'digest.{k}'] = np.array([float(v.double().sum()), float(v[0, :, :, ::97, ::101].double().sum())])
+    arrs['digest.sem'] = np.array([int(sem.sum()), int(sem[:, ::97, ::101].sum())])
+    for ti, lr_mult in enumerate(ks['lr_mults']):
+        torch.manual_seed(spec['seed_params'])
+        head = nh.NeuSHead(**copy.deepcopy(cfg))
+        head.model.differentiable = True
+        f = head.model.field
+        with torch.no_grad():
+            f.net.density_net[-1].bias[0] = 0.4
+        H, W, D, C = f.mapping.size_h, f.mapping.size_w, f.mapping.size_d, cfg['embed_dims']
+        g = torch.Generator().manual_seed(spec['seed_rep'])
+        rep = [torch.nn.Parameter(torch.randn(1, n, C, generator=g)) for n in (H * W, D * H, W * D)]
+        named = [(f'rep{i}', r) for i, r in enumerate(rep)] + [('sd.' + n, p) for n, p in head.named_parameters()]
+        params = [p for _, p in named]
+        if ti == 0:
+            for n, p in named:
+                arrs[f'init.{n}'] = p.detach().numpy().copy()
+        optimizer = torch.optim.AdamW(params, **dict(opt_cfg, lr=opt_cfg['lr'] * lr_mult))
+        loss_func = LOSS_REG.build(copy.deepcopy(loss_cfg))
+        os.environ['eval'] = 'false'
+        head.train()
+        np.random.seed(ks['seed_np'])
+        torch.manual_seed(ks['seed_torch'])
+        pre = f't{ti}'
+        n_steps = 0
+        reliable = {n: np.ones(p.shape, dtype=bool) for n, p in named}
+        for it in range(ks['K']):
+            global_iter = ks['first_iter'] + it
+            DRAWS.clear()
+            # ---- train.py:219-254 ----
+            result_dict = head(rep, metas, global_iter=global_iter)
+            loss_input = {'curr_imgs': imgs['curr_imgs'], 'prev_imgs': imgs['prev_imgs'], 'next_imgs': imgs['next_imgs'],
+                          'curr_feats': imgs['curr_imgs'], 'prev_feats': imgs['prev_imgs'], 'next_feats': imgs['next_imgs'],
+                          'metas': metas, 'color_imgs': imgs['color_imgs']}
+            for k, v in conv.items():
+                loss_input[k] = result_dict[v]
+            loss, loss_dict = loss_func(loss_input)
+            loss = loss / ks['grad_accumulation']
+            loss.backward()
+            arrs[f'{pre}.it{it}.loss.total'] = loss.detach().numpy()
+            for k, v in loss_dict.items():
+                arrs[f'{pre}.it{it}.loss.{k}'] = np.float64(v)
+            arrs[f'{pre}.it{it}.draw.t_rand'] = DRAWS['t_rand'].numpy()
+            arrs[f'{pre}.it{it}.draw.bkgd'] = DRAWS['bkgd'][0].numpy()
+            arrs[f'{pre}.it{it}.ms_rays'] = result_dict['ms_rays'].detach().numpy()
+            arrs[f'{pre}.it{it}.inv_s'] = np.float64(float(f.inv_s()))
+            if (global_iter + 1) % ks['grad_accumulation'] == 0:
+                gn = torch.nn.utils.clip_grad_norm_(params, grad_max_norm)
+                arrs[f'{pre}.step{n_steps}.grad_norm'] = np.float64(float(gn))
+                for n, p in named:      # Adam divides by sqrt(v): an element whose gradient is noise moves by +-lr whatever its sign
+                    ga = p.grad.abs()
+                    reliable[n] &= (ga > 1e-3 * ga.max()).numpy()
+                optimizer.step()
+                optimizer.zero_grad()
+                n_steps += 1
+        for n, p in named:
+            arrs[f'{pre}.final.{n}'] = p.detach().numpy().copy()
+            arrs[f'{pre}.exp_avg.{n}'] = optimizer.state[p]['exp_avg'].numpy().copy()
+            arrs[f'{pre}.reliable.{n}'] = np.packbits(reliable[n].reshape(-1))
+        print(f'train_steps_k {pre}: lr x{lr_mult}', [float(arrs[f"{pre}.it{i}.loss.total"]) for i in range(ks['K'])],
+              'grad_norm', [float(arrs[f"{pre}.step{i}.grad_norm"]) for i in range(n_steps)],
+              'inv_s', [float(arrs[f"{pre}.it{i}.inv_s"]) for i in range(ks['K'])],
+              'reliable frac', {n: round(float(reliable[n].mean()), 3) for n, _ in named})
+    save('train_steps_k.npz', **arrs)
+    with open(os.path.join(HERE, 'train_steps_k_cfg.json'), 'w') as fjs:
+        json.dump(dict(head=cfg, loss=loss_cfg, loss_input_convertion=conv, spec=spec, steps=ks, optimizer=dict(opt_cfg, type='AdamW'),
+                       grad_max_norm=grad_max_norm), fjs, indent=1)
+
+
 FULL_ENCODER = dict(dim=96, heads=6, cams=6, tpv=(25, 25, 7), fpn=((12, 25), (6, 13), (3, 7), (2, 4)), img_shape=(96, 200),
                     seed_params=31, seed_lifter=32, seed_feats=33, seed_loss=34)
 
@@ -1249,6 +1500,8 @@ if __name__ == '__main__':
                 encoder=lambda: golden_encoder(REG), bev_encoder=lambda: golden_bev_encoder(REG),
                 segmentor=lambda: golden_segmentor(REG), head=lambda: golden_head(REG),
                 train_step=lambda: golden_train_step(REG, LOSS_REG),
+                train_step_variants=lambda: golden_train_step_variants(REG, LOSS_REG),
+                train_steps_k=lambda: golden_train_steps(REG, LOSS_REG),
                 encoder_full=lambda: golden_encoder_full(REG))
     for name, fn in todo.items():
         if not only or name in only:

@@ -40,11 +40,12 @@ def _gen():
     return m
 
 
-_INPUTS = {}
+_INPUTS_ALL = {}
 
 
-def _inputs(z, spec):
-    """the seeded images / label map of the generator, regenerated once per session and checked against its digests"""
+def _inputs(z, spec, stem="train_step"):
+    """the seeded images / label map of the generator, regenerated once per session and fixture and checked against its digests"""
+    _INPUTS = _INPUTS_ALL.setdefault(stem, {})
     if not _INPUTS:
         imgs, sem, prev, nxt = _gen().train_step_inputs(spec)
         for k, v in imgs.items():
@@ -74,34 +75,54 @@ def _errs(a, b):
 
 @pytest.mark.parametrize("scatter,fused_field", [('atomic', True), ('binned', True), ('binned', False)])
 def test_train_step_losses_and_gradients_vs_reference(hip, monkeypatch, scatter, fused_field):
+    _run(monkeypatch, "train_step", scatter, fused_field)
+
+
+@pytest.mark.parametrize("scatter,fused_field", [('atomic', True), ('binned', True), ('binned', False)])
+@pytest.mark.parametrize("stem", ["train_step_occ_bev", "train_step_kitti_raw"])
+def test_train_step_of_the_other_shipped_compositions_vs_reference(hip, monkeypatch, stem, scatter, fused_field):
+    """round 6: config/nuscenes/nuscenes_occ_bev.py (BEV field, SemLossMS + SoftSparsityLoss on the shifted uniform-SDF
+    lattice) and config/kitti_raw/kitti_raw_depth.py (one camera, color_dims = 0, ReprojLossMonoMultiNew + EdgeLoss3DMS) —
+    head and loss dictionaries read from the shipped config files by make_golden.py::golden_train_step_variants, held to the
+    bounds of the nuscenes_occ step."""
+    _run(monkeypatch, stem, scatter, fused_field)
+
+
+def _run(monkeypatch, stem, scatter, fused_field):
     from selfocc_amd.registry import MODELS, OPENOCC_LOSS
     import selfocc_amd.model, selfocc_amd.loss  # noqa: F401
-    z = np.load(os.path.join(G, "train_step.npz"))
-    cfg = json.load(open(os.path.join(G, "train_step_cfg.json")))
+    z = np.load(os.path.join(G, stem + ".npz"))
+    cfg = json.load(open(os.path.join(G, stem + "_cfg.json")))
     spec = cfg['spec']
+    tpv = cfg['head'].get('tpv', True)
     head = MODELS.build(dict(type='NeuSHead', **copy.deepcopy(cfg['head'])))
     sd = {k[3:].replace('model.field.net.density_net', 'model.field.density_net'): torch.tensor(z[k])
           for k in z.files if k.startswith('sd.')}
     head.load_state_dict(sd, strict=True)
     head = head.to(D0).train()
     head.model.field.fused_volume = fused_field
-    rep = [torch.tensor(z[f'rep{i}']).to(D0).requires_grad_(True) for i in range(3)]
-    imgs, sem = _inputs(z, spec)
+    rep = [torch.tensor(z[f'rep{i}']).to(D0).requires_grad_(True) for i in range(3 if tpv else 1)]
+    imgs, sem = _inputs(z, spec, stem)
     metas = [dict(img2lidar=list(z['img2lidar']), temImg2lidar=list(z['temImg2lidar']), img2prevImg=z['img2prevImg'],
                   img2nextImg=z['img2nextImg'], sem=sem)]
     loss_func = OPENOCC_LOSS.build(copy.deepcopy(cfg['loss']))          # the shipped `loss` dict, through our registry
     monkeypatch.setenv('SELFOCC_RB_SCATTER', scatter)
     os.environ['eval'] = 'false'
-    rp = Replay([z['draw.t_rand'], z['draw.bkgd']])
+    draws = [z['draw.t_rand'], z['draw.bkgd']] + ([z['draw.shift']] if 'draw.shift' in z.files else [])
+    rp = Replay(draws)
+    orig_rand, orig_rand_like = torch.rand, torch.rand_like
     monkeypatch.setattr(torch, 'rand', rp.rand)
+    monkeypatch.setattr(torch, 'rand_like', rp.rand_like)
     np.random.seed(spec['seed_np'])
     # ---- train.py:219-239 ----
-    result_dict = head(rep, metas, global_iter=spec['global_iter'])
-    monkeypatch.setattr(torch, 'rand', torch.rand)
-    assert rp.used == 2
+    result_dict = head(rep if tpv else rep[0], metas, global_iter=spec['global_iter'])
+    monkeypatch.setattr(torch, 'rand', orig_rand)
+    monkeypatch.setattr(torch, 'rand_like', orig_rand_like)
+    assert rp.used == len(draws)
     vol = head.model.field.volume
     vol.sdf.retain_grad()
-    vol.feat.retain_grad()
+    if vol.feat is not None:
+        vol.feat.retain_grad()
     loss_input = {'curr_imgs': imgs['curr_imgs'], 'prev_imgs': imgs['prev_imgs'], 'next_imgs': imgs['next_imgs'],
                   'curr_feats': imgs['curr_imgs'], 'prev_feats': imgs['prev_imgs'], 'next_feats': imgs['next_imgs'],
                   'metas': metas, 'color_imgs': imgs['color_imgs']}
@@ -111,11 +132,14 @@ def test_train_step_losses_and_gradients_vs_reference(hip, monkeypatch, scatter,
     loss.backward()
     torch.cuda.synchronize()
 
-    tag = f'{scatter}/{"fused" if fused_field else "torch"}-field'
+    tag = f'{stem}:{scatter}/{"fused" if fused_field else "torch"}-field'
     # forward: the rendered maps the losses consume
-    for k, ref in (('ms_depths', z['out.ms_depths.0']), ('ms_colors', z['out.ms_colors.0']), ('ms_accs', z['out.ms_accs.0']),
-                   ('sem', z['out.sem.0'])):
-        emax, el2, sc = _errs(result_dict[k][0], ref)
+    fwd = [(k, result_dict[k][0], z[f'out.{k}.0']) for k in ('ms_depths', 'ms_colors', 'ms_accs', 'sem')
+           if f'out.{k}.0' in z.files and z[f'out.{k}.0'].size]
+    if 'out.uniform_sdf' in z.files:
+        fwd.append(('uniform_sdf', result_dict['uniform_sdf'], z['out.uniform_sdf']))
+    for k, got, ref in fwd:
+        emax, el2, sc = _errs(got, ref)
         _log(where=tag, kind='forward', key=k, err_max=emax, err_l2=el2, scale=sc)
         assert emax <= FWD_TOL, (tag, k, emax)
     # every loss term and the total
@@ -127,8 +151,8 @@ def test_train_step_losses_and_gradients_vs_reference(hip, monkeypatch, scatter,
         _log(where=tag, kind='loss', key=k, err_rel=e, ref=ref, got=got)
         assert e <= LOSS_RTOL, (tag, k, got, ref)
     # gradients: planes, field MLP, variance, the dense volume
-    g_vol = torch.cat([vol.sdf.grad[None], vol.feat.grad.permute(3, 0, 1, 2)], 0)          # (1 + color_dims, H, W, D)
-    pairs = [(f'rep{i}', rep[i].grad, z[f'grad.rep{i}']) for i in range(3)] + [('volume', g_vol, z['grad.volume'])]
+    g_vol = vol.sdf.grad[None] if vol.feat is None else torch.cat([vol.sdf.grad[None], vol.feat.grad.permute(3, 0, 1, 2)], 0)   # (1 + color_dims, H, W, D)
+    pairs = [(f'rep{i}', rep[i].grad, z[f'grad.rep{i}']) for i in range(len(rep))] + [('volume', g_vol, z['grad.volume'])]
     for n, p in head.named_parameters():
         pairs.append((n, p.grad, z['grad.sd.' + n.replace('model.field.density_net', 'model.field.net.density_net')]))
     worst = {}
