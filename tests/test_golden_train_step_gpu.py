@@ -153,12 +153,18 @@ def _run(monkeypatch, stem, scatter, fused_field):
     # gradients: planes, field MLP, variance, the dense volume
     g_vol = vol.sdf.grad[None] if vol.feat is None else torch.cat([vol.sdf.grad[None], vol.feat.grad.permute(3, 0, 1, 2)], 0)   # (1 + color_dims, H, W, D)
     pairs = [(f'rep{i}', rep[i].grad, z[f'grad.rep{i}']) for i in range(len(rep))] + [('volume', g_vol, z['grad.volume'])]
+    floors = {}
     for n, p in head.named_parameters():
-        pairs.append((n, p.grad, z['grad.sd.' + n.replace('model.field.density_net', 'model.field.net.density_net')]))
+        rn = n.replace('model.field.density_net', 'model.field.net.density_net')
+        pairs.append((n, p.grad, z['grad.sd.' + rn]))
+        if 'gradscale.sd.' + rn in z.files:       # a scalar that sums signed terms: compared on the scale of what was summed
+            floors[n] = float(z['gradscale.sd.' + rn])
     worst = {}
     for name, g, ref in pairs:
         assert g is not None and torch.isfinite(g).all(), (tag, name)
         emax, el2, sc = _errs(g, ref)
+        if floors.get(name, 0.0) > sc:
+            emax, el2, sc = emax * sc / floors[name], el2 * sc / floors[name], floors[name]
         _log(where=tag, kind='grad', key=name, err_max=emax, err_l2=el2, scale=sc)
         worst[name] = (emax, el2)
     bad = {n: e for n, e in worst.items() if e[0] > GRAD_MAX_TOL or e[1] > GRAD_L2_TOL}

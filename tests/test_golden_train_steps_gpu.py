@@ -31,6 +31,7 @@ LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 
 LOSS_RTOL = 1e-5           # every loss term of every iteration, relative
 NORM_RTOL = 1e-5           # the clipped gradient norm of every optimiser step
+GRAD_MAX_TOL, GRAD_L2_TOL = 5e-5, 7e-5      # the accumulated gradient at every optimiser step (the bounds of the one-step test)
 STATE_TOL = 5e-5           # AdamW exp_avg: max |m - m_ref| / max |m_ref| per tensor
 PARAM_TOL = 5e-5           # final parameters on reliable elements: max |p - p_ref| / max(|p_ref|, update scale)
 
@@ -48,9 +49,9 @@ def _ours(name):
     return name.replace('model.field.net.density_net', 'model.field.density_net')
 
 
-@pytest.mark.parametrize("scatter", ['binned', 'atomic'])
+@pytest.mark.parametrize("scatter,fused_field", [('binned', True), ('atomic', True), ('binned', False)])
 @pytest.mark.parametrize("traj", [0, 1])
-def test_k_training_iterations_with_accumulation_vs_reference(hip, monkeypatch, traj, scatter):
+def test_k_training_iterations_with_accumulation_vs_reference(hip, monkeypatch, traj, scatter, fused_field):
     from selfocc_amd.registry import MODELS, OPENOCC_LOSS
     import selfocc_amd.model, selfocc_amd.loss  # noqa: F401
     z = np.load(os.path.join(G, "train_steps_k.npz"))
@@ -61,6 +62,7 @@ def test_k_training_iterations_with_accumulation_vs_reference(hip, monkeypatch, 
     sd = {_ours(k[8:]): torch.tensor(z[k]) for k in z.files if k.startswith('init.sd.')}
     head.load_state_dict(sd, strict=True)
     head = head.to(D0).train()
+    head.model.field.fused_volume = fused_field
     rep = [torch.nn.Parameter(torch.tensor(z[f'init.rep{i}']).to(D0)) for i in range(3)]
     named = [(f'rep{i}', r) for i, r in enumerate(rep)] + [('sd.' + n, p) for n, p in head.named_parameters()]
     params = [p for _, p in named]
@@ -75,7 +77,7 @@ def test_k_training_iterations_with_accumulation_vs_reference(hip, monkeypatch, 
     os.environ['eval'] = 'false'
     np.random.seed(ks['seed_np'])
     orig_rand = torch.rand
-    tag = f'{pre}(lr x{lr_mult:g})/{scatter}'
+    tag = f'{pre}(lr x{lr_mult:g})/{scatter}/{"fused" if fused_field else "torch"}-field'
     n_steps, worst_loss = 0, 0.0
     for it in range(ks['K']):
         global_iter = ks['first_iter'] + it
@@ -109,6 +111,12 @@ def test_k_training_iterations_with_accumulation_vs_reference(hip, monkeypatch, 
             ref = float(z[f'{pre}.step{n_steps}.grad_norm'])
             _log(where=tag, kind='grad_norm', step=n_steps, err_rel=abs(gn - ref) / ref, ref=ref, got=gn)
             assert abs(gn - ref) <= NORM_RTOL * ref, (tag, n_steps, gn, ref)
+            for n, p in named:       # the accumulated gradient the optimiser is about to see (planes: every 8th row)
+                rn = n.replace('model.field.density_net', 'model.field.net.density_net')
+                g_max, g_l2, g_sc = _errs(p.grad[0, ::8] if n.startswith('rep') else p.grad, z[f'{pre}.step{n_steps}.grad.{rn}'])
+                _log(where=tag, kind='step_grad', step=n_steps, key=n, err_max=g_max, err_l2=g_l2, scale=g_sc)
+                if os.environ.get('SO_TS_NOASSERT') != '1':
+                    assert g_max <= GRAD_MAX_TOL and g_l2 <= GRAD_L2_TOL, (tag, n_steps, n, g_max, g_l2)
             optimizer.step()
             optimizer.zero_grad()
             n_steps += 1
@@ -117,10 +125,11 @@ def test_k_training_iterations_with_accumulation_vs_reference(hip, monkeypatch, 
     lr = opt_cfg['lr'] * lr_mult
     bad = {}
     for n, p in named:
-        m_max, m_l2, m_sc = _errs(optimizer.state[p]['exp_avg'], z[f'{pre}.exp_avg.{n}'])
-        ref, init = torch.tensor(z[f'{pre}.final.{n}']).double(), torch.tensor(z[f'init.{n}']).double()
+        rn = n.replace('model.field.density_net', 'model.field.net.density_net')        # the reference's state-dict key
+        m_max, m_l2, m_sc = _errs(optimizer.state[p]['exp_avg'], z[f'{pre}.exp_avg.{rn}'])
+        ref, init = torch.tensor(z[f'{pre}.final.{rn}']).double(), torch.tensor(z[f'init.{rn}']).double()
         got = p.detach().double().cpu()
-        rel = torch.tensor(np.unpackbits(z[f'{pre}.reliable.{n}'])[:ref.numel()].astype(bool)).reshape(ref.shape)
+        rel = torch.tensor(np.unpackbits(z[f'{pre}.reliable.{rn}'])[:ref.numel()].astype(bool)).reshape(ref.shape)
         scale = max(float(ref.abs().max()), 1e-30)
         e_rel = float((got - ref)[rel].abs().max()) / scale if rel.any() else 0.0
         e_unrel = float((got - ref)[~rel].abs().max()) if (~rel).any() else 0.0
