@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define SELFOCC_ABI_VERSION 31
+#define SELFOCC_ABI_VERSION 32
 
 int selfocc_abi_version(void);
 const char *selfocc_last_error(void);
@@ -232,7 +232,13 @@ enum { SO_VALUE_PIXEL_MAJOR = 0, SO_VALUE_HEAD_MAJOR = 1 };
 int selfocc_msda_fused_fwd(const void *value, const int32_t *shapes, const int32_t *starts,
                            const float *ref, int32_t ref_kind, const float *off_raw, const float *logits,
                            float *out, int32_t bs, int32_t nv, int32_t nq, int32_t heads, int32_t d,
-                           int32_t L, int32_t P, int32_t value_layout, int32_t value_dtype, void *stream);
+                           int32_t L, int32_t P, int32_t value_layout, int32_t value_dtype, int32_t ol_stride, void *stream);
+/* ol_stride (ABI 32; the four fused / camera-loop entry points): floats between consecutive QUERY rows of off_raw and logits
+ * (and of g_off / g_logits in the backward forms).  0 = the dense tensors described above.  3 * heads * L * P (or more, even)
+ * = ONE row per query [heads*L*P*2 raw offsets | heads*L*P logits], i.e. the output of the `sampling_offsets` and
+ * `attention_weights` Linears computed as ONE projection with the two weights stacked (image_cross_attention.py:296-312
+ * reads the same `query` twice); `logits` = `off_raw` + 2 * heads * L * P then, and the backward forms write the gradient
+ * of that merged row, which is what ONE input-gradient and ONE weight-gradient pass of the stacked Linear consume. */
 
 /* Camera-loop inference form: BEVCrossAttention's re-batch -> offset / weight linears -> MSDA ->
  * scatter-add -> divide-by-count (bevformer/attention/image_cross_attention.py:90-136) as ONE launch.
@@ -248,7 +254,7 @@ int selfocc_msda_cross_fwd(const void *value, const int32_t *shapes, const int32
                            const float *ref, const uint8_t *vis, const float *off_raw, const float *logits,
                            float *out, int32_t cams, int32_t nv, int32_t nq, int32_t heads, int32_t d,
                            int32_t L, int32_t P, int32_t value_stride, int32_t value_layout, int32_t value_dtype,
-                           void *stream);
+                           int32_t ol_stride, void *stream);
 
 /* Training counterpart of selfocc_msda_cross_fwd: g_out (nq, heads*d) is the gradient of the camera MEAN;
  * returns g_value (cams,nv,heads,d; zero-initialised by the caller), g_off (nq,heads,L,P,2) and
@@ -260,7 +266,7 @@ int selfocc_msda_cross_bwd(const void *value, const int32_t *shapes, const int32
                            const float *off_raw, const float *logits, const float *g_out,
                            float *g_value, float *g_off, float *g_logits, int32_t cams, int32_t nv,
                            int32_t nq, int32_t heads, int32_t d, int32_t L, int32_t P, int32_t value_layout,
-                           int32_t value_dtype, void *workspace, size_t workspace_bytes, void *stream);
+                           int32_t value_dtype, int32_t ol_stride, void *workspace, size_t workspace_bytes, void *stream);
 
 /* g_value must be zero-initialised by the caller (atomically accumulated). */
 int selfocc_msda_bwd(const float *value, const int32_t *shapes, const int32_t *starts,
@@ -299,7 +305,7 @@ int selfocc_msda_fused_bwd(const void *value, const int32_t *shapes, const int32
                            const float *off_raw, const float *logits, const float *g_out,
                            float *g_value, float *g_off, float *g_logits, int32_t bs, int32_t nv,
                            int32_t nq, int32_t heads, int32_t d, int32_t L, int32_t P, int32_t value_layout,
-                           int32_t value_dtype, void *workspace, size_t workspace_bytes, void *stream);
+                           int32_t value_dtype, int32_t ol_stride, void *workspace, size_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Dense SDF / semantic query on a regular metre lattice + Occ3D occupancy tail.

@@ -8,6 +8,7 @@ import argparse
 import json
 import os
 import sys
+import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
@@ -49,19 +50,24 @@ for name in names:
         optimizer = torch.optim.AdamW(params, **opt_cfg)
         fr = hc.frame_inputs(cfg, name, d, seed=0)
         evs = []
+        host = []
         for it in range(args.warm + args.iters):
             optimizer.zero_grad(set_to_none=True)
             e = {}
+            h0 = time.perf_counter()
             hc.train_iteration(mods, cfg, fr, global_iter=it, events=e)
+            h1 = time.perf_counter()
             torch.nn.utils.clip_grad_norm_(params, cfg['grad_max_norm'])
             optimizer.step()
             e['t5'] = hc.ev()
             torch.cuda.synchronize()
             if it >= args.warm:
                 evs.append(e)
+                host.append((h1 - h0) * 1e3)
         t = mean_stages(evs, dict(encoder_fwd=('t0', 't1'), head_fwd=('t1', 't2'), losses_fwd=('t2', 't3'), backward=('t3', 't4'),
                                   clip_and_adamw=('t4', 't5')))
         t['total_ms'] = round(sum(v for k, v in t.items() if k != 'clip_and_adamw'), 2)
+        t['host_enqueue_ms'] = round(sum(host) / len(host), 2)      # the python / launch side of the same iteration (no device wait)
         t['rays'] = cfg['num_rays'][0] * cfg['num_rays'][1] * cfg['model']['encoder']['num_cams']
         t['losses'] = [c['type'] for c in cfg['loss']['loss_cfgs']]
         r['train'] = t
@@ -74,20 +80,24 @@ for name in names:
         for m in mods[:3]:
             m.eval()
         fr = hc.frame_inputs(cfg, name, d, seed=1, want_images=False)
-        evs, state = [], {}
+        evs, state, host = [], {}, []
         with torch.no_grad():
             for it in range(args.warm + args.iters):
                 e = {}
+                h0 = time.perf_counter()
                 out = hc.eval_entry(mods, cfg, name, fr, state, events=e)
+                h1 = time.perf_counter()
                 torch.cuda.synchronize()
                 if it >= args.warm:
                     evs.append(e)
+                    host.append((h1 - h0) * 1e3)
         kind = hc.SHIPPED[name]['eval']
         second = {'render': 'prepare_volume', 'render_novel': 'prepare_volume', 'occ3d': 'volume_and_dense_query',
                   'occ_kitti': 'volume_and_dense_query'}[kind]
         third = {'render': 'render', 'render_novel': 'render', 'occ3d': 'resample_lut_iou_counts', 'occ_kitti': 'threshold_crop_iou_counts'}[kind]
         t = mean_stages(evs, {'encoder_fwd': ('t0', 't1'), second: ('t1', 't2'), third: ('t2', 't3')})
         t['total_ms'] = round(sum(t.values()), 2)
+        t['host_enqueue_ms'] = round(sum(host) / len(host), 2)
         t['entry'] = kind
         if kind.startswith('render'):
             t['rays'] = int(out['ms_depths'][0].numel())

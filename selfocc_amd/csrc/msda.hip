@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256, SO_MSDA_FWD_WAVES(D)) void msda_fused_fwd_kern
 #pragma unroll
     for (int r = 0; r < MAXR; ++r) {
         const int pt = gl + r * G;
-        lg[r] = (pt < LP) ? logits[(size_t)gq * LP + pt] : -INFINITY;
+        lg[r] = (pt < LP) ? logits[so_lg_index(dm, bq, h, LP, pt)] : -INFINITY;
         mx = fmaxf(mx, lg[r]);
     }
 #pragma unroll
@@ -137,8 +137,7 @@ __global__ __launch_bounds__(256, SO_MSDA_FWD_WAVES(D)) void msda_fused_fwd_kern
             const int l = so_level_of(pt, dm.P, dm.L);
             const int pp = pt - l * dm.P;
             const int Hl = shapes[2 * l], Wl = shapes[2 * l + 1];
-            const size_t idx = (size_t)gq * LP + pt;
-            const float2 o = *(const float2 *)(off_raw + 2 * idx);
+            const float2 o = *(const float2 *)(off_raw + so_off_index(dm, bq, h, LP, pt));
             size_t ri;
             if (ref_kind == 1) ri = (size_t)bq * dm.P + pp;
             else if (ref_kind == 2) ri = ((size_t)bq * dm.L + l) * dm.P + pp;
@@ -200,7 +199,7 @@ __global__ __launch_bounds__(256, SO_MSDA_CROSS_WAVES(D, LOGG)) void msda_cross_
 #pragma unroll
     for (int r = 0; r < MAXR; ++r) {
         const int pt = gl + r * G;
-        lg[r] = (pt < LP) ? logits[(size_t)gq * LP + pt] : -INFINITY;
+        lg[r] = (pt < LP) ? logits[so_lg_index(dm, q, h, LP, pt)] : -INFINITY;
         mx = fmaxf(mx, lg[r]);
     }
 #pragma unroll
@@ -214,7 +213,7 @@ __global__ __launch_bounds__(256, SO_MSDA_CROSS_WAVES(D, LOGG)) void msda_cross_
         ox[r] = oy[r] = 0.0f;
         if (pt < LP) {
             const int l = so_level_of(pt, dm.P, dm.L);
-            const float2 o = *(const float2 *)(off_raw + 2 * ((size_t)gq * LP + pt));
+            const float2 o = *(const float2 *)(off_raw + so_off_index(dm, q, h, LP, pt));
             ox[r] = o.x / (float)shapes[2 * l + 1];
             oy[r] = o.y / (float)shapes[2 * l];
         }
@@ -597,7 +596,7 @@ __global__ __launch_bounds__(256) void msda_fused_bwd_point_kernel(const VT *__r
 #pragma unroll
     for (int r = 0; r < MAXR; ++r) {
         const int pt = gl + r * G;
-        lg[r] = (pt < LP) ? logits[(size_t)gq * LP + pt] : -INFINITY;
+        lg[r] = (pt < LP) ? logits[so_lg_index(dm, bq, h, LP, pt)] : -INFINITY;
         mx = fmaxf(mx, lg[r]);
     }
 #pragma unroll
@@ -627,8 +626,8 @@ __global__ __launch_bounds__(256) void msda_fused_bwd_point_kernel(const VT *__r
         const int l = so_level_of(ptc, dm.P, dm.L);
         const int pp = ptc - l * dm.P;
         const int Hl = shapes[2 * l], Wl = shapes[2 * l + 1];
-        const size_t idx = (size_t)gq * LP + ptc;
-        const float2 o = *(const float2 *)(off_raw + 2 * idx);
+        const size_t oidx = so_off_index(dm, bq, h, LP, ptc);
+        const float2 o = *(const float2 *)(off_raw + oidx);
         size_t ri;
         if (ref_kind == 1) ri = (size_t)bq * dm.P + pp;
         else if (ref_kind == 2) ri = ((size_t)bq * dm.L + l) * dm.P + pp;
@@ -666,7 +665,7 @@ __global__ __launch_bounds__(256) void msda_fused_bwd_point_kernel(const VT *__r
                 gy = (float)Hl * gh * aw;
             }
             // loc = ref + off / (W, H)  =>  g_off = g_loc / (W, H)
-            *(float2 *)(g_off + 2 * idx) = make_float2(gx / (float)Wl, gy / (float)Hl);
+            *(float2 *)(g_off + oidx) = make_float2(gx / (float)Wl, gy / (float)Hl);
             sum_l = fmaf(aw, ga[r], sum_l);
             const size_t ki = ((((size_t)b * dm.heads + h) * dm.L + l) * dm.nq + q) * dm.P + pp;
             keys[ki] = (int16_t)(bl.any ? bl.h_low : kKeyOutside);
@@ -678,7 +677,7 @@ __global__ __launch_bounds__(256) void msda_fused_bwd_point_kernel(const VT *__r
 #pragma unroll
     for (int r = 0; r < MAXR; ++r) {
         const int pt = gl + r * G;
-        if (live && pt < LP) g_logits[(size_t)gq * LP + pt] = (lg[r] * iden) * (ga[r] - sum_l);
+        if (live && pt < LP) g_logits[so_lg_index(dm, bq, h, LP, pt)] = (lg[r] * iden) * (ga[r] - sum_l);
     }
 }
 
@@ -732,7 +731,7 @@ __global__ __launch_bounds__(256) void msda_cross_bwd_point_kernel(const VT *__r
 #pragma unroll
     for (int r = 0; r < MAXR; ++r) {
         const int pt = gl + r * G;
-        lg[r] = (pt < LP) ? logits[(size_t)gq * LP + pt] : -INFINITY;
+        lg[r] = (pt < LP) ? logits[so_lg_index(dm, q, h, LP, pt)] : -INFINITY;
         mx = fmaxf(mx, lg[r]);
     }
 #pragma unroll
@@ -746,7 +745,7 @@ __global__ __launch_bounds__(256) void msda_cross_bwd_point_kernel(const VT *__r
         ox[r] = oy[r] = 0.0f;
         if (pt < LP) {
             const int l = so_level_of(pt, dm.P, dm.L);
-            const float2 o = *(const float2 *)(off_raw + 2 * ((size_t)gq * LP + pt));
+            const float2 o = *(const float2 *)(off_raw + so_off_index(dm, q, h, LP, pt));
             ox[r] = o.x / (float)shapes[2 * l + 1];
             oy[r] = o.y / (float)shapes[2 * l];
         }
@@ -867,9 +866,8 @@ __global__ __launch_bounds__(256) void msda_cross_bwd_point_kernel(const VT *__r
     for (int r = 0; r < MAXR; ++r) {
         const int pt = gl + r * G;
         if (live && pt < LP) {
-            const size_t idx = (size_t)gq * LP + pt;
-            g_logits[idx] = (lg[r] * iden) * (ga[r] - sum_l);
-            *(float2 *)(g_off + 2 * idx) = make_float2(gxs[r] / cnt, gys[r] / cnt);
+            g_logits[so_lg_index(dm, q, h, LP, pt)] = (lg[r] * iden) * (ga[r] - sum_l);
+            *(float2 *)(g_off + so_off_index(dm, q, h, LP, pt)) = make_float2(gxs[r] / cnt, gys[r] / cnt);
         }
     }
 }
@@ -1270,10 +1268,27 @@ extern "C" int selfocc_msda_fwd(const float *value, const int32_t *shapes, const
         }                                                                                 \
     } while (0)
 
+// off_raw / logits row strides of a launch: dense tensors, or one merged [offsets | logits] projection row per query
+static inline int so_set_ol(MsdaDims &dm, int ol_stride, const float *off_raw, const float *logits, const char *who) {
+    const int LP = dm.L * dm.P;
+    if (ol_stride == 0) {
+        dm.off_ld = dm.heads * LP * 2;
+        dm.lg_ld = dm.heads * LP;
+        return 0;
+    }
+    SO_REQUIRE(ol_stride >= 3 * dm.heads * LP && ol_stride % 2 == 0, "%s: ol_stride must be 0 (dense) or an even number >= 3 * heads * L * P = %d (got %d)",
+               who, 3 * dm.heads * LP, ol_stride);
+    SO_REQUIRE((((uintptr_t)off_raw) & 7) == 0, "%s: off_raw must be 8-byte aligned", who);
+    SO_REQUIRE((long long)dm.bs * dm.nq * ol_stride < (1LL << 40), "%s: offsets / logits too large", who);
+    dm.off_ld = dm.lg_ld = ol_stride;
+    return 0;
+}
+
 extern "C" int selfocc_msda_fused_fwd(const void *value, const int32_t *shapes, const int32_t *starts,
                                       const float *ref, int32_t ref_kind, const float *off_raw, const float *logits,
                                       float *out, int32_t bs, int32_t nv, int32_t nq, int32_t heads, int32_t d,
-                                      int32_t L, int32_t P, int32_t value_layout, int32_t value_dtype, void *stream) {
+                                      int32_t L, int32_t P, int32_t value_layout, int32_t value_dtype, int32_t ol_stride,
+                                      void *stream) {
     if (validate((const float *)value, shapes, starts, off_raw, logits, bs, nv, nq, heads, d, L, P)) return -1;
     const long long n_groups = (long long)bs * nq * heads;
     if (n_groups == 0) return 0;
@@ -1291,6 +1306,7 @@ extern "C" int selfocc_msda_fused_fwd(const void *value, const int32_t *shapes, 
     const long long blocks = (n_groups + gpb - 1) / gpb;
     SO_REQUIRE(blocks < (1LL << 31), "msda_fused_fwd: grid too large");
     MsdaDims dm{bs, nv, nq, heads, L, P, 0, 0, value_layout};
+    if (so_set_ol(dm, ol_stride, off_raw, logits, "msda_fused_fwd")) return -1;
     hipStream_t st = (hipStream_t)stream;
 #define SO_LAUNCH_VT(DD, LG, VT) \
         hipLaunchKernelGGL((msda_fused_fwd_kernel<DD, LG, VT>), dim3((unsigned)blocks), dim3(256), 0, st, \
@@ -1304,7 +1320,7 @@ extern "C" int selfocc_msda_cross_fwd(const void *value, const int32_t *shapes, 
                                       const float *ref, const uint8_t *vis, const float *off_raw,
                                       const float *logits, float *out, int32_t cams, int32_t nv, int32_t nq,
                                       int32_t heads, int32_t d, int32_t L, int32_t P, int32_t value_stride,
-                                      int32_t value_layout, int32_t value_dtype, void *stream) {
+                                      int32_t value_layout, int32_t value_dtype, int32_t ol_stride, void *stream) {
     SO_REQUIRE(cams >= 1, "msda_cross_fwd: cams must be >= 1");
     SO_REQUIRE(value_dtype == SO_DTYPE_F32 || value_dtype == SO_DTYPE_BF16, "msda_cross_fwd: bad value_dtype");
     SO_REQUIRE(value_layout == SO_VALUE_PIXEL_MAJOR || (value_layout == SO_VALUE_HEAD_MAJOR && value_stride == 0),
@@ -1327,6 +1343,7 @@ extern "C" int selfocc_msda_cross_fwd(const void *value, const int32_t *shapes, 
     const long long blocks = (n_groups + gpb - 1) / gpb;
     SO_REQUIRE(blocks < (1LL << 31), "msda_cross_fwd: grid too large");
     MsdaDims dm{1, nv, nq, heads, L, P, 0, value_stride, value_layout};
+    if (so_set_ol(dm, ol_stride, off_raw, logits, "msda_cross_fwd")) return -1;
     hipStream_t st = (hipStream_t)stream;
 #define SO_LAUNCH_VT(DD, LG, VT) \
         hipLaunchKernelGGL((msda_cross_fwd_kernel<DD, LG, VT>), dim3((unsigned)blocks), dim3(256), 0, st, \
@@ -1551,7 +1568,8 @@ extern "C" int selfocc_msda_fused_bwd(const void *value, const int32_t *shapes, 
                                       const float *off_raw, const float *logits, const float *g_out,
                                       float *g_value, float *g_off, float *g_logits, int32_t bs, int32_t nv,
                                       int32_t nq, int32_t heads, int32_t d, int32_t L, int32_t P, int32_t value_layout,
-                                      int32_t value_dtype, void *workspace, size_t workspace_bytes, void *stream) {
+                                      int32_t value_dtype, int32_t ol_stride, void *workspace, size_t workspace_bytes,
+                                      void *stream) {
     if (validate((const float *)value, shapes, starts, off_raw, logits, bs, nv, nq, heads, d, L, P)) return -1;
     SO_REQUIRE(value_dtype == SO_DTYPE_F32 || value_dtype == SO_DTYPE_BF16, "msda_fused_bwd: bad value_dtype");
     const long long n_groups = (long long)bs * nq * heads;
@@ -1572,7 +1590,11 @@ extern "C" int selfocc_msda_fused_bwd(const void *value, const int32_t *shapes, 
                        "(check selfocc_msda_banded_supported and use the unfused op)");
     hipStream_t st = (hipStream_t)stream;
     MsdaDims dm{bs, nv, nq, heads, L, P, 0, 0, value_layout};
+    if (so_set_ol(dm, ol_stride, off_raw, logits, "msda_fused_bwd")) return -1;
+    SO_REQUIRE(ol_stride == 0 || (((uintptr_t)g_off) & 7) == 0, "msda_fused_bwd: g_off must be 8-byte aligned");
     if (nv == 0) {   // every point is outside every (empty) map: all gradients are zero
+        if (ol_stride)   // merged rows: [offsets | logits] of a query are adjacent
+            return (int)hipMemset2DAsync(g_off, (size_t)ol_stride * sizeof(float), 0, (size_t)3 * heads * LP * sizeof(float), (size_t)bs * nq, st);
         (void)hipMemsetAsync(g_off, 0, (size_t)n_groups * LP * 2 * sizeof(float), st);
         return (int)hipMemsetAsync(g_logits, 0, (size_t)n_groups * LP * sizeof(float), st);
     }
@@ -1599,7 +1621,8 @@ extern "C" int selfocc_msda_cross_bwd(const void *value, const int32_t *shapes, 
                                       const float *off_raw, const float *logits, const float *g_out,
                                       float *g_value, float *g_off, float *g_logits, int32_t cams, int32_t nv,
                                       int32_t nq, int32_t heads, int32_t d, int32_t L, int32_t P, int32_t value_layout,
-                                      int32_t value_dtype, void *workspace, size_t workspace_bytes, void *stream) {
+                                      int32_t value_dtype, int32_t ol_stride, void *workspace, size_t workspace_bytes,
+                                      void *stream) {
     SO_REQUIRE(cams >= 1, "msda_cross_bwd: cams must be >= 1");
     SO_REQUIRE(value_dtype == SO_DTYPE_F32 || value_dtype == SO_DTYPE_BF16, "msda_cross_bwd: bad value_dtype");
     SO_REQUIRE(value_layout == SO_VALUE_PIXEL_MAJOR || value_layout == SO_VALUE_HEAD_MAJOR, "msda_cross_bwd: bad value_layout");
@@ -1621,11 +1644,15 @@ extern "C" int selfocc_msda_cross_bwd(const void *value, const int32_t *shapes, 
                        "(check selfocc_msda_banded_supported with bs = cams)");
     hipStream_t st = (hipStream_t)stream;
     const long long n_pts = (long long)cams * nq * heads * LP;
+    MsdaDims dm{cams, nv, nq, heads, L, P, 1, 0, value_layout};
+    if (so_set_ol(dm, ol_stride, off_raw, logits, "msda_cross_bwd")) return -1;
+    SO_REQUIRE(ol_stride == 0 || (((uintptr_t)g_off) & 7) == 0, "msda_cross_bwd: g_off must be 8-byte aligned");
     if (nv == 0) {
+        if (ol_stride)
+            return (int)hipMemset2DAsync(g_off, (size_t)ol_stride * sizeof(float), 0, (size_t)3 * heads * LP * sizeof(float), (size_t)nq, st);
         (void)hipMemsetAsync(g_off, 0, (size_t)n_groups * LP * 2 * sizeof(float), st);
         return (int)hipMemsetAsync(g_logits, 0, (size_t)n_groups * LP * sizeof(float), st);
     }
-    MsdaDims dm{cams, nv, nq, heads, L, P, 1, 0, value_layout};
     const BandWorkspace w = so_band_workspace(workspace, cams, nq, heads, L, P);
     // the point kernel writes the keys of every (camera, query) pair it visits; the bin kernels skip the others by
     // `vis` (P >= 4), otherwise the unvisited keys are preset to "outside"

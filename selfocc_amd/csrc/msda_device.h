@@ -8,7 +8,18 @@ struct MsdaDims {
     int go_shared;   // band kernel: g_out has one row per (query, head) shared by all batch items (camera loop)
     int vs;          // camera-loop forward: floats between consecutive pixels of `value` (0 = dense: heads * D)
     int hm;          // value / grad_value layout: 0 = (bs, nv, heads, D) (mmcv), 1 = head-major (bs, heads, nv, D)
+    int off_ld, lg_ld;   // floats between consecutive QUERY rows of the raw offsets / attention logits (and of their gradients).
+                         // Dense tensors: heads * L * P * 2 and heads * L * P.  One merged projection row per query
+                         // [heads * L * P * 2 offsets | heads * L * P logits] (round 6): 3 * heads * L * P for both.
 };
+
+// float index of point pt's raw offset pair / attention logit of (query row bq, head h); LP = L * P
+SO_DEVFN size_t so_off_index(const MsdaDims &dm, long long bq, int h, int LP, int pt) {
+    return (size_t)bq * dm.off_ld + ((size_t)h * LP + pt) * 2;
+}
+SO_DEVFN size_t so_lg_index(const MsdaDims &dm, long long bq, int h, int LP, int pt) {
+    return (size_t)bq * dm.lg_ld + (size_t)h * LP + pt;
+}
 
 // Addressing of `value` / `grad_value` in either layout.  Head-major puts the D channels of horizontally adjacent
 // pixels of ONE head next to each other (64-byte segments back to back), so that the two x-corners of a bilinear

@@ -356,6 +356,62 @@ class _TallLinearHeadsMulti(torch.autograd.Function):
         return (dx, None, *grads)
 
 
+class _TallLinearMerged(torch.autograd.Function):
+    """G Linears of the SAME rows as ONE projection with the weights stacked: y (T, N_1 + ... + N_G).  Used for the
+    `sampling_offsets` | `attention_weights` pair of every deformable attention (image_cross_attention.py:296-312 and
+    cross_view_hybrid_attention.py:78-90 read the same `query` twice): one read of x and one launch forward, and — because
+    the MSDA backward writes the gradient of the merged row (ABI 32 ``ol_stride``) — ONE input-gradient pass, ONE
+    weight-gradient pass and no gradient add in backward, instead of two each and an add."""
+
+    @staticmethod
+    @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
+    def forward(ctx, x, *wb):
+        w = torch.cat(wb[0::2], 0)
+        b = torch.cat(wb[1::2], 0)
+        ctx.save_for_backward(x, w)
+        ctx.sizes = [t.shape[0] for t in wb[0::2]]
+        if FUSED_LINEAR_FWD and _linear_fwd_ok(x, w):
+            return linear_fwd(x, w, b)
+        return torch.addmm(b, x, w.t())
+
+    @staticmethod
+    @torch.amp.custom_bwd(device_type='cuda')
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx, dw, db = _tall_linear_backward(x, w, dy, True, ctx.needs_input_grad[0])
+        grads, o = [], 0
+        for n in ctx.sizes:
+            grads += [dw[o:o + n], db[o:o + n]]
+            o += n
+        return (dx, *grads)
+
+
+# sampling_offsets | attention_weights as one projection (env SELFOCC_MERGED_OFF_LOGITS=0: two Linears, as until round 5)
+MERGED_OFF_LOGITS = os.environ.get('SELFOCC_MERGED_OFF_LOGITS', '1') == '1'
+
+
+def merged_off_logits(module, x2d):
+    """(T, 3 * heads * L * P) rows [heads*L*P*2 raw offsets | heads*L*P logits] = the module's `sampling_offsets` and
+    `attention_weights` Linears of the rows ``x2d`` (T, K) in ONE projection, or None when the module / input does not qualify
+    (the caller then runs the two Linears).  Same parameters, same state-dict keys; under autograd the result carries one
+    backward for both (``_TallLinearMerged``)."""
+    so, aw = module.sampling_offsets, module.attention_weights
+    if not (MERGED_OFF_LOGITS and x2d.is_cuda and x2d.dtype == torch.float32 and not torch.is_autocast_enabled()
+            and so.bias is not None and aw.bias is not None and so.weight.dtype == torch.float32
+            and so.weight.shape[0] == 2 * aw.weight.shape[0] and x2d.shape[0] >= LINEAR_FWD_MIN_ROWS):
+        return None
+    if torch.is_grad_enabled() and (x2d.requires_grad or so.weight.requires_grad or aw.weight.requires_grad):
+        return _TallLinearMerged.apply(x2d, so.weight, so.bias, aw.weight, aw.bias)
+    key = tuple((t._version, t.data_ptr()) for t in (so.weight, so.bias, aw.weight, aw.bias))
+    cache = getattr(module, '_ol_cache', None)
+    if cache is None or cache[0] != key:           # stacked once, rebuilt when a parameter changes
+        cache = module._ol_cache = (key, torch.cat([so.weight, aw.weight], 0).detach(), torch.cat([so.bias, aw.bias], 0).detach())
+    w, b = cache[1], cache[2]
+    if FUSED_LINEAR_FWD and _linear_fwd_ok(x2d, w):
+        return linear_fwd(x2d, w, b)
+    return torch.addmm(b, x2d, w.t())
+
+
 class TallLinear(nn.Linear):
     """nn.Linear (same parameters / state-dict keys) whose training forward goes through ``_TallLinear``
     when the input has many rows: the encoder's projections see 66 k - 153 k rows x 96 features, and the
@@ -480,14 +536,28 @@ def deformable_sampling(module, query, value, reference_points, spatial_shapes, 
         raise ValueError('Last dim of reference_points must be 2 on the SelfOcc path, '
                          f'got {reference_points.shape[-1]}')
     LP = module.num_levels * module.num_points
-    off = module.sampling_offsets(query).view(bs, num_query, module.num_heads, module.num_levels,
-                                              module.num_points, 2)
     d_head = module.value_proj.weight.shape[0] // module.num_heads
     use_bf16 = VALUE_BF16 and d_head == 16          # the bfloat16 gathers are built for 16 channels per head only
-    if not torch.is_grad_enabled() and LP <= 256 and msda_fused_kernels_built(d_head):
+    kind = {'level': 0, 'point': 1, 'level_point': 2}[per_level_reference]
+    fused_inf = not torch.is_grad_enabled() and LP <= 256 and msda_fused_kernels_built(d_head)
+    fused_train = False
+    if not fused_inf and FUSED_TRAINING and value.is_cuda and LP <= 256:
+        host = getattr(spatial_shapes, '_so_host', None)
+        if host is None:
+            host = [int(v) for v in spatial_shapes.reshape(-1).tolist()]
+        fused_train = msda_fused_supported(host, bs, num_query, module.num_heads, d_head, module.num_levels, module.num_points)
+    # sampling_offsets | attention_weights: ONE projection with the stacked weight for the fused kernels (they read — and
+    # in backward write — the merged row in place), the two Linears of the reference otherwise
+    ol = merged_off_logits(module, query.reshape(bs * num_query, -1)) if (fused_inf or fused_train) else None
+    if ol is not None:
+        ol, off, logits, mlp = ol.view(bs, num_query, -1), None, None, (module.num_levels, module.num_points)
+    else:
+        mlp = None
+        off = module.sampling_offsets(query).view(bs, num_query, module.num_heads, module.num_levels, module.num_points, 2)
+    if fused_inf:
         # inference: softmax + sampling-location prologue fused into the HIP kernel (no loc / weight tensors)
-        logits = module.attention_weights(query).view(bs, num_query, module.num_heads, LP)
-        kind = {'level': 0, 'point': 1, 'level_point': 2}[per_level_reference]
+        if ol is None:
+            logits = module.attention_weights(query).view(bs, num_query, module.num_heads, LP)
         hm = HEAD_MAJOR_VALUE
         if v_hm is not None:
             value, hm = v_hm.view(v_hm.shape[1:]), True      # G = 1: a view (select's backward is a zero fill + a copy)
@@ -495,22 +565,19 @@ def deformable_sampling(module, query, value, reference_points, spatial_shapes, 
             value = to_head_major(value)
         if use_bf16:
             value = value.to(torch.bfloat16)
-        return msda_fused_inference(value, spatial_shapes, level_start_index, reference_points, kind, off, logits, hm)
-    if FUSED_TRAINING and value.is_cuda and LP <= 256:
+        return msda_fused_inference(value, spatial_shapes, level_start_index, reference_points, kind,
+                                    ol if ol is not None else off, logits, hm, mlp)
+    if fused_train:
         # training: the same fusion in both directions (no loc / weight tensors, no softmax / normalise kernels)
-        host = getattr(spatial_shapes, '_so_host', None)
-        if host is None:
-            host = [int(v) for v in spatial_shapes.reshape(-1).tolist()]
-        if msda_fused_supported(host, bs, num_query, module.num_heads, d_head, module.num_levels, module.num_points):
+        if ol is None:
             logits = module.attention_weights(query).view(bs, num_query, module.num_heads, LP)
-            kind = {'level': 0, 'point': 1, 'level_point': 2}[per_level_reference]
-            hm = HEAD_MAJOR_VALUE
-            if v_hm is not None:
-                value, hm = v_hm.view(v_hm.shape[1:]), True      # G = 1: a view (select's backward is a zero fill + a copy)
-            elif HEAD_MAJOR_VALUE:
-                value = to_head_major(value)
-            return MSDAFusedFunction.apply(value, spatial_shapes, level_start_index, reference_points, kind, off,
-                                           logits, host, hm, use_bf16)
+        hm = HEAD_MAJOR_VALUE
+        if v_hm is not None:
+            value, hm = v_hm.view(v_hm.shape[1:]), True      # G = 1: a view (select's backward is a zero fill + a copy)
+        elif HEAD_MAJOR_VALUE:
+            value = to_head_major(value)
+        return MSDAFusedFunction.apply(value, spatial_shapes, level_start_index, reference_points, kind,
+                                       ol if ol is not None else off, logits, host, hm, use_bf16, mlp)
     if v_hm is not None:      # (the unfused fallback below wants the mmcv layout)
         value = v_hm.view(v_hm.shape[1:]).permute(0, 2, 1, 3).contiguous()
     aw = module.attention_weights(query).view(bs, num_query, module.num_heads,

@@ -193,14 +193,20 @@ class BEVCrossAttention(BaseModule):
         if bf16 and host_shapes is None and v.dtype != torch.bfloat16:
             v = v.to(torch.bfloat16)
         q2 = query.reshape(-1, query.shape[-1])   # bs == 1; a view, not query[0]: select's backward is a zero fill + a copy
-        off = da.sampling_offsets(q2).view(-1, heads, L, P, 2)
-        logits = da.attention_weights(q2).view(-1, heads, L * P)
+        # sampling_offsets | attention_weights of the (un-rebatched) queries: ONE projection with the stacked weight, read
+        # in place by the kernel (bricks.merged_off_logits), else the two Linears
+        off = bricks.merged_off_logits(da, q2)
+        mlp = (L, P) if off is not None else None
+        logits = None
+        if off is None:
+            off = da.sampling_offsets(q2).view(-1, heads, L, P, 2)
+            logits = da.attention_weights(q2).view(-1, heads, L * P)
         if host_shapes is None:
             slots = msda_cross_inference(v, spatial_shapes, level_start_index, reference_points_cams[:, 0], visible,
-                                         off, logits, hm)[None]
+                                         off, logits, hm, mlp)[None]
         else:
             slots = MSDACrossFunction.apply(v, spatial_shapes, level_start_index, reference_points_cams[:, 0], visible,
-                                            off, logits, host_shapes, hm, bf16)[None]
+                                            off, logits, host_shapes, hm, bf16, mlp)[None]
         if not self.training and not torch.is_grad_enabled():
             # eval: dropout is the identity; output_proj + residual (+ the layer's next norm) in one launch, written
             # straight into the caller's slice of the concatenated plane buffer (`out`)

@@ -145,8 +145,29 @@ def _value_dims(value, head_major):
     return bs, nv, heads, d
 
 
+def _off_logits_args(sampling_offsets, attention_logits, heads, merged_LP):
+    """(off tensor kept alive, off pointer, logits pointer, nq-leading shape, L, P, ol_stride) for the fused / camera-loop
+    entry points.  Two forms: the dense pair ``sampling_offsets (..., nq, h, L, P, 2)`` + ``attention_logits (..., nq, h, L*P)``,
+    or — ``attention_logits is None`` — ONE merged projection output ``sampling_offsets (..., nq, 3 * h * L * P)`` whose rows
+    are [h*L*P*2 raw offsets | h*L*P logits] (the stacked sampling_offsets | attention_weights Linear, ABI 32 ``ol_stride``);
+    ``merged_LP = (L, P)``."""
+    import ctypes
+    if attention_logits is not None:
+        off = sampling_offsets.contiguous().float()
+        lg = attention_logits.contiguous().float()
+        L, P = off.shape[-3], off.shape[-2]
+        return (off, lg), ptr(off), ptr(lg), off.shape[:-4], L, P, 0
+    L, P = merged_LP
+    ol = sampling_offsets
+    n = 3 * heads * L * P
+    assert ol.shape[-1] == n and ol.dtype == torch.float32, (tuple(ol.shape), n)
+    if ol.stride(-1) != 1 or (ol.dim() > 1 and ol.stride(-2) % 2) or not ol.reshape(-1, n).is_contiguous():
+        ol = ol.contiguous()
+    return (ol,), ptr(ol), ctypes.c_void_p(ol.data_ptr() + 8 * heads * L * P), ol.shape[:-1], L, P, n
+
+
 def msda_fused_inference(value, spatial_shapes, level_start_index, reference_points, ref_kind, sampling_offsets,
-                         attention_logits, head_major=False):
+                         attention_logits, head_major=False, merged_LP=None):
     """Inference-only fused op (no autograd): value (bs,nv,h,d), or (bs,h,nv,d) with ``head_major``;
     reference_points per ``ref_kind``
     (0: (bs,nq,L,2), 1: (bs,nq,P,2), 2: (bs,nq,L,P,2)); sampling_offsets (bs,nq,h,L,P,2) raw linear
@@ -154,22 +175,21 @@ def msda_fused_inference(value, spatial_shapes, level_start_index, reference_poi
     if not value.is_cuda:
         raise RuntimeError("msda_fused_inference needs CUDA(HIP) tensors: selfocc_amd has no CPU fallback")
     bs, nv, heads, d = _value_dims(value, head_major)
-    _, nq, _, L, P, _ = sampling_offsets.shape
+    keep, p_off, p_lg, lead, L, P, ols = _off_logits_args(sampling_offsets, attention_logits, heads, merged_LP)
+    nq = lead[-1]
     value, vdt = _value_arg(value)
-    off = sampling_offsets.contiguous().float()
-    lg = attention_logits.contiguous().float()
     ref = reference_points.contiguous().float()
     sh, st = _i32(spatial_shapes, value.device), _i32(level_start_index, value.device)
     out = torch.empty(bs, nq, heads * d, device=value.device, dtype=torch.float32)
-    check(lib().selfocc_msda_fused_fwd(ptr(value), ptr(sh), ptr(st), ptr(ref), int(ref_kind), ptr(off), ptr(lg),
-                                       ptr(out), bs, nv, nq, heads, d, L, P, int(bool(head_major)), vdt,
+    check(lib().selfocc_msda_fused_fwd(ptr(value), ptr(sh), ptr(st), ptr(ref), int(ref_kind), p_off, p_lg,
+                                       ptr(out), bs, nv, nq, heads, d, L, P, int(bool(head_major)), vdt, ols,
                                        current_stream(value.device)),
           "selfocc_msda_fused_fwd")
     return out
 
 
 def msda_cross_inference(value, spatial_shapes, level_start_index, reference_points_cam, visible,
-                         sampling_offsets, attention_logits, head_major=False):
+                         sampling_offsets, attention_logits, head_major=False, merged_LP=None):
     """Inference-only camera-loop op (no autograd): the sampling stage of BEVCrossAttention
     (bevformer/attention/image_cross_attention.py:90-136) without re-batching.
     value (cams,nv,h,d), or (cams,h,nv,d) with ``head_major``; reference_points_cam (cams,nq,P,2); visible (cams,nq) bool — the cameras that see
@@ -178,7 +198,8 @@ def msda_cross_inference(value, spatial_shapes, level_start_index, reference_poi
     if not value.is_cuda:
         raise RuntimeError("msda_cross_inference needs CUDA(HIP) tensors: selfocc_amd has no CPU fallback")
     cams, nv, heads, d = _value_dims(value, head_major)
-    nq, _, L, P, _ = sampling_offsets.shape
+    keep, p_off, p_lg, lead, L, P, ols = _off_logits_args(sampling_offsets, attention_logits, heads, merged_LP)
+    nq = lead[-1]
     vstride = 0
     vdt = abi.DTYPE_BF16 if value.dtype == torch.bfloat16 else abi.DTYPE_F32
     if (not head_major and value.dtype in (torch.float32, torch.bfloat16) and not value.is_contiguous()
@@ -187,15 +208,13 @@ def msda_cross_inference(value, spatial_shapes, level_start_index, reference_poi
         vstride = value.stride(1)        # a column block of a wider (cams * nv, N) matrix: no copy
     else:
         value, vdt = _value_arg(value)
-    off = sampling_offsets.contiguous().float()
-    lg = attention_logits.contiguous().float()
     ref = reference_points_cam.contiguous().float()
     vis = _u8(visible)
     assert ref.shape == (cams, nq, P, 2) and vis.shape == (cams, nq)
     sh, st = _i32(spatial_shapes, value.device), _i32(level_start_index, value.device)
     out = torch.empty(nq, heads * d, device=value.device, dtype=torch.float32)
-    check(lib().selfocc_msda_cross_fwd(ptr(value), ptr(sh), ptr(st), ptr(ref), ptr(vis), ptr(off), ptr(lg),
-                                       ptr(out), cams, nv, nq, heads, d, L, P, vstride, int(bool(head_major)), vdt,
+    check(lib().selfocc_msda_cross_fwd(ptr(value), ptr(sh), ptr(st), ptr(ref), ptr(vis), p_off, p_lg,
+                                       ptr(out), cams, nv, nq, heads, d, L, P, vstride, int(bool(head_major)), vdt, ols,
                                        current_stream(value.device)),
           "selfocc_msda_cross_fwd")
     return out
@@ -209,14 +228,20 @@ class MSDAFusedFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, value, spatial_shapes, level_start_index, reference_points, ref_kind, sampling_offsets,
-                attention_logits, host_shapes, head_major=False, value_bf16=False):
+                attention_logits, host_shapes, head_major=False, value_bf16=False, merged_LP=None):
+        """``attention_logits is None``: ``sampling_offsets`` is the merged projection output (bs, nq, 3 h L P) (rows
+        [offsets | logits], ``merged_LP = (L, P)``) and the backward returns ONE gradient of that shape."""
         if value_bf16:      # bfloat16 STORAGE of value for the gathers (forward and backward); gradients stay float32
             value = value.to(torch.bfloat16)
         out = msda_fused_inference(value, spatial_shapes, level_start_index, reference_points, ref_kind,
-                                   sampling_offsets, attention_logits, head_major)
+                                   sampling_offsets, attention_logits, head_major, merged_LP)
         ctx.head_major = bool(head_major)
         sh, st = _i32(spatial_shapes, value.device), _i32(level_start_index, value.device)
-        ctx.save_for_backward(value, sh, st, reference_points, sampling_offsets, attention_logits)
+        ctx.merged_LP = merged_LP if attention_logits is None else None
+        if ctx.merged_LP is None:
+            ctx.save_for_backward(value, sh, st, reference_points, sampling_offsets, attention_logits)
+        else:
+            ctx.save_for_backward(value, sh, st, reference_points, sampling_offsets)
         ctx.ref_kind, ctx.host_shapes = int(ref_kind), list(host_shapes)
         return out
 
@@ -224,24 +249,32 @@ class MSDAFusedFunction(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, grad_output):
         import ctypes
-        value, sh, st, ref, off, lg = ctx.saved_tensors
-        ref, off, lg = (t.contiguous().float() for t in (ref, off, lg))
+        if ctx.merged_LP is None:
+            value, sh, st, ref, off, lg = ctx.saved_tensors
+        else:
+            (value, sh, st, ref, off), lg = ctx.saved_tensors, None
+        ref = ref.contiguous().float()
         value, vdt = _value_arg(value)
         bs, nv, heads, d = _value_dims(value, ctx.head_major)
-        _, nq, _, L, P, _ = off.shape
+        keep, p_off, p_lg, lead, L, P, ols = _off_logits_args(off, lg, heads, ctx.merged_LP)
+        nq = lead[-1]
         g_out = grad_output.contiguous().float()
         g_value = torch.zeros(value.shape, device=value.device, dtype=torch.float32)
-        g_off = torch.empty_like(off)
-        g_lg = torch.empty_like(lg)
+        if ols:
+            g_off = torch.empty(*lead, ols, device=value.device, dtype=torch.float32)
+            g_lg, pg_lg = None, ctypes.c_void_p(g_off.data_ptr() + 8 * heads * L * P)
+        else:
+            g_off, g_lg = torch.empty_like(keep[0]), torch.empty_like(keep[1])
+            pg_lg = ptr(g_lg)
         arr = (ctypes.c_int32 * len(ctx.host_shapes))(*ctx.host_shapes)
         nbytes = int(lib().selfocc_msda_bwd_banded_workspace(bs, nq, heads, L, P))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=value.device)
         check(lib().selfocc_msda_fused_bwd(ptr(value), ptr(sh), ptr(st), ctypes.cast(arr, ctypes.c_void_p), ptr(ref),
-                                           ctx.ref_kind, ptr(off), ptr(lg), ptr(g_out), ptr(g_value), ptr(g_off),
-                                           ptr(g_lg), bs, nv, nq, heads, d, L, P, int(ctx.head_major), vdt, ptr(ws), nbytes,
+                                           ctx.ref_kind, p_off, p_lg, ptr(g_out), ptr(g_value), ptr(g_off),
+                                           pg_lg, bs, nv, nq, heads, d, L, P, int(ctx.head_major), vdt, ols, ptr(ws), nbytes,
                                            current_stream(value.device)),
               "selfocc_msda_fused_bwd")
-        return g_value, None, None, None, None, g_off, g_lg, None, None, None
+        return g_value, None, None, None, None, g_off, g_lg, None, None, None, None
 
 
 def msda_fused_kernels_built(d, value_bf16=False):
@@ -266,15 +299,19 @@ class MSDACrossFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, value, spatial_shapes, level_start_index, reference_points_cam, visible, sampling_offsets,
-                attention_logits, host_shapes, head_major=False, value_bf16=False):
+                attention_logits, host_shapes, head_major=False, value_bf16=False, merged_LP=None):
+        """``attention_logits is None``: ``sampling_offsets`` is the merged projection output (nq, 3 h L P), see MSDAFusedFunction."""
         if value_bf16:
             value = value.to(torch.bfloat16)
         out = msda_cross_inference(value, spatial_shapes, level_start_index, reference_points_cam, visible,
-                                   sampling_offsets, attention_logits, head_major)
+                                   sampling_offsets, attention_logits, head_major, merged_LP)
         ctx.head_major = bool(head_major)
         sh, st = _i32(spatial_shapes, value.device), _i32(level_start_index, value.device)
-        ctx.save_for_backward(value, sh, st, reference_points_cam, _u8(visible), sampling_offsets,
-                              attention_logits)
+        ctx.merged_LP = merged_LP if attention_logits is None else None
+        if ctx.merged_LP is None:
+            ctx.save_for_backward(value, sh, st, reference_points_cam, _u8(visible), sampling_offsets, attention_logits)
+        else:
+            ctx.save_for_backward(value, sh, st, reference_points_cam, _u8(visible), sampling_offsets)
         ctx.host_shapes = list(host_shapes)
         return out
 
@@ -282,22 +319,30 @@ class MSDACrossFunction(torch.autograd.Function):
     @once_differentiable
     def backward(ctx, grad_output):
         import ctypes
-        value, sh, st, ref, vis, off, lg = ctx.saved_tensors
-        ref, off, lg = (t.contiguous().float() for t in (ref, off, lg))
+        if ctx.merged_LP is None:
+            value, sh, st, ref, vis, off, lg = ctx.saved_tensors
+        else:
+            (value, sh, st, ref, vis, off), lg = ctx.saved_tensors, None
+        ref = ref.contiguous().float()
         value, vdt = _value_arg(value)
         vis = vis.contiguous()
         cams, nv, heads, d = _value_dims(value, ctx.head_major)
-        nq, _, L, P, _ = off.shape
+        keep, p_off, p_lg, lead, L, P, ols = _off_logits_args(off, lg, heads, ctx.merged_LP)
+        nq = lead[-1]
         g_out = grad_output.contiguous().float()
         g_value = torch.zeros(value.shape, device=value.device, dtype=torch.float32)
-        g_off = torch.empty_like(off)
-        g_lg = torch.empty_like(lg)
+        if ols:
+            g_off = torch.empty(*lead, ols, device=value.device, dtype=torch.float32)
+            g_lg, pg_lg = None, ctypes.c_void_p(g_off.data_ptr() + 8 * heads * L * P)
+        else:
+            g_off, g_lg = torch.empty_like(keep[0]), torch.empty_like(keep[1])
+            pg_lg = ptr(g_lg)
         arr = (ctypes.c_int32 * len(ctx.host_shapes))(*ctx.host_shapes)
         nbytes = int(lib().selfocc_msda_bwd_banded_workspace(cams, nq, heads, L, P))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=value.device)
         check(lib().selfocc_msda_cross_bwd(ptr(value), ptr(sh), ptr(st), ctypes.cast(arr, ctypes.c_void_p), ptr(ref),
-                                           ptr(vis), ptr(off), ptr(lg), ptr(g_out), ptr(g_value), ptr(g_off),
-                                           ptr(g_lg), cams, nv, nq, heads, d, L, P, int(ctx.head_major), vdt, ptr(ws),
+                                           ptr(vis), p_off, p_lg, ptr(g_out), ptr(g_value), ptr(g_off),
+                                           pg_lg, cams, nv, nq, heads, d, L, P, int(ctx.head_major), vdt, ols, ptr(ws),
                                            nbytes, current_stream(value.device)),
               "selfocc_msda_cross_bwd")
-        return g_value, None, None, None, None, g_off, g_lg, None, None, None
+        return g_value, None, None, None, None, g_off, g_lg, None, None, None, None

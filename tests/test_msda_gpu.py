@@ -455,3 +455,106 @@ def test_msda_kernels_beside_a_bf16_mfma_kernel_on_another_stream(hip):
                     bad[k] += not torch.equal(f(), quiet[k])
             torch.cuda.synchronize()
     assert not any(bad.values()), f"launches (of 40) that differ from the quiet result: {bad}"
+
+
+@pytest.mark.parametrize("L,P,nq,cams", [(4, 8, 3001, 3), (3, 12, 1777, 0), (4, 48, 501, 2)])
+def test_merged_offset_logit_rows_equal_the_dense_pair(hip, L, P, nq, cams):
+    """ABI 32 ``ol_stride``: the fused / camera-loop kernels read the raw offsets and logits of a query from ONE merged row
+    [heads*L*P*2 offsets | heads*L*P logits] (the stacked sampling_offsets | attention_weights projection) and write the
+    gradient of that row — bit for bit what the dense pair gives, in both directions."""
+    from selfocc_amd.msda import (msda_fused_inference, msda_cross_inference, MSDAFusedFunction, MSDACrossFunction, to_head_major)
+    d0 = torch.device("cuda:0")
+    g = torch.Generator(device=d0).manual_seed(L * 100 + P)
+    heads, d = 6, 16
+    shapes = torch.tensor([[24, 50], [12, 25], [6, 13], [3, 7]][:L])
+    starts = torch.cat([shapes.new_zeros(1), (shapes[:, 0] * shapes[:, 1]).cumsum(0)[:-1]])
+    nv = int((shapes[:, 0] * shapes[:, 1]).sum())
+    sh, st = shapes.to(d0), starts.to(d0)
+    host = [int(v) for v in shapes.reshape(-1).tolist()]
+    nb = max(cams, 1)
+    v_hm = to_head_major(torch.randn(nb, nv, heads, d, device=d0, generator=g))
+    off = torch.randn(nq, heads, L, P, 2, device=d0, generator=g) * 2
+    lg = torch.randn(nq, heads, L * P, device=d0, generator=g)
+    ol = torch.cat([off.reshape(nq, -1), lg.reshape(nq, -1)], -1).contiguous()
+    gout = torch.randn(nq, heads * d, device=d0, generator=g)
+    if cams:
+        ref = torch.rand(cams, nq, P, 2, device=d0, generator=g) * 1.2 - 0.1
+        vis = torch.rand(cams, nq, device=d0, generator=g) < 0.5
+        a = msda_cross_inference(v_hm, sh, st, ref, vis, off, lg, True)
+        b = msda_cross_inference(v_hm, sh, st, ref, vis, ol, None, True, (L, P))
+        assert torch.equal(a, b)
+
+        def run(merged):
+            v = v_hm.clone().requires_grad_(True)
+            if merged:
+                x = ol.clone().requires_grad_(True)
+                MSDACrossFunction.apply(v, sh, st, ref, vis, x, None, host, True, False, (L, P)).backward(gout)
+                return v.grad, x.grad
+            o, l_ = off.clone().requires_grad_(True), lg.clone().requires_grad_(True)
+            MSDACrossFunction.apply(v, sh, st, ref, vis, o, l_, host, True, False).backward(gout)
+            return v.grad, torch.cat([o.grad.reshape(nq, -1), l_.grad.reshape(nq, -1)], -1)
+    else:
+        ref = torch.rand(1, nq, L, P, 2, device=d0, generator=g) * 1.1 - 0.05
+        a = msda_fused_inference(v_hm, sh, st, ref, 2, off[None], lg[None], True)
+        b = msda_fused_inference(v_hm, sh, st, ref, 2, ol[None], None, True, (L, P))
+        assert torch.equal(a, b)
+
+        def run(merged):
+            v = v_hm.clone().requires_grad_(True)
+            if merged:
+                x = ol[None].clone().requires_grad_(True)
+                MSDAFusedFunction.apply(v, sh, st, ref, 2, x, None, host, True, False, (L, P)).backward(gout[None])
+                return v.grad, x.grad[0]
+            o, l_ = off[None].clone().requires_grad_(True), lg[None].clone().requires_grad_(True)
+            MSDAFusedFunction.apply(v, sh, st, ref, 2, o, l_, host, True, False).backward(gout[None])
+            return v.grad, torch.cat([o.grad.reshape(nq, -1), l_.grad.reshape(nq, -1)], -1)
+    (gv_m, gol_m), (gv_d, gol_d) = run(True), run(False)
+    assert torch.equal(gol_m, gol_d)
+    assert torch.allclose(gv_m, gv_d, rtol=1e-5, atol=1e-6 * float(gv_d.abs().max()))        # grad_value: atomic order
+
+
+def test_merged_offset_logit_projection_module_equals_two_linears(hip, monkeypatch):
+    """bricks.merged_off_logits through a whole attention module: outputs and every parameter gradient equal the
+    two-Linear route (SELFOCC_MERGED_OFF_LOGITS off) to float32 rounding of the projections' summation order."""
+    from selfocc_amd.model import bricks
+    from selfocc_amd.registry import MODELS
+    import selfocc_amd.model  # noqa: F401
+    d0 = torch.device("cuda:0")
+    torch.manual_seed(3)
+    att = MODELS.build(dict(type='CrossViewHybridAttention', embed_dims=96, num_heads=6, num_levels=3, num_points=12,
+                            dropout=0.0, batch_first=True)).to(d0)
+    # the bilinear gradient w.r.t. a sampling location is piece-wise constant in the pixel cell, so two correct projections
+    # that differ in the last bit can put a location on either side of a pixel edge and move a few gradient entries by O(1)
+    # (measured here with random weights: 1e-3 of scale).  Dyadic queries / weights make both projections EXACT, hence equal.
+    gi = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for lin, sc in ((att.sampling_offsets, 64.0), (att.attention_weights, 64.0)):
+            lin.weight.copy_(torch.randint(-8, 9, lin.weight.shape, generator=gi).float() / sc)
+            lin.bias.copy_(torch.randint(-16, 17, lin.bias.shape, generator=gi).float() / 8.0)
+    sizes = [(33, 33), (9, 33), (33, 9)]
+    shapes = torch.tensor(sizes, device=d0)
+    shapes._so_host = [v for s_ in sizes for v in s_]
+    starts = torch.tensor([0, 33 * 33, 33 * 33 + 9 * 33], device=d0)
+    nq = sum(a * b for a, b in sizes)
+    q = (torch.randint(-16, 17, (1, nq, 96), generator=gi).float() / 8.0).to(d0)
+    ref = torch.rand(1, nq, 3, 12, 2, device=d0)
+    gy = torch.randn(1, nq, 96, device=d0)
+    res = {}
+    for merged in (True, False):
+        monkeypatch.setattr(bricks, 'MERGED_OFF_LOGITS', merged)
+        monkeypatch.setattr(bricks, 'LINEAR_FWD_MIN_ROWS', 64)
+        att.zero_grad(set_to_none=True)
+        qq = q.clone().requires_grad_(True)
+        att.train()
+        y = att(qq, reference_points=ref, spatial_shapes=shapes, level_start_index=starts)
+        y.backward(gy)
+        with torch.no_grad():
+            att.eval()
+            y_inf = att(q, reference_points=ref, spatial_shapes=shapes, level_start_index=starts)
+        res[merged] = (y.detach(), y_inf, qq.grad, {n: p.grad.clone() for n, p in att.named_parameters()})
+    ym, yim, gqm, gpm = res[True]
+    yd, yid, gqd, gpd = res[False]
+    err = lambda a, b: float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)      # of the tensor's scale
+    errs = dict(y=err(ym, yd), y_inference=err(yim, yid), g_query=err(gqm, gqd), **{n: err(gpm[n], gpd[n]) for n in gpd})
+    bad = {k: v for k, v in errs.items() if v > 1e-5}
+    assert not bad, (bad, errs)
