@@ -62,6 +62,14 @@ try:
     PMC = json.load(open(os.path.join(ROOT, "profiles", "pmc_msda.json")))
 except OSError:
     PMC = {}
+# the recorded counters are keyed by a hash of the kernels' sources (like profiles/pmc_traffic.json): counters taken on an
+# older build of the kernels are not attached to rows timed on this one
+sys.path.insert(0, ROOT)
+import bench as _bench
+PMC_STALE = bool(PMC) and PMC.get("sources_sha1") != _bench.sources_hash(_bench.MSDA_SOURCES)
+if PMC_STALE:
+    PMC = {"source": f"{PMC.get('source')}: measured on kernel sources {PMC.get('sources_sha1')} != current "
+                     f"{_bench.sources_hash(_bench.MSDA_SOURCES)} — not attached", "cases": {}}
 # row label -> the HIP kernels it launches (function names; the gathers are in the first one)
 HIP_KERNELS = (("linears + msda_cross_fwd", ["msda_cross_fwd_kernel"]),
                ("linears + msda_fused_fwd", ["msda_fused_fwd_kernel"]),

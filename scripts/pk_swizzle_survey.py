@@ -2,7 +2,7 @@
 Runs the isolated instruction-form victims of scripts/micro/xlane_probe_lib.hip on one HIP stream while the LIBRARY's bf16 x 3
 GEMM (selfocc_linear_fwd, the strong disturber of profiles/r5_b_packed_fp32_mfma.txt) loops on a second one, and appends
     {time, host, device name / uuid / pci bus, arch, per-form wrong-result counts, results per form}
-to gpurun_out/pk_swizzle_boxes.jsonl (copied to profiles/ per round).  ~10 s.  The probe library is built on first use:
+to gpurun_out/pk_swizzle_boxes/<time>_<uuid>.json (collected into profiles/r6_pk_swizzle_boxes.jsonl).  ~10 s.  The probe library is built on first use:
     hipcc --offload-arch=gfx950 -O3 -shared -fPIC -o scripts/micro/libxlane_probe.so scripts/micro/xlane_probe_lib.hip"""
 import ctypes as C
 import json
@@ -65,7 +65,8 @@ try:
     rec["rocm_smi"] = json.loads(out) if out.strip().startswith("{") else out.strip()[:300]
 except Exception as e:
     rec["rocm_smi"] = repr(e)[:100]
-os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-with open(os.path.join(ROOT, "gpurun_out", "pk_swizzle_boxes.jsonl"), "a") as f:
+# one FILE per lease (gpurun merges gpurun_out/ back by file name: a single appended file would be overwritten by the next lease)
+os.makedirs(os.path.join(ROOT, "gpurun_out", "pk_swizzle_boxes"), exist_ok=True)
+with open(os.path.join(ROOT, "gpurun_out", "pk_swizzle_boxes", f"{time.strftime('%Y%m%dT%H%M%S')}_{rec['uuid'][:8]}.json"), "w") as f:
     f.write(json.dumps(rec) + "\n")
 print(json.dumps(rec))

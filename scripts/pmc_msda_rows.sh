@@ -38,6 +38,8 @@ for case in ("cross_hw", "cross_zh", "self_xview"):
         out["cases"][case][k] = e
         per = e['gui_active'] / 8
         txt.append(f"   {k:58s} n={e['n']:3d} gui_active={e['gui_active']:.4g} ta_util={e['ta_busy_avr'] / per:.3f} ta_unit_util={e['ta_ta_busy_sum'] / 256 / per:.3f} tcp_accesses={e['tcp_total_cache_accesses']}")
+import sys; sys.path.insert(0, "$R"); import bench
+out["sources_sha1"] = bench.sources_hash(bench.MSDA_SOURCES)      # keys the record to the kernels it measured (bench_msda.py checks)
 json.dump(out, open("$R/gpurun_out/${TAG}_pmc_msda.json", "w"), indent=1)
 open("$R/gpurun_out/${TAG}_msda_ta_pmc.txt", "w").write("\n".join(txt) + "\n")
 print("\n".join(txt))

@@ -8,9 +8,9 @@ KRE='band_list|render_bwd_kernel|rb_brick|rb_count|bwd_point_kernel|msda_bin_ker
 rm -rf /tmp/pmcb; i=0
 for pass in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $pass --output-format csv -d /tmp/pmcb/p$i -o p -- python $R/scripts/bench_hotpath_train.py > /dev/null 2>&1
+  timeout 300 rocprofv3 --pmc $pass --output-format csv -d /tmp/pmcb/p$i -o p -- python $R/scripts/bench_hotpath_all.py --only nuscenes_occ --no-eval > /dev/null 2>&1
 done
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pmcb/trace -o p -- python $R/scripts/bench_hotpath_train.py > /dev/null 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pmcb/trace -o p -- python $R/scripts/bench_hotpath_all.py --only nuscenes_occ --no-eval > /dev/null 2>&1
 python - <<PY
 import csv, glob, collections, re, json
 KRE = re.compile(r"$KRE")
@@ -39,6 +39,8 @@ with open("$R/gpurun_out/${TAG}_train_bwd_pmc.txt", "w") as fo:
         g = lambda cn: (sum(agg[k][cn]) / len(agg[k][cn])) if agg[k].get(cn) else None
         out[k] = dict(calls=c, avg_us=round(us, 1), fetch_kb=g('FETCH_SIZE'), write_kb=g('WRITE_SIZE'))
 out["_round"] = "$TAG"
+import sys; sys.path.insert(0, "$R"); import bench
+out["_sources_sha1"] = bench.sources_hash(bench.BWD_SOURCES)      # keys the record to the kernels it measured (bench.py: roofline_bwd.sources_match)
 json.dump(out, open("$R/gpurun_out/${TAG}_pmc_bwd.json", "w"), indent=1)
 print(open("$R/gpurun_out/${TAG}_train_bwd_pmc.txt").read())
 PY

@@ -22,4 +22,21 @@ print(sys.argv[2], "n =", sys.argv[3], "rays/s", j["value"], "ms/step", j["ms_pe
       "devices", j["ranks_seen"]["distinct_devices"])
 PY
   done
+  # ONE SCALE-shaped JSON line per mode (what the driver's SCALE_rNN.json holds: per-N values; efficiency is the reader's to compute)
+  python - "$R" "$mode" <<'PY'
+import json, sys
+R, mode = sys.argv[1], sys.argv[2]
+per_n = {}
+for n in (1, 2, 4, 8):
+    try:
+        l = [x for x in open(f"{R}/gpurun_out/scale_{mode}_n{n}.json") if x.startswith("{")]
+        j = json.loads(l[-1])
+        per_n[str(n)] = {"value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "scaling": j["scaling"],
+                         "backend": j["ranks_seen"]["backend"], "distinct_devices": j["ranks_seen"]["distinct_devices"]}
+    except Exception as e:
+        per_n[str(n)] = {"error": repr(e)[:120]}
+line = {"metric": "rendered rays/sec (6-cam 450x800, 128 samples/ray)", "mode": mode, "per_n": per_n}
+open(f"{R}/gpurun_out/SCALE_{mode}.json", "w").write(json.dumps(line) + "\n")
+print(json.dumps(line))
+PY
 done
