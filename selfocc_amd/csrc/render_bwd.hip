@@ -324,10 +324,18 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba, 
     if constexpr (NF > 0) {
         float col[M][3];
         float rgb_l[3] = {0.0f, 0.0f, 0.0f};
-        // pass 1: interpolated colour per sample (kept), forward rgb for the clamp mask
+        // pass 1: ONE gather of the 8 corners' feature rows per sample (round 6: the colours used to be gathered here and the whole
+        // rows again in pass 2 — the corner gathers are 475 of the ray kernel's 994 us, profiles/r6_c_render_bwd_gather_bound.txt):
+        // interpolated colour (kept: forward rgb for the clamp mask) and, with semantics, the sample's softmax probabilities (kept)
+        // (the probabilities wait in lane-private LDS columns [j][k][thread], not in 21 registers: kept live across the ray
+        // reduction they pushed the 24-channel kernel from 213 to 256 + 24 registers — one wave per SIMD — or into scratch)
+        __shared__ float pk_s[(NSEM > 0 ? NSEM : 1) * M * 256];
 #pragma unroll
         for (int j = 0; j < M; ++j) {
             float f3[3] = {0.0f, 0.0f, 0.0f};
+            float lg[NSEM > 0 ? NSEM : 1];
+#pragma unroll
+            for (int k = 0; k < (NSEM > 0 ? NSEM : 1); ++k) lg[k] = 0.0f;
             const float fd[2] = {cell[j].fd0, cell[j].fd1}, fw[2] = {cell[j].fw0, cell[j].fw1}, fh[2] = {cell[j].fh0, cell[j].fh1};
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
@@ -336,21 +344,50 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba, 
                 const int hc = min(max(h, 0), H - 1), wc = min(max(ww, 0), W - 1), dc = min(max(d, 0), D - 1);
                 const float wgt = in ? (fd[kk & 1] * fw[(kk >> 1) & 1]) * fh[kk >> 2] : 0.0f;
                 const size_t vox = ((size_t)hc * W + wc) * D + dc;
-                float c3[3];
-                if constexpr (!BF16) {
-                    const float *p = (const float *)a.feat_vol + vox * NF;
-                    c3[0] = p[0]; c3[1] = p[1]; c3[2] = p[2];
-                } else {
-                    const uint16_t *p = (const uint16_t *)a.feat_vol + vox * NF;
-                    c3[0] = so_bf16_to_f32(p[0]); c3[1] = so_bf16_to_f32(p[1]); c3[2] = so_bf16_to_f32(p[2]);
-                }
+                if constexpr (NSEM > 0) {
+                    float f[NF];
+#ifdef SO_RB_NO_GATHER      // A/B build (scripts/build_variant.sh nogather render_bwd.hip -DSO_RB_NO_GATHER; timing only): no corner gathers —
+#pragma unroll              // the bound of "keep the forward's interpolated features".  (As a RUN-TIME switch the branch cost the shipped
+                    for (int k = 0; k < NF; ++k) f[k] = 0.01f * k;      // kernel 45 %: 1 040 -> 1 502 us.)
+#else
+                    load_feat<NF, BF16>(a.feat_vol, vox, f);
+#endif
 #pragma unroll
-                for (int k = 0; k < 3; ++k) f3[k] = fmaf(c3[k], wgt, f3[k]);
+                    for (int k = 0; k < 3; ++k) f3[k] = fmaf(f[k], wgt, f3[k]);
+#pragma unroll
+                    for (int k = 0; k < NSEM; ++k) lg[k] = fmaf(f[3 + k], wgt, lg[k]);
+                } else {
+                    float c3[3];
+#ifdef SO_RB_NO_GATHER
+                    c3[0] = 0.1f; c3[1] = 0.2f; c3[2] = 0.3f;
+#else
+                    if constexpr (!BF16) {
+                        const float *p = (const float *)a.feat_vol + vox * NF;
+                        c3[0] = p[0]; c3[1] = p[1]; c3[2] = p[2];
+                    } else {
+                        const uint16_t *p = (const uint16_t *)a.feat_vol + vox * NF;
+                        c3[0] = so_bf16_to_f32(p[0]); c3[1] = so_bf16_to_f32(p[1]); c3[2] = so_bf16_to_f32(p[2]);
+                    }
+#endif
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) f3[k] = fmaf(c3[k], wgt, f3[k]);
+                }
             }
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 col[j][k] = 0.28209479177387814f * f3[k] + 0.5f;  // pre-relu
                 rgb_l[k] = fmaf(w[j], fmaxf(col[j][k], 0.0f), rgb_l[k]);
+            }
+            if constexpr (NSEM > 0) {
+                float mx = lg[0];
+#pragma unroll
+                for (int k = 1; k < NSEM; ++k) mx = fmaxf(mx, lg[k]);
+                float den = 0.0f;
+#pragma unroll
+                for (int k = 0; k < NSEM; ++k) { lg[k] = so_expf(lg[k] - mx); den += lg[k]; }
+                const float iden = 1.0f / den;
+#pragma unroll
+                for (int k = 0; k < NSEM; ++k) pk_s[(j * NSEM + k) * 256 + threadIdx.x] = lg[k] * iden;
             }
         }
         float bgk[3] = {0.0f, 0.0f, 0.0f};
@@ -392,30 +429,12 @@ __global__ __launch_bounds__(256) void render_bwd_kernel(so_render_bwd_args ba, 
                     df[k] = (col[j][k] > 0.0f) ? g_rgb[k] * w[j] * 0.28209479177387814f : 0.0f;
                 }
                 if constexpr (NSEM > 0) {
-                    float lg[NSEM];
+                    float pk[NSEM];
 #pragma unroll
-                    for (int k = 0; k < NSEM; ++k) lg[k] = 0.0f;
-#pragma unroll
-                    for (int kk = 0; kk < 8; ++kk) {
-                        const int h = cell[j].h0 + (kk >> 2), ww = cell[j].w0 + ((kk >> 1) & 1), d = cell[j].d0 + (kk & 1);
-                        const bool in = (h >= 0) && (h < H) && (ww >= 0) && (ww < W) && (d >= 0) && (d < D);
-                        const int hc = min(max(h, 0), H - 1), wc = min(max(ww, 0), W - 1), dc = min(max(d, 0), D - 1);
-                        const float wgt = in ? (fd[kk & 1] * fw[(kk >> 1) & 1]) * fh[kk >> 2] : 0.0f;
-                        float f[NF];
-                        load_feat<NF, BF16>(a.feat_vol, ((size_t)hc * W + wc) * D + dc, f);
-#pragma unroll
-                        for (int k = 0; k < NSEM; ++k) lg[k] = fmaf(f[3 + k], wgt, lg[k]);
-                    }
-                    float mx = lg[0];
-#pragma unroll
-                    for (int k = 1; k < NSEM; ++k) mx = fmaxf(mx, lg[k]);
-                    float den = 0.0f, pk[NSEM];
-#pragma unroll
-                    for (int k = 0; k < NSEM; ++k) { pk[k] = so_expf(lg[k] - mx); den += pk[k]; }
-                    const float iden = 1.0f / den;
+                    for (int k = 0; k < NSEM; ++k) pk[k] = pk_s[(j * NSEM + k) * 256 + threadIdx.x];
                     float gp = 0.0f;
 #pragma unroll
-                    for (int k = 0; k < NSEM; ++k) { pk[k] *= iden; gp = fmaf(g_semr[k], pk[k], gp); }
+                    for (int k = 0; k < NSEM; ++k) gp = fmaf(g_semr[k], pk[k], gp);
                     Gw[j] += gp;
 #pragma unroll
                     for (int k = 0; k < NSEM; ++k) df[3 + k] = w[j] * pk[k] * (g_semr[k] - gp);  // softmax backward
