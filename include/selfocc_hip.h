@@ -238,7 +238,11 @@ int selfocc_msda_fused_fwd(const void *value, const int32_t *shapes, const int32
  * = ONE row per query [heads*L*P*2 raw offsets | heads*L*P logits], i.e. the output of the `sampling_offsets` and
  * `attention_weights` Linears computed as ONE projection with the two weights stacked (image_cross_attention.py:296-312
  * reads the same `query` twice); `logits` = `off_raw` + 2 * heads * L * P then, and the backward forms write the gradient
- * of that merged row, which is what ONE input-gradient and ONE weight-gradient pass of the stacked Linear consume. */
+ * of that merged row, which is what ONE input-gradient and ONE weight-gradient pass of the stacked Linear consume.
+ * g_value_stride (ABI 32; the two backward forms): 0 = g_value has the layout of `value`.  > 0 = g_value is written PIXEL-major
+ * into rows of that many floats — (bs | cams, nv) rows, this op's heads * d channels starting at the pointer —, i.e. straight
+ * into a column block of the row-major gradient of the (stacked) value projection: no head-major -> row-major transposing copy
+ * before its weight- / input-gradient passes.  The rows must be zero-initialised by the caller like g_value. */
 
 /* Camera-loop inference form: BEVCrossAttention's re-batch -> offset / weight linears -> MSDA ->
  * scatter-add -> divide-by-count (bevformer/attention/image_cross_attention.py:90-136) as ONE launch.
@@ -266,7 +270,8 @@ int selfocc_msda_cross_bwd(const void *value, const int32_t *shapes, const int32
                            const float *off_raw, const float *logits, const float *g_out,
                            float *g_value, float *g_off, float *g_logits, int32_t cams, int32_t nv,
                            int32_t nq, int32_t heads, int32_t d, int32_t L, int32_t P, int32_t value_layout,
-                           int32_t value_dtype, int32_t ol_stride, void *workspace, size_t workspace_bytes, void *stream);
+                           int32_t value_dtype, int32_t ol_stride, int32_t g_value_stride, void *workspace, size_t workspace_bytes,
+                           void *stream);
 
 /* g_value must be zero-initialised by the caller (atomically accumulated). */
 int selfocc_msda_bwd(const float *value, const int32_t *shapes, const int32_t *starts,
@@ -305,7 +310,8 @@ int selfocc_msda_fused_bwd(const void *value, const int32_t *shapes, const int32
                            const float *off_raw, const float *logits, const float *g_out,
                            float *g_value, float *g_off, float *g_logits, int32_t bs, int32_t nv,
                            int32_t nq, int32_t heads, int32_t d, int32_t L, int32_t P, int32_t value_layout,
-                           int32_t value_dtype, int32_t ol_stride, void *workspace, size_t workspace_bytes, void *stream);
+                           int32_t value_dtype, int32_t ol_stride, int32_t g_value_stride, void *workspace, size_t workspace_bytes,
+                           void *stream);
 
 /* ------------------------------------------------------------------------------------
  * Dense SDF / semantic query on a regular metre lattice + Occ3D occupancy tail.

@@ -110,10 +110,10 @@ SYMBOLS = {
     "selfocc_msda_fwd": (C.c_int, [_p, _p, _p, _p, _p, _p] + [_i] * 7 + [_p]),
     "selfocc_msda_fused_fwd": (C.c_int, [_p, _p, _p, _p, _i, _p, _p, _p] + [_i] * 10 + [_p]),
     "selfocc_msda_cross_fwd": (C.c_int, [_p] * 8 + [_i] * 11 + [_p]),
-    "selfocc_msda_cross_bwd": (C.c_int, [_p] * 12 + [_i] * 10 + [_p, C.c_size_t, _p]),
+    "selfocc_msda_cross_bwd": (C.c_int, [_p] * 12 + [_i] * 11 + [_p, C.c_size_t, _p]),
     "selfocc_msda_bwd": (C.c_int, [_p] * 9 + [_i] * 7 + [_p]),
     "selfocc_msda_banded_supported": (C.c_int, [_p] + [_i] * 6),
-    "selfocc_msda_fused_bwd": (C.c_int, [_p] * 5 + [_i] + [_p] * 6 + [_i] * 10 + [_p, C.c_size_t, _p]),
+    "selfocc_msda_fused_bwd": (C.c_int, [_p] * 5 + [_i] + [_p] * 6 + [_i] * 11 + [_p, C.c_size_t, _p]),
     "selfocc_msda_bwd_banded_workspace": (C.c_size_t, [_i] * 5),
     "selfocc_msda_bwd_banded": (C.c_int, [_p] * 10 + [_i] * 7 + [_p, C.c_size_t, _p]),
     "selfocc_field_query": (C.c_int, [C.POINTER(SoQueryArgs), _p]),

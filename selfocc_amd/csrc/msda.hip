@@ -1472,8 +1472,12 @@ BandWorkspace so_band_workspace(void *workspace, int bs, int nq, int heads, int 
 // invisible (camera, query) pairs are unwritten and must not be read (needs P >= 4, see msda_bin_kernel)
 int so_band_scatter(const int32_t *shapes, const int32_t *starts, const float *g_out, float *g_value,
                     const BandWorkspace &w, const BandSetup &bsu, MsdaDims dm, int d, const unsigned char *vis,
-                    hipStream_t st, bool counted = false) {
+                    hipStream_t st, bool counted = false, int gv_stride = 0) {
     const MsdaBinPlan &bp = bsu.bin;
+    // g_value in its own layout (round 6): rows of gv_stride floats per pixel, this op's heads * d channels at the pointer —
+    // a column block of the row-major gradient of a (stacked) value projection, whatever layout `value` itself was gathered from
+    MsdaDims dm_g = dm;
+    if (gv_stride > 0) { dm_g.hm = 0; dm_g.vs = gv_stride; }
     const int nb = dm.bs * dm.heads * bp.nbands;                 // bands over all (batch, head)
     int32_t *cnt = w.counters, *cursor = cnt + 2 * (size_t)nb, *off = cursor + 2 * (size_t)nb, *item0 = off + 2 * (size_t)nb;
     const long long n = (long long)dm.nq * dm.P;
@@ -1497,7 +1501,7 @@ int so_band_scatter(const int32_t *shapes, const int32_t *starts, const float *g
         (void)hipFuncSetAttribute((const void *)msda_bwd_band_list_kernel<DD, TT>,                               \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, band_tile_bytes(TT));              \
         hipLaunchKernelGGL((msda_bwd_band_list_kernel<DD, TT>), dim3((unsigned)max_items), dim3(TT), shm, st,    \
-                           shapes, starts, g_out, g_value, w.recs, cnt, off, item0, w.list, nb, dm, bp);         \
+                           shapes, starts, g_out, g_value, w.recs, cnt, off, item0, w.list, nb, dm_g, bp);       \
     }
 #define SO_LAUNCH(DD)                                                                                            \
     if (bsu.threads == 512) SO_LAUNCH_T(DD, 512) else SO_LAUNCH_T(DD, 1024)
@@ -1568,8 +1572,8 @@ extern "C" int selfocc_msda_fused_bwd(const void *value, const int32_t *shapes, 
                                       const float *off_raw, const float *logits, const float *g_out,
                                       float *g_value, float *g_off, float *g_logits, int32_t bs, int32_t nv,
                                       int32_t nq, int32_t heads, int32_t d, int32_t L, int32_t P, int32_t value_layout,
-                                      int32_t value_dtype, int32_t ol_stride, void *workspace, size_t workspace_bytes,
-                                      void *stream) {
+                                      int32_t value_dtype, int32_t ol_stride, int32_t g_value_stride, void *workspace,
+                                      size_t workspace_bytes, void *stream) {
     if (validate((const float *)value, shapes, starts, off_raw, logits, bs, nv, nq, heads, d, L, P)) return -1;
     SO_REQUIRE(value_dtype == SO_DTYPE_F32 || value_dtype == SO_DTYPE_BF16, "msda_fused_bwd: bad value_dtype");
     const long long n_groups = (long long)bs * nq * heads;
@@ -1591,6 +1595,8 @@ extern "C" int selfocc_msda_fused_bwd(const void *value, const int32_t *shapes, 
     hipStream_t st = (hipStream_t)stream;
     MsdaDims dm{bs, nv, nq, heads, L, P, 0, 0, value_layout};
     if (so_set_ol(dm, ol_stride, off_raw, logits, "msda_fused_bwd")) return -1;
+    SO_REQUIRE(g_value_stride == 0 || (g_value_stride >= heads * d && (long long)bs * nv * g_value_stride < (1LL << 31)),
+               "msda_fused_bwd: g_value_stride must be 0 or >= heads * d with bs * nv * stride < 2^31 (got %d)", g_value_stride);
     SO_REQUIRE(ol_stride == 0 || (((uintptr_t)g_off) & 7) == 0, "msda_fused_bwd: g_off must be 8-byte aligned");
     if (nv == 0) {   // every point is outside every (empty) map: all gradients are zero
         if (ol_stride)   // merged rows: [offsets | logits] of a query are adjacent
@@ -1612,7 +1618,7 @@ extern "C" int selfocc_msda_fused_bwd(const void *value, const int32_t *shapes, 
                            g_logits, w.keys, w.recs, dm)
     SO_FUSED_DISPATCH(d, logG, value_dtype == SO_DTYPE_BF16);
 #undef SO_LAUNCH_VT
-    return so_band_scatter(shapes, starts, g_out, g_value, w, bsu, dm, d, nullptr, st);
+    return so_band_scatter(shapes, starts, g_out, g_value, w, bsu, dm, d, nullptr, st, false, g_value_stride);
 }
 
 
@@ -1621,8 +1627,8 @@ extern "C" int selfocc_msda_cross_bwd(const void *value, const int32_t *shapes, 
                                       const float *off_raw, const float *logits, const float *g_out,
                                       float *g_value, float *g_off, float *g_logits, int32_t cams, int32_t nv,
                                       int32_t nq, int32_t heads, int32_t d, int32_t L, int32_t P, int32_t value_layout,
-                                      int32_t value_dtype, int32_t ol_stride, void *workspace, size_t workspace_bytes,
-                                      void *stream) {
+                                      int32_t value_dtype, int32_t ol_stride, int32_t g_value_stride, void *workspace,
+                                      size_t workspace_bytes, void *stream) {
     SO_REQUIRE(cams >= 1, "msda_cross_bwd: cams must be >= 1");
     SO_REQUIRE(value_dtype == SO_DTYPE_F32 || value_dtype == SO_DTYPE_BF16, "msda_cross_bwd: bad value_dtype");
     SO_REQUIRE(value_layout == SO_VALUE_PIXEL_MAJOR || value_layout == SO_VALUE_HEAD_MAJOR, "msda_cross_bwd: bad value_layout");
@@ -1646,6 +1652,8 @@ extern "C" int selfocc_msda_cross_bwd(const void *value, const int32_t *shapes, 
     const long long n_pts = (long long)cams * nq * heads * LP;
     MsdaDims dm{cams, nv, nq, heads, L, P, 1, 0, value_layout};
     if (so_set_ol(dm, ol_stride, off_raw, logits, "msda_cross_bwd")) return -1;
+    SO_REQUIRE(g_value_stride == 0 || (g_value_stride >= heads * d && (long long)cams * nv * g_value_stride < (1LL << 31)),
+               "msda_cross_bwd: g_value_stride must be 0 or >= heads * d with cams * nv * stride < 2^31 (got %d)", g_value_stride);
     SO_REQUIRE(ol_stride == 0 || (((uintptr_t)g_off) & 7) == 0, "msda_cross_bwd: g_off must be 8-byte aligned");
     if (nv == 0) {
         if (ol_stride)
@@ -1679,5 +1687,5 @@ extern "C" int selfocc_msda_cross_bwd(const void *value, const int32_t *shapes, 
                            w.keys, w.recs, cams, dm, count_here ? w.counters : nullptr, bsu.bin)
     SO_FUSED_DISPATCH(d, logG, value_dtype == SO_DTYPE_BF16);
 #undef SO_LAUNCH_VT
-    return so_band_scatter(shapes, starts, g_out, g_value, w, bsu, dm, d, bin_vis, st, count_here);
+    return so_band_scatter(shapes, starts, g_out, g_value, w, bsu, dm, d, bin_vis, st, count_here, g_value_stride);
 }

@@ -14,7 +14,7 @@ from ..dropout import dropout_add
 from ..linear import (linear_wgrad, wgrad_supported, linear_fwd, linear_fwd_supported, linear_fwd_heads, linear_dgrad, dgrad_supported,
                       linear_fwd_heads_supported)
 from ..msda import (MultiScaleDeformableAttnFunction, msda_fused_inference, MSDAFusedFunction, to_head_major,
-                    msda_fused_supported, msda_fused_kernels_built)
+                    msda_fused_supported, msda_fused_kernels_built, ValueGradSink)
 
 
 class BaseModule(nn.Module):
@@ -144,8 +144,18 @@ def value_proj_head_major(lin_weight, lin_bias, value2d, nv, num_heads):
     if torch.is_grad_enabled() and (value2d.requires_grad or lin_weight.requires_grad):
         if not HEAD_MAJOR_PROJ_TRAIN:
             return None
-        return _TallLinearHeads.apply(value2d, lin_weight, lin_bias, nv)
+        G = n_out // 96
+        sink = ValueGradSink(G) if VALUE_GRAD_SINK else None
+        out = _TallLinearHeads.apply(value2d, lin_weight, lin_bias, nv, sink)
+        if sink is not None:
+            out._so_grad_sink = sink           # read by the caller, which hands (sink, g) to the g-th attention's MSDA Function
+        return out
     return linear_fwd_heads(value2d, lin_weight, lin_bias, nv)
+
+
+# training: the MSDA backward writes grad_value pixel-major straight into the row-major gradient of the (stacked) value
+# projection (msda.ValueGradSink, ABI 32 g_value_stride) instead of head-major + one transposing copy per attention
+VALUE_GRAD_SINK = os.environ.get('SELFOCC_VALUE_GRAD_SINK', '1') == '1'
 
 
 # training: the three TPV planes' value projections of the same image features as ONE projection / ONE backward
@@ -170,7 +180,12 @@ def value_proj_head_major_multi(lins, value2d, nv, num_heads):
     if not (value2d.requires_grad or any(l.weight.requires_grad for l in lins)):
         return None
     wb = [t for l in lins for t in (l.weight, l.bias)]
-    return list(_TallLinearHeadsMulti.apply(value2d, nv, *wb))
+    sink = ValueGradSink(len(lins)) if VALUE_GRAD_SINK else None
+    outs = list(_TallLinearHeadsMulti.apply(value2d, nv, sink, *wb))
+    if sink is not None:
+        for g, o in enumerate(outs):
+            o._so_grad_sink = (sink, g)        # read by BEVCrossAttention._forward_camera_loop
+    return outs
 
 
 def _linear_fwd_ok(x2d, weight):
@@ -310,9 +325,10 @@ class _TallLinearHeads(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
-    def forward(ctx, x, weight, bias, nv):
+    def forward(ctx, x, weight, bias, nv, sink=None):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.sink = sink
         return linear_fwd_heads(x, weight, bias, nv)
 
     @staticmethod
@@ -320,8 +336,11 @@ class _TallLinearHeads(torch.autograd.Function):
     def backward(ctx, dy_hm):
         x, weight = ctx.saved_tensors
         G, B, H, nv, d = dy_hm.shape
-        dy = dy_hm.permute(1, 3, 0, 2, 4).reshape(B * nv, G * H * d)        # (b, pix, g, h, c): one transposing copy
-        return (*_tall_linear_backward(x, weight, dy, ctx.has_bias, ctx.needs_input_grad[0]), None)
+        # the MSDA backward wrote its grad_value pixel-major into the sink (msda.ValueGradSink): dy_hm is a view of it
+        dy = ctx.sink.rows([dy_hm[g] for g in range(G)]) if ctx.sink is not None else None
+        if dy is None:
+            dy = dy_hm.permute(1, 3, 0, 2, 4).reshape(B * nv, G * H * d)    # (b, pix, g, h, c): one transposing copy
+        return (*_tall_linear_backward(x, weight, dy, ctx.has_bias, ctx.needs_input_grad[0]), None, None)
 
 
 class _TallLinearHeadsMulti(torch.autograd.Function):
@@ -331,11 +350,12 @@ class _TallLinearHeadsMulti(torch.autograd.Function):
 
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
-    def forward(ctx, x, nv, *wb):
+    def forward(ctx, x, nv, sink, *wb):
         w = torch.cat(wb[0::2], 0)
         b = torch.cat(wb[1::2], 0)
         ctx.save_for_backward(x, w)
         ctx.G = len(wb) // 2
+        ctx.sink = sink
         return tuple(linear_fwd_heads(x, w, b, nv).unbind(0))
 
     @staticmethod
@@ -344,16 +364,21 @@ class _TallLinearHeadsMulti(torch.autograd.Function):
         x, w = ctx.saved_tensors
         G = ctx.G
         B, H, nv, d = next(g for g in gys if g is not None).shape
-        dy = x.new_empty(B, nv, G, H, d)                       # (b, pix, g, h, c): row-major (rows, G * 96)
-        for g, gy in enumerate(gys):
-            if gy is None:
-                dy[:, :, g].zero_()
-            else:
-                dy[:, :, g].copy_(gy.permute(0, 2, 1, 3))      # one transposing copy per group
-        dx, dw, db = _tall_linear_backward(x, w, dy.view(B * nv, G * H * d), True, ctx.needs_input_grad[0])
+        # the G attentions' MSDA backward wrote their grad_value pixel-major into ONE row-major buffer (msda.ValueGradSink):
+        # the gys are views of it — no transposing copies
+        dy2 = ctx.sink.rows(list(gys)) if ctx.sink is not None else None
+        if dy2 is None:
+            dy = x.new_empty(B, nv, G, H, d)                       # (b, pix, g, h, c): row-major (rows, G * 96)
+            for g, gy in enumerate(gys):
+                if gy is None:
+                    dy[:, :, g].zero_()
+                else:
+                    dy[:, :, g].copy_(gy.permute(0, 2, 1, 3))      # one transposing copy per group
+            dy2 = dy.view(B * nv, G * H * d)
+        dx, dw, db = _tall_linear_backward(x, w, dy2, True, ctx.needs_input_grad[0])
         n = H * d
         grads = [t for g in range(G) for t in (dw[g * n:(g + 1) * n], db[g * n:(g + 1) * n])]
-        return (dx, None, *grads)
+        return (dx, None, None, *grads)
 
 
 class _TallLinearMerged(torch.autograd.Function):
@@ -388,6 +413,7 @@ class _TallLinearMerged(torch.autograd.Function):
 
 # sampling_offsets | attention_weights as one projection (env SELFOCC_MERGED_OFF_LOGITS=0: two Linears, as until round 5)
 MERGED_OFF_LOGITS = os.environ.get('SELFOCC_MERGED_OFF_LOGITS', '1') == '1'
+MERGED_OFF_LOGITS_CALLS = [0]      # calls served by the merged projection (tests read this)
 
 
 def merged_off_logits(module, x2d):
@@ -400,6 +426,7 @@ def merged_off_logits(module, x2d):
             and so.bias is not None and aw.bias is not None and so.weight.dtype == torch.float32
             and so.weight.shape[0] == 2 * aw.weight.shape[0] and x2d.shape[0] >= LINEAR_FWD_MIN_ROWS):
         return None
+    MERGED_OFF_LOGITS_CALLS[0] += 1
     if torch.is_grad_enabled() and (x2d.requires_grad or so.weight.requires_grad or aw.weight.requires_grad):
         return _TallLinearMerged.apply(x2d, so.weight, so.bias, aw.weight, aw.bias)
     key = tuple((t._version, t.data_ptr()) for t in (so.weight, so.bias, aw.weight, aw.bias))
@@ -576,8 +603,10 @@ def deformable_sampling(module, query, value, reference_points, spatial_shapes, 
             value, hm = v_hm.view(v_hm.shape[1:]), True      # G = 1: a view (select's backward is a zero fill + a copy)
         elif HEAD_MAJOR_VALUE:
             value = to_head_major(value)
+        sink = getattr(v_hm, '_so_grad_sink', None) if v_hm is not None else None
         return MSDAFusedFunction.apply(value, spatial_shapes, level_start_index, reference_points, kind,
-                                       ol if ol is not None else off, logits, host, hm, use_bf16, mlp)
+                                       ol if ol is not None else off, logits, host, hm, use_bf16, mlp,
+                                       (sink, 0) if sink is not None else None)
     if v_hm is not None:      # (the unfused fallback below wants the mmcv layout)
         value = v_hm.view(v_hm.shape[1:]).permute(0, 2, 1, 3).contiguous()
     aw = module.attention_weights(query).view(bs, num_query, module.num_heads,

@@ -171,8 +171,10 @@ class BEVCrossAttention(BaseModule):
         num_cams, heads, L, P = self.num_cams, da.num_heads, da.num_levels, da.num_points
         _, l, _, _ = value.shape                                            # (cams, nv, bs, C)
         hm = bricks.HEAD_MAJOR_VALUE
+        sink = None    # (ValueGradSink, g): where the backward puts grad_value (set by bricks.value_proj_head_major[_multi])
         if value_pre is not None and value_pre.dim() == 4:
             v, hm = value_pre, True    # TPVCrossAttention already laid this plane's values out head-major
+            sink = getattr(value_pre, '_so_grad_sink', None)
         elif value_pre is not None:    # this plane's column block of the merged value projection (TPVCrossAttention)
             v, hm = value_pre.view(num_cams, l, heads, -1), False
         else:
@@ -183,6 +185,8 @@ class BEVCrossAttention(BaseModule):
                 v_hm = bricks.value_proj_head_major(da.value_proj.weight, da.value_proj.bias, vin, l, heads)
             if v_hm is not None:
                 v, hm = v_hm.view(v_hm.shape[1:]), True      # G = 1: a view, not a select
+                s1 = getattr(v_hm, '_so_grad_sink', None)
+                sink = (s1, 0) if s1 is not None else None
             else:
                 v = da.value_proj(vin.view(num_cams, l, self.embed_dims)).view(num_cams, l, heads, -1)
                 if hm:
@@ -206,7 +210,7 @@ class BEVCrossAttention(BaseModule):
                                          off, logits, hm, mlp)[None]
         else:
             slots = MSDACrossFunction.apply(v, spatial_shapes, level_start_index, reference_points_cams[:, 0], visible,
-                                            off, logits, host_shapes, hm, bf16, mlp)[None]
+                                            off, logits, host_shapes, hm, bf16, mlp, sink)[None]
         if not self.training and not torch.is_grad_enabled():
             # eval: dropout is the identity; output_proj + residual (+ the layer's next norm) in one launch, written
             # straight into the caller's slice of the concatenated plane buffer (`out`)

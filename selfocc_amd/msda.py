@@ -220,6 +220,52 @@ def msda_cross_inference(value, spatial_shapes, level_start_index, reference_poi
     return out
 
 
+def _grad_value_target(grad_sink, value, B, nv, heads, d):
+    """(tensor returned as grad_value, pointer handed to the kernel, g_value_stride): a fresh zeroed tensor in the layout of
+    ``value``, or — with a ValueGradSink — this attention's column block of the shared row-major buffer"""
+    import ctypes
+    if grad_sink is None:
+        g_value = torch.zeros(value.shape, device=value.device, dtype=torch.float32)
+        return g_value, ptr(g_value), 0
+    sink, g = grad_sink
+    buf = sink.slot(g, B, nv, heads, d, value.device)
+    return (buf[:, :, g].permute(0, 2, 1, 3), ctypes.c_void_p(buf.data_ptr() + 4 * g * heads * d), sink.G * heads * d)
+
+
+class ValueGradSink:
+    """Where the MSDA backward of G attentions that share ONE stacked value projection put their grad_value: a single
+    row-major buffer (B, nv, G, heads, d) — the dy of that projection's weight- / input-gradient passes — written PIXEL-major by
+    the band kernels themselves (ABI 32 ``g_value_stride``).  Until round 6 every attention returned a head-major grad_value
+    and the projection's backward re-assembled the rows with one transposing copy per attention (12 x 59 MB copies per
+    nuscenes_occ iteration).  Created by bricks.value_proj_head_major[_multi], handed to the attention's MSDA Function as
+    ``grad_sink=(sink, g)``; the Function returns a (B, heads, nv, d) VIEW of the buffer as the gradient of its head-major
+    input, and the projection's backward recognises the views (``rows()``) and uses the buffer as it is."""
+
+    hits = 0        # backward passes that used the shared buffer as it was (tests read this)
+
+    def __init__(self, G):
+        self.G, self.buf, self.filled = G, None, set()
+
+    def slot(self, g, B, nv, heads, d, device):
+        if self.buf is None or g in self.filled:       # a new backward pass (or the same attention twice): a fresh buffer
+            self.buf, self.filled = torch.zeros(B, nv, self.G, heads, d, device=device, dtype=torch.float32), set()
+        self.filled.add(g)
+        return self.buf
+
+    def rows(self, grads):
+        """the (B * nv, G * heads * d) matrix when ``grads`` are exactly this buffer's G views, else None; releases the buffer"""
+        buf, self.buf, self.filled = self.buf, None, set()
+        if buf is None or len(grads) != self.G:
+            return None
+        for g, t in enumerate(grads):
+            v = buf[:, :, g].permute(0, 2, 1, 3)
+            if t is None or t.data_ptr() != v.data_ptr() or t.shape != v.shape or any(
+                    a != b for a, b, n in zip(t.stride(), v.stride(), v.shape) if n > 1):      # (size-1 dims: any stride)
+                return None
+        ValueGradSink.hits += 1
+        return buf.view(buf.shape[0] * buf.shape[1], -1)
+
+
 class MSDAFusedFunction(torch.autograd.Function):
     """Training form of the fused op: out = MSDA(value, ref + off / (W_l, H_l), softmax(logits)) with the
     prologue inside the kernels in BOTH directions.  The forward saves only its inputs (no sampling_locations /
@@ -228,9 +274,11 @@ class MSDAFusedFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, value, spatial_shapes, level_start_index, reference_points, ref_kind, sampling_offsets,
-                attention_logits, host_shapes, head_major=False, value_bf16=False, merged_LP=None):
+                attention_logits, host_shapes, head_major=False, value_bf16=False, merged_LP=None, grad_sink=None):
         """``attention_logits is None``: ``sampling_offsets`` is the merged projection output (bs, nq, 3 h L P) (rows
-        [offsets | logits], ``merged_LP = (L, P)``) and the backward returns ONE gradient of that shape."""
+        [offsets | logits], ``merged_LP = (L, P)``) and the backward returns ONE gradient of that shape.
+        ``grad_sink = (ValueGradSink, g)`` (head-major float32 value only): grad_value is written pixel-major into the sink."""
+        ctx.grad_sink = grad_sink if (head_major and not value_bf16) else None
         if value_bf16:      # bfloat16 STORAGE of value for the gathers (forward and backward); gradients stay float32
             value = value.to(torch.bfloat16)
         out = msda_fused_inference(value, spatial_shapes, level_start_index, reference_points, ref_kind,
@@ -259,7 +307,7 @@ class MSDAFusedFunction(torch.autograd.Function):
         keep, p_off, p_lg, lead, L, P, ols = _off_logits_args(off, lg, heads, ctx.merged_LP)
         nq = lead[-1]
         g_out = grad_output.contiguous().float()
-        g_value = torch.zeros(value.shape, device=value.device, dtype=torch.float32)
+        g_value, p_gv, gvs = _grad_value_target(ctx.grad_sink, value, bs, nv, heads, d)
         if ols:
             g_off = torch.empty(*lead, ols, device=value.device, dtype=torch.float32)
             g_lg, pg_lg = None, ctypes.c_void_p(g_off.data_ptr() + 8 * heads * L * P)
@@ -270,11 +318,11 @@ class MSDAFusedFunction(torch.autograd.Function):
         nbytes = int(lib().selfocc_msda_bwd_banded_workspace(bs, nq, heads, L, P))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=value.device)
         check(lib().selfocc_msda_fused_bwd(ptr(value), ptr(sh), ptr(st), ctypes.cast(arr, ctypes.c_void_p), ptr(ref),
-                                           ctx.ref_kind, p_off, p_lg, ptr(g_out), ptr(g_value), ptr(g_off),
-                                           pg_lg, bs, nv, nq, heads, d, L, P, int(ctx.head_major), vdt, ols, ptr(ws), nbytes,
+                                           ctx.ref_kind, p_off, p_lg, ptr(g_out), p_gv, ptr(g_off),
+                                           pg_lg, bs, nv, nq, heads, d, L, P, int(ctx.head_major), vdt, ols, gvs, ptr(ws), nbytes,
                                            current_stream(value.device)),
               "selfocc_msda_fused_bwd")
-        return g_value, None, None, None, None, g_off, g_lg, None, None, None, None
+        return g_value, None, None, None, None, g_off, g_lg, None, None, None, None, None
 
 
 def msda_fused_kernels_built(d, value_bf16=False):
@@ -299,8 +347,10 @@ class MSDACrossFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, value, spatial_shapes, level_start_index, reference_points_cam, visible, sampling_offsets,
-                attention_logits, host_shapes, head_major=False, value_bf16=False, merged_LP=None):
-        """``attention_logits is None``: ``sampling_offsets`` is the merged projection output (nq, 3 h L P), see MSDAFusedFunction."""
+                attention_logits, host_shapes, head_major=False, value_bf16=False, merged_LP=None, grad_sink=None):
+        """``attention_logits is None``: ``sampling_offsets`` is the merged projection output (nq, 3 h L P); ``grad_sink``: see
+        MSDAFusedFunction."""
+        ctx.grad_sink = grad_sink if (head_major and not value_bf16) else None
         if value_bf16:
             value = value.to(torch.bfloat16)
         out = msda_cross_inference(value, spatial_shapes, level_start_index, reference_points_cam, visible,
@@ -330,7 +380,7 @@ class MSDACrossFunction(torch.autograd.Function):
         keep, p_off, p_lg, lead, L, P, ols = _off_logits_args(off, lg, heads, ctx.merged_LP)
         nq = lead[-1]
         g_out = grad_output.contiguous().float()
-        g_value = torch.zeros(value.shape, device=value.device, dtype=torch.float32)
+        g_value, p_gv, gvs = _grad_value_target(ctx.grad_sink, value, cams, nv, heads, d)
         if ols:
             g_off = torch.empty(*lead, ols, device=value.device, dtype=torch.float32)
             g_lg, pg_lg = None, ctypes.c_void_p(g_off.data_ptr() + 8 * heads * L * P)
@@ -341,8 +391,8 @@ class MSDACrossFunction(torch.autograd.Function):
         nbytes = int(lib().selfocc_msda_bwd_banded_workspace(cams, nq, heads, L, P))
         ws = torch.empty(nbytes, dtype=torch.uint8, device=value.device)
         check(lib().selfocc_msda_cross_bwd(ptr(value), ptr(sh), ptr(st), ctypes.cast(arr, ctypes.c_void_p), ptr(ref),
-                                           ptr(vis), p_off, p_lg, ptr(g_out), ptr(g_value), ptr(g_off),
-                                           pg_lg, cams, nv, nq, heads, d, L, P, int(ctx.head_major), vdt, ols, ptr(ws),
+                                           ptr(vis), p_off, p_lg, ptr(g_out), p_gv, ptr(g_off),
+                                           pg_lg, cams, nv, nq, heads, d, L, P, int(ctx.head_major), vdt, ols, gvs, ptr(ws),
                                            nbytes, current_stream(value.device)),
               "selfocc_msda_cross_bwd")
-        return g_value, None, None, None, None, g_off, g_lg, None, None, None, None
+        return g_value, None, None, None, None, g_off, g_lg, None, None, None, None, None

@@ -111,8 +111,10 @@ def test_encoder_full_structure_forward_and_gradients_vs_reference(hip, variant)
     MultiScaleDeformableAttnFunction (mmcv's boundary) with torch softmax / locations around it."""
     from selfocc_amd.model import bricks
     from selfocc_amd.model.encoder.attention import BEVCrossAttention
+    from selfocc_amd.msda import ValueGradSink
     z, enc, lifter, feats, metas, loss_dirs = _setup()
     old = (bricks.LINEAR_FWD_MIN_ROWS, bricks.TallLinear.min_rows, bricks.FUSED_TRAINING)
+    sink0, merged0 = ValueGradSink.hits, bricks.MERGED_OFF_LOGITS_CALLS[0]
     try:
         if variant == 'all_kernels':
             bricks.LINEAR_FWD_MIN_ROWS, bricks.TallLinear.min_rows = 1, 1
@@ -125,6 +127,12 @@ def test_encoder_full_structure_forward_and_gradients_vs_reference(hip, variant)
         out, loss, grads = _train_pass(enc, lifter, feats, metas, loss_dirs)
     finally:
         bricks.LINEAR_FWD_MIN_ROWS, bricks.TallLinear.min_rows, bricks.FUSED_TRAINING = old
+    if variant == 'all_kernels':
+        # round 6's routes really ran: per layer 4 merged sampling_offsets | attention_weights projections (3 planes + self) and
+        # 2 value-gradient sinks (the three planes' stacked value projection, the self-attention's) used without a copy
+        n_layers = len(enc.layers)
+        assert bricks.MERGED_OFF_LOGITS_CALLS[0] - merged0 == 4 * n_layers, bricks.MERGED_OFF_LOGITS_CALLS[0] - merged0
+        assert ValueGradSink.hits - sink0 == 2 * n_layers, ValueGradSink.hits - sink0
     _check(variant, z, out, loss, grads)
 
 
