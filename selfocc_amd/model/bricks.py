@@ -351,8 +351,9 @@ class _TallLinearHeadsMulti(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
     def forward(ctx, x, nv, sink, *wb):
-        w = torch.cat(wb[0::2], 0)
-        b = torch.cat(wb[1::2], 0)
+        w, b = stacked_view(list(wb[0::2])), stacked_view(list(wb[1::2]))
+        if w is None or b is None:
+            w, b = torch.cat(wb[0::2], 0), torch.cat(wb[1::2], 0)
         ctx.save_for_backward(x, w)
         ctx.G = len(wb) // 2
         ctx.sink = sink
@@ -381,6 +382,43 @@ class _TallLinearHeadsMulti(torch.autograd.Function):
         return (dx, None, None, *grads)
 
 
+STACKED_VIEW = os.environ.get('SELFOCC_STACKED_VIEW', '1') == '1'      # A/B: 0 = torch.cat per call
+
+
+def stacked_view(params):
+    """ONE contiguous tensor that IS the row-concatenation of the leaf parameters ``params`` — their storages are made to
+    alias consecutive row blocks of it — so that a stacked projection costs no ``torch.cat`` per call (the round-6 training
+    iteration launched ~40 five-microsecond cats for the merged sampling_offsets | attention_weights and value projections).
+    The parameters stay separate ``nn.Parameter`` objects with their own names, gradients and optimiser state; in-place
+    updates (optimisers, ``load_state_dict``) keep the aliasing, a ``module.to(...)`` / ``.data =`` assignment breaks it and the
+    next call re-establishes it.  None when a tensor is not a leaf parameter (``functional_call`` views under row sharding, ...)."""
+    p0 = params[0]
+    if not STACKED_VIEW:
+        return None
+    if any((not isinstance(p, nn.Parameter)) or (not p.is_leaf) or p.dtype != p0.dtype or p.device != p0.device
+           or p.shape[1:] != p0.shape[1:] for p in params):
+        return None
+    rows = sum(p.shape[0] for p in params)
+    inner = 1
+    for n in p0.shape[1:]:
+        inner *= n
+    st, off, aliased = p0.untyped_storage(), p0.storage_offset(), True
+    for p in params:
+        if p.untyped_storage().data_ptr() != st.data_ptr() or p.storage_offset() != off or not p.is_contiguous():
+            aliased = False
+            break
+        off += p.numel()
+    if aliased:
+        return torch.as_strided(p0.data, (rows, *p0.shape[1:]), p0.data.stride(), p0.storage_offset())
+    with torch.no_grad():
+        buf = torch.cat([p.data for p in params], 0).contiguous()
+        o = 0
+        for p in params:
+            p.data = buf[o:o + p.shape[0]]
+            o += p.shape[0]
+    return buf
+
+
 class _TallLinearMerged(torch.autograd.Function):
     """G Linears of the SAME rows as ONE projection with the weights stacked: y (T, N_1 + ... + N_G).  Used for the
     `sampling_offsets` | `attention_weights` pair of every deformable attention (image_cross_attention.py:296-312 and
@@ -391,8 +429,9 @@ class _TallLinearMerged(torch.autograd.Function):
     @staticmethod
     @torch.amp.custom_fwd(device_type='cuda', cast_inputs=torch.float32)
     def forward(ctx, x, *wb):
-        w = torch.cat(wb[0::2], 0)
-        b = torch.cat(wb[1::2], 0)
+        w, b = stacked_view(list(wb[0::2])), stacked_view(list(wb[1::2]))      # the parameters themselves, aliased: no copy
+        if w is None or b is None:
+            w, b = torch.cat(wb[0::2], 0), torch.cat(wb[1::2], 0)
         ctx.save_for_backward(x, w)
         ctx.sizes = [t.shape[0] for t in wb[0::2]]
         if FUSED_LINEAR_FWD and _linear_fwd_ok(x, w):
@@ -429,11 +468,9 @@ def merged_off_logits(module, x2d):
     MERGED_OFF_LOGITS_CALLS[0] += 1
     if torch.is_grad_enabled() and (x2d.requires_grad or so.weight.requires_grad or aw.weight.requires_grad):
         return _TallLinearMerged.apply(x2d, so.weight, so.bias, aw.weight, aw.bias)
-    key = tuple((t._version, t.data_ptr()) for t in (so.weight, so.bias, aw.weight, aw.bias))
-    cache = getattr(module, '_ol_cache', None)
-    if cache is None or cache[0] != key:           # stacked once, rebuilt when a parameter changes
-        cache = module._ol_cache = (key, torch.cat([so.weight, aw.weight], 0).detach(), torch.cat([so.bias, aw.bias], 0).detach())
-    w, b = cache[1], cache[2]
+    w, b = stacked_view([so.weight, aw.weight]), stacked_view([so.bias, aw.bias])
+    if w is None or b is None:
+        w, b = torch.cat([so.weight, aw.weight], 0).detach(), torch.cat([so.bias, aw.bias], 0).detach()
     if FUSED_LINEAR_FWD and _linear_fwd_ok(x2d, w):
         return linear_fwd(x2d, w, b)
     return torch.addmm(b, x2d, w.t())
