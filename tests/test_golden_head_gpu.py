@@ -139,10 +139,12 @@ def compare(ours, ref, where):
             elif k == 'sem' and a.dtype == torch.int64:
                 pass        # arg-max of the logits: checked against the logits by the caller
             elif k == 'ms_max_depths':
-                # arg-max over w / delta: an (almost) tie may legitimately resolve to the neighbouring sample
-                frac = close(a, b, 1e-5, 1e-5).float().mean().item()   # measured 1.0 on every recorded call
+                # arg-max over w / delta.  An (almost) tie could in principle resolve to the neighbouring sample; on the recorded
+                # calls it never does — every ray of every call agrees — and that is what is asserted (round-5 review: "assert
+                # what is measured"; the bound was 99 %)
+                frac = close(a, b, 1e-5, 1e-5).float().mean().item()
                 _log(where, k, i, frac=frac)
-                assert frac >= 0.99, (tag, frac)
+                assert frac == 1.0, (tag, frac)
             elif k == 'eik_grad':
                 # trilinear gradients jump across voxel faces: a sample within rounding of a face may sit next door
                 ok = close(a, b, 1e-4, 1e-4 * b.abs().max().item()).all(-1)
