@@ -558,3 +558,46 @@ def test_merged_offset_logit_projection_module_equals_two_linears(hip, monkeypat
     errs = dict(y=err(ym, yd), y_inference=err(yim, yid), g_query=err(gqm, gqd), **{n: err(gpm[n], gpd[n]) for n in gpd})
     bad = {k: v for k, v in errs.items() if v > 1e-5}
     assert not bad, (bad, errs)
+
+
+def test_abi32_stride_arguments_are_validated_at_the_c_boundary(hip):
+    """ol_stride / g_value_stride of the fused entry points (include/selfocc_hip.h, ABI 32): a bad value is an error string,
+    never a wild write."""
+    import ctypes as C
+    from selfocc_amd._lib import lib, ptr, current_stream
+    from selfocc_amd import abi
+    d0 = torch.device("cuda:0")
+    heads, d, L, P, nq, bs = 6, 16, 2, 4, 33, 1
+    shapes = torch.tensor([[6, 10], [3, 5]], dtype=torch.int32, device=d0)
+    starts = torch.tensor([0, 60], dtype=torch.int32, device=d0)
+    nv, LP = 75, L * P
+    value = torch.randn(bs, heads, nv, d, device=d0)
+    ref = torch.rand(bs, nq, L, 2, device=d0)
+    ol = torch.randn(bs, nq, 3 * heads * LP, device=d0)
+    out = torch.empty(bs, nq, heads * d, device=d0)
+    lg_ptr = C.c_void_p(ol.data_ptr() + 8 * heads * LP)
+    st = current_stream(d0)
+    l = lib()
+
+    def fwd(ols):
+        return l.selfocc_msda_fused_fwd(ptr(value), ptr(shapes), ptr(starts), ptr(ref), 0, ptr(ol), lg_ptr, ptr(out), bs, nv, nq, heads,
+                                        d, L, P, 1, abi.DTYPE_F32, ols, st)
+    assert fwd(3 * heads * LP) == 0
+    for bad in (3 * heads * LP - 2, 3 * heads * LP + 1, -4):
+        assert fwd(bad) != 0 and b"ol_stride" in l.selfocc_last_error()
+    host = (C.c_int32 * 4)(6, 10, 3, 5)
+    g_out = torch.randn(bs, nq, heads * d, device=d0)
+    g_ol = torch.empty_like(ol)
+    g_rows = torch.zeros(bs, nv, 2, heads, d, device=d0)
+    nbytes = int(l.selfocc_msda_bwd_banded_workspace(bs, nq, heads, L, P))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=d0)
+
+    def bwd(gvs):
+        return l.selfocc_msda_fused_bwd(ptr(value), ptr(shapes), ptr(starts), C.cast(host, C.c_void_p), ptr(ref), 0, ptr(ol), lg_ptr,
+                                        ptr(g_out), ptr(g_rows), ptr(g_ol), C.c_void_p(g_ol.data_ptr() + 8 * heads * LP), bs, nv, nq,
+                                        heads, d, L, P, 1, abi.DTYPE_F32, 3 * heads * LP, gvs, ptr(ws), nbytes, st)
+    assert bwd(2 * heads * d) == 0
+    torch.cuda.synchronize()
+    assert float(g_rows[:, :, 0].abs().sum()) > 0 and float(g_rows[:, :, 1].abs().sum()) == 0      # only this op's column block is written
+    for bad in (heads * d - 16, -1):
+        assert bwd(bad) != 0 and b"g_value_stride" in l.selfocc_last_error()
