@@ -96,8 +96,10 @@ with torch.no_grad():
                   "torch_gather": lambda: gtab.index_select(0, gidx), "encoder_pass": lambda: enc(lifter(feats)['representation'], ms_img_feats=feats, metas=metas),
                   "lifter": lambda: lifter(feats), "torch_elementwise": lambda: (xx * 2 + 1).relu().sum(),
                   "layernorm": lambda: enc.layers[0].norms[0](xx[None]) if hasattr(enc.layers[0], 'norms') else ln(xx)}
-    for (n, _, _), (fn, a, k) in calls.items():
+    for (n, sa_, sk_), (fn, a, k) in calls.items():
         if "msda" not in n:
+            if n not in disturbers and os.environ.get("DIAG_SHOW_SIG"):
+                print("disturber signature", n, sa_, sk_, flush=True)
             disturbers.setdefault(n, (lambda fn=fn, a=a, k=k: fn(*a, **k)))
     want = os.environ.get("DIAG_DISTURB", "none,encoder_pass").split(",")
     sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
