@@ -9,7 +9,9 @@ stream is needed.  Build (where the git history is):
     d=$(mktemp -d); for f in msda_pro.hip msda_device.h so_device.h common.hip; do git show 0d60026^:selfocc_amd/csrc/$f > $d/$f; done
     (the headers' relative include of include/selfocc_hip.h: two directories up) ; hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC
     -ffp-contract=off -fno-fast-math -fno-slp-vectorize -fno-vectorize -shared msda_pro.hip common.hip -o scripts/diag/libmsda_pro_diag.so
-usage: python scripts/diag/msda_pro_replay.py [launches per shape, default 10000]"""
+    (libmsda_pro_diag_packed.so: the same without the two -fno-* flags = the round-5 build, 2 469 v_pk_* of which 128 half-swapping
+    v_pk_mul_f32: `hipcc -S` + grep; the replay's positive control)
+usage: python scripts/diag/msda_pro_replay.py [launches per shape, default 10000] [plain | packed]"""
 import ctypes as C
 import json
 import os
@@ -23,8 +25,9 @@ from selfocc_amd.linear import linear_fwd
 from selfocc_amd.msda import msda_fused_inference, msda_cross_inference, to_head_major
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+VARIANT = sys.argv[2] if len(sys.argv) > 2 else "plain"      # "packed": the same source with the compiler's vectorizers ON (the round-5 build: 128 half-swapping v_pk_mul_f32) — the replay's positive control
 d0 = torch.device("cuda:0")
-so = C.CDLL(os.path.join(ROOT, "scripts", "diag", "libmsda_pro_diag.so"))
+so = C.CDLL(os.path.join(ROOT, "scripts", "diag", "libmsda_pro_diag.so" if VARIANT == "plain" else "libmsda_pro_diag_packed.so"))
 so.selfocc_last_error.restype = C.c_char_p
 g = torch.Generator(device=d0).manual_seed(5)
 rn = lambda *s: torch.randn(*s, device=d0, generator=g)
@@ -100,6 +103,7 @@ with torch.no_grad():
         res[name] = dict(launches=N, launches_differing_from_the_first=bad_launches, wrong_rows_total=bad_rows,
                          max_rel_diff_vs_separate_route=vs_sep, seconds=round(time.time() - t0, 1), examples=examples)
 p = torch.cuda.get_device_properties(0)
+res['variant'] = VARIANT
 res['device'] = dict(uuid=str(getattr(p, 'uuid', '')), pci=f"{getattr(p, 'pci_bus_id', 0):02x}", name=p.name)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 with open(os.path.join(ROOT, "gpurun_out", "msda_pro_replay.jsonl"), "a") as f:
