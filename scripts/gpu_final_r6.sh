@@ -17,9 +17,14 @@ TOPN=40 bash scripts/gpu_trace.sh ${T}_occ python scripts/bench_hotpath_all.py -
 TOPN=40 bash scripts/gpu_trace.sh ${T}_kitti python scripts/bench_hotpath_all.py --only kitti_novel_depth --no-train --iters 10 > /dev/null
 TOPN=64 bash scripts/gpu_trace.sh ${T}_train python scripts/bench_hotpath_all.py --only nuscenes_occ --no-eval > /dev/null
 python scripts/bench_hotpath_all.py > gpurun_out/${T}_hotpath_all.json 2>/dev/null
-rm -f gpurun_out/concurrency_matrix.jsonl
+rm -f gpurun_out/msda_pro_replay.jsonl
+python scripts/diag/msda_pro_replay.py 10000 packed > /dev/null 2>&1; python scripts/diag/msda_pro_replay.py 10000 plain > /dev/null 2>&1
+cp gpurun_out/msda_pro_replay.jsonl gpurun_out/${T}_msda_pro_replay.jsonl 2>/dev/null
+rm -f gpurun_out/concurrency_matrix.jsonl gpurun_out/shipped_routes_parity.jsonl
 python -m pytest tests/test_concurrency_gpu.py -m gpu -q 2>&1 | tail -2 > gpurun_out/${T}_concurrency.log
 cp gpurun_out/concurrency_matrix.jsonl gpurun_out/${T}_concurrency_matrix.jsonl 2>/dev/null
+python -m pytest tests/test_shipped_configs_gpu.py -m gpu -q 2>&1 | tail -2 > gpurun_out/${T}_shipped_configs.log
+cp gpurun_out/shipped_routes_parity.jsonl gpurun_out/${T}_shipped_routes_parity.jsonl 2>/dev/null
 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
 cp gpurun_out/bench_detail.json gpurun_out/${T}_bench_detail.json 2>/dev/null
 wc -c gpurun_out/${T}_bench.json; ls gpurun_out | grep "^$T"
