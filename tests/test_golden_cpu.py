@@ -167,6 +167,32 @@ def test_shipped_configs_parse_and_resolve():
         walk(cfg.model['encoder'])
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference/config"), reason="reference configs only exist in the build container")
+def test_dumped_shipped_configs_are_what_the_reference_ships():
+    """scripts/shipped_cfg/*.json (what the GPU box builds the seven configs from, tests/test_shipped_configs_gpu.py and bench.py's
+    hot_path) == the hot-path part of config/{nuscenes,kitti,kitti_raw}/*.py as selfocc_amd.config reads them today: all seven, no
+    hand edits (scripts/dump_shipped_configs.py regenerates them byte for byte)."""
+    import glob
+    import json
+    from selfocc_amd.config import Config
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(f for d in ("nuscenes", "kitti", "kitti_raw") for f in glob.glob(f"/root/reference/config/{d}/*.py"))
+    dumps = sorted(glob.glob(os.path.join(root, "scripts", "shipped_cfg", "*.json")))
+    assert len(files) == len(dumps) == 7
+    for f in files:
+        name = os.path.basename(f)[:-3]
+        got = json.load(open(os.path.join(root, "scripts", "shipped_cfg", name + ".json")))
+        c = Config.fromfile(f).to_dict()
+        assert got["source"] == os.path.relpath(f, "/root/reference")
+        want = {"model": {k: c["model"][k] for k in ("type", "lifter", "encoder", "head")}, "loss": c["loss"],
+                "loss_input_convertion": c["loss_input_convertion"], "img_size": c["img_size"], "num_rays": c["num_rays"],
+                "optimizer": c["optimizer"], "grad_max_norm": c["grad_max_norm"], "amp": c.get("amp", False)}
+        if "crop_size" in c:
+            want["crop_size"] = c["crop_size"]
+        # through JSON: tuples become lists on both sides
+        assert json.loads(json.dumps(want, sort_keys=True)) == {k: got[k] for k in want}, name
+
+
 # ---- fixtures of tests/golden/more.npz: Img2LiDAR, BEVNeRF, the small volume losses, LUT ----------------------
 mor = np.load(os.path.join(G, "more.npz"))
 
