@@ -39,6 +39,18 @@
 #include <atomic>
 #include <cstdlib>
 
+#ifdef SO_LIN_TRACE
+// dev build only (scripts/build_variant.sh lintrace linear_fwd.hip -DSO_LIN_TRACE): per-wave s_memtime stamps of
+// linear_fwd_b3_kernel — [wave][0] = start, [1] = W staged, then per tile: top, x arrived, MFMAs done, stores issued, stores acknowledged
+__device__ unsigned long long so_lin_trace[4096 * 64];
+extern "C" int selfocc_diag_lin_trace(unsigned long long *dst, size_t n) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(so_lin_trace), n * sizeof(unsigned long long));
+}
+#define SO_TR(slot) do { if (lane == 0 && (slot) < 64) so_lin_trace[(size_t)(blockIdx.x * WAVES + wave) * 64 + (slot)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define SO_TR(slot) do { } while (0)
+#endif
+
 namespace {
 
 struct LinearFwdArgs {
@@ -47,6 +59,7 @@ struct LinearFwdArgs {
     long long T;
     int N, K, ldy, ldr;
     int relu, ncb, groups, col0;
+    int vec;                 // b3 kernel: x / y / residual / y_pre rows start 16-byte aligned (float4 epilogue)
     int hm_nv;               // > 0: head-major output (selfocc_linear_fwd_heads): rows per batch item
     unsigned hm_sg;          // floats per 96-column group of the head-major output: (T / nv) * 6 * nv * 16
     float eps;
@@ -277,10 +290,24 @@ __global__ __launch_bounds__(WAVES * 64) void linear_fwd16_kernel(LinearFwdArgs 
 // of 32 cycles — 2.67 x fewer matrix-pipe cycles.  Products of bfloat16 pairs are exact in the float32 accumulator; the
 // three small terms are accumulated first.
 //   * W: split once per persistent block into three bf16 planes in LDS ([column][K + 8]: 16-byte reads, conflict-free);
-//   * x: a wave owns 32 rows (two 16-row MFMA tiles share every B read: at 16 rows the LDS stream, 54 KB per tile, would
-//     be the bound); lane (m, kb) holds x[row m][32 ks + 8 kb ..+8], split in registers per k step;
-//   * epilogues: the accumulator layout is that of the f32 kernel, so bias / ReLU / residual / LayerNorm / head-major
-//     stores are the same functions.
+//   * x: a wave owns 32 rows where column blocks share the rows (two 16-row MFMA tiles use every W fragment read from LDS
+//     twice), 16 rows on the short N <= 192 launches; lane (m, kb) holds x[row m][32 ks + 8 kb ..+8]; the whole tile is
+//     split into its planes first (the raw registers then take the NEXT tile's loads), the MFMAs follow as one phase with the
+//     W fragments of the next (k step, column tile) read from LDS ahead of the current one's MFMAs;
+//   * epilogues: the W fragment is the MFMA's A operand, so a lane ends up with four consecutive COLUMNS of a row
+//     (so_linear_epilogue_t below): float4 stores / residual / bias reads, two shuffle steps per LayerNorm row.
+// Where the time goes (round 6; scripts/diag/linear_fwd_trace.py on the -DSO_LIN_TRACE build, s_memtime per wave, 66 049 x 576):
+// a wave needs ~14 k cycles per 32-row tile (x wait 2.7 k before the prefetch / 0.9 k with it, split + 216 MFMAs 5.6 - 6.7 k,
+// epilogue 2.2 k, the rest contention with the SIMD's other wave); the 216 MFMAs are 3 456 cycles of the matrix pipe, so two
+// waves per SIMD keep it 49 % busy while they live and 31 - 34 % over the launch (SQ_VALU_MFMA_BUSY_CYCLES = 16 x SQ_INSTS_MFMA
+// exactly).  The output stream by itself — the same tile order, float4 stores, no loads, no arithmetic
+// (scripts/micro/store_pattern.hip) — takes 30 us at this shape (6.0 TB/s), the kernel 55: the remaining factor is matrix +
+// VALU issue per wave, not DRAM page locality and not the x re-reads (FETCH_SIZE = 1.2 x the size of x: the column blocks'
+// re-reads hit the XCD's L2).  Tried on the way, same-box A/B, none moved a wide launch by more than +-3 %: the next tile's x
+// in a second register set (one or two tiles ahead), straight-line iterations per epilogue kind so that the wait for the
+// prefetch is s_waitcnt vmcnt(<stores>) instead of vmcnt(0), the tail column block folded into the main launch, four
+// accumulators taking turns, 6 or 8 waves per block (3 - 4 per SIMD: 10 - 20 % SLOWER).  What did pay: the transposed tile
+// (LayerNorm launches 33 -> 22 us at 78 899 x 96) and 16-row tiles on the N <= 192 launches (21 -> 19.5, 17.4 -> 15.9 us).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 SO_DEVFN void so_split3(const float (&x)[8], bf16x8 &a1, bf16x8 &a2, bf16x8 &a3) {
@@ -294,8 +321,118 @@ SO_DEVFN void so_split3(const float (&x)[8], bf16x8 &a1, bf16x8 &a2, bf16x8 &a3)
     }
 }
 
-template <int KS /* K / 32 */, bool LN, int NT /* 32-column tiles per block */, int WAVES>
-__global__ __launch_bounds__(WAVES * 64) void linear_fwd_b3_kernel(LinearFwdArgs a) {
+// Epilogues of the b3 kernel.  Its MFMAs take the W fragment as the A operand and the x fragment as B, so the accumulator tile
+// is the TRANSPOSE of the one above: lane (r = l % 16, kq = l / 16) holds row r of the 16-row half and the four CONSECUTIVE
+// columns 16 t + 4 kq + j — a float4 per (lane, tile).  Twelve 16-byte stores per 32-row tile instead of forty-eight 4-byte
+// ones (round 6, s_memtime stamps per wave: the scalar-store epilogue was 2 900 of a tile's 13 400 cycles, issue-bound), the
+// bias / gamma / beta / residual reads are float4 too and a LayerNorm row reduces over 24 values in the lane plus two
+// shuffle steps (lanes r, r + 16, r + 32, r + 48) instead of six values and four steps.
+//   VEC: every row start is 16-byte aligned (pointers and leading dimensions, checked by the launcher); otherwise scalar stores.
+//   nval[t]: how many of the lane's four columns of tile t exist (4 everywhere in a full column block).
+template <bool LN, bool FULL, bool VEC, int NT16>
+SO_DEVFN void so_linear_epilogue_t(f32x4 (&acc)[NT16], const f32x4 (&bv)[NT16], const float *lnp /* LDS: [bias | gamma | beta][96] */,
+                                   const int (&nval)[NT16], float relu_lo, const float *rb, int ldr, float *yb, int ldy, float *pb,
+                                   float *mb, float *sb, int N, float eps, int rem, int r, int kq) {
+    const bool rok = FULL || r < rem;
+    const unsigned c0 = 4u * (unsigned)kq;
+    f32x4 o[NT16];
+#pragma unroll
+    for (int t = 0; t < NT16; ++t) {
+        f32x4 bq;
+        if (LN) bq = *(const f32x4 *)(lnp + 16 * t + c0);       // LayerNorm instances keep bias / gamma / beta in LDS (registers: the
+        else bq = bv[t];                                         // row's 24 values twice over, the accumulators and the next tile's x)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[t][j] = fmaxf(acc[t][j] + bq[j], relu_lo);
+    }
+    if (rb) {
+        const float *rr = rb + (size_t)r * ldr + c0;
+#pragma unroll
+        for (int t = 0; t < NT16; ++t) {
+            if (FULL && VEC) {
+                const float4 v = *(const float4 *)(rr + 16 * t);
+                o[t][0] += v.x; o[t][1] += v.y; o[t][2] += v.z; o[t][3] += v.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[t][j] += (rok && j < nval[t]) ? rr[16 * t + j] : 0.0f;
+            }
+        }
+    }
+    auto put = [&](float *dst, int t, const f32x4 &v) __attribute__((always_inline)) {
+        if (FULL && VEC) *(float4 *)dst = make_float4(v[0], v[1], v[2], v[3]);
+        else if (rok) {
+            if (VEC && nval[t] == 4) *(float4 *)dst = make_float4(v[0], v[1], v[2], v[3]);
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (j < nval[t]) dst[j] = v[j];
+            }
+        }
+    };
+    float *yr = yb + (size_t)r * ldy + c0;
+    if (LN) {
+        if (pb) {
+            float *pr = pb + (size_t)r * N + c0;
+#pragma unroll
+            for (int t = 0; t < NT16; ++t) put(pr + 16 * t, t, o[t]);
+        }
+        const float inv_n = 1.0f / (float)N;
+        float s = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NT16; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += (FULL || j < nval[t]) ? o[t][j] : 0.0f;
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        const float mean = s * inv_n;
+        f32x4 dlt[NT16];
+        float q2 = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NT16; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dlt[t][j] = (FULL || j < nval[t]) ? o[t][j] - mean : 0.0f;
+                q2 += dlt[t][j] * dlt[t][j];
+            }
+        q2 += __shfl_xor(q2, 16, 64);
+        q2 += __shfl_xor(q2, 32, 64);
+        const float rstd = 1.0f / sqrtf(q2 * inv_n + eps);
+#pragma unroll
+        for (int t = 0; t < NT16; ++t) {
+            const f32x4 gq = *(const f32x4 *)(lnp + 96 + 16 * t + c0), tq = *(const f32x4 *)(lnp + 192 + 16 * t + c0);
+            f32x4 v;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaf(dlt[t][j] * rstd, gq[j], tq[j]);
+            put(yr + 16 * t, t, v);
+        }
+        if (mb && kq == 0 && rok) { mb[r] = mean; sb[r] = rstd; }
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT16; ++t) put(yr + 16 * t, t, o[t]);
+    }
+}
+
+// head-major output (selfocc_linear_fwd_heads) from the transposed tile: column tile t IS head t, the lane's float4 is
+// channels 4 kq .. 4 kq + 3 of pixel row r -> y[group][b][t][pix][4 kq ..]
+template <int NT16>
+SO_DEVFN void so_linear_epilogue_t_hm(f32x4 (&acc)[NT16], const f32x4 (&bv)[NT16], float relu_lo, float *yg, long long row0, int rem,
+                                      int nv, int r, int kq) {
+    const long long b0 = row0 / nv;
+    int pix = (int)(row0 - b0 * nv) + r;
+    const unsigned hs = (unsigned)nv * 16u;                       // floats per (b, head)
+    unsigned bo = (unsigned)b0 * 6u * hs;
+    if (pix >= nv) { pix -= nv; bo += 6u * hs; }
+    float *dst = yg + bo + (unsigned)pix * 16u + 4u * (unsigned)kq;
+    if (r < rem) {
+#pragma unroll
+        for (int t = 0; t < NT16; ++t)
+            *(float4 *)(dst + (unsigned)t * hs) = make_float4(fmaxf(acc[t][0] + bv[t][0], relu_lo), fmaxf(acc[t][1] + bv[t][1], relu_lo),
+                                                              fmaxf(acc[t][2] + bv[t][2], relu_lo), fmaxf(acc[t][3] + bv[t][3], relu_lo));
+    }
+}
+
+template <int KS /* K / 32 */, bool LN, int NT /* 32-column tiles per block */, int WAVES, int H = 2 /* 16-row halves per wave tile */>
+__global__ __launch_bounds__(WAVES * 64, 2) void linear_fwd_b3_kernel(LinearFwdArgs a) {
+    constexpr int TR = 16 * H;
     constexpr int K = 32 * KS, KPB = K + 8, NT16 = 2 * NT, THREADS = WAVES * 64, NCOL = 32 * NT;
     extern __shared__ __attribute__((aligned(16))) __bf16 wb[];    // [3][NCOL][KPB]
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -304,7 +441,8 @@ __global__ __launch_bounds__(WAVES * 64) void linear_fwd_b3_kernel(LinearFwdArgs
     const int cb = __builtin_amdgcn_readfirstlane((int)(logical % (unsigned)a.ncb));
     const long long rc = __builtin_amdgcn_readfirstlane((int)(logical / (unsigned)a.ncb));
     const int n0 = a.col0 + cb * 96;
-    const long long nwt = (a.T + 31) / 32, wt_step = (long long)WAVES * a.groups;
+    const long long nwt = (a.T + TR - 1) / TR, wt_step = (long long)WAVES * a.groups;
+    SO_TR(0);
     // ---- stage W: 8 consecutive k of one column per thread and step, split into the three planes ----
     {
         constexpr int NV = NCOL * (K / 8);
@@ -326,26 +464,42 @@ __global__ __launch_bounds__(WAVES * 64) void linear_fwd_b3_kernel(LinearFwdArgs
 
     const bool full_cols = a.N - n0 >= 32 * NT;
     const float relu_lo = a.relu ? 0.0f : -__builtin_huge_valf();
-    float bv[NT16], gv[NT16], bt[NT16];
-    bool cok[NT16];
+    f32x4 bv[NT16];                         // the lane's four consecutive columns 16 t + 4 kb + j of every tile
+    int nval[NT16];
+    __shared__ __attribute__((aligned(16))) float lnp[LN ? 3 * 96 : 4];
+    if (LN) {
+        for (int c = threadIdx.x; c < 96; c += THREADS) {
+            const bool ok = n0 + c < a.N;
+            lnp[c] = (a.bias && ok) ? a.bias[n0 + c] : 0.0f;
+            lnp[96 + c] = ok ? a.gamma[n0 + c] : 0.0f;
+            lnp[192 + c] = ok ? a.beta[n0 + c] : 0.0f;
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int t = 0; t < NT16; ++t) {
-        const int col = n0 + 16 * t + n;
-        cok[t] = col < a.N;
-        bv[t] = (a.bias && cok[t]) ? a.bias[col] : 0.0f;
-        gv[t] = (LN && cok[t]) ? a.gamma[col] : 0.0f;
-        bt[t] = (LN && cok[t]) ? a.beta[col] : 0.0f;
-    }
-
-    for (long long wt = rc * WAVES + wave; wt < nwt; wt += wt_step) {
-        const long long row0 = wt * 32;
-        const int rem = (int)min(32LL, a.T - row0);
-        // raw x of both 16-row halves, all k steps in flight at once
-        float xr[2][KS][8];
+        const int col = n0 + 16 * t + 4 * kb;
+        nval[t] = max(0, min(4, a.N - col));
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int rl = min(16 * h + n, rem - 1);
-            const float *xb = a.x + (row0 + rl) * K + 8 * kb;
+        for (int j = 0; j < 4; ++j) bv[t][j] = (!LN && a.bias && j < nval[t]) ? a.bias[col + j] : 0.0f;
+    }
+    const bool vec = a.vec != 0;
+
+    SO_TR(1);
+#ifdef SO_LIN_TRACE
+    int tr_i = 0;
+#endif
+    // raw x of both 16-row halves of a tile, all k steps in flight at once.  The registers are free again as soon as the tile
+    // is split into its bf16 planes, so the NEXT tile's x is requested right there — before the matrix phase — into the same
+    // registers: its latency runs under this tile's MFMAs and stores at no register cost.
+    float xr[H][KS][8];
+    auto load_tile = [&](long long wt_) __attribute__((always_inline)) {
+        const long long row0_ = wt_ * TR;
+        const int rem_ = (int)min((long long)TR, a.T - row0_);
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            const int rl = min(16 * h + n, rem_ - 1);
+            const float *xb = a.x + (row0_ + rl) * K + 8 * kb;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
                 const float4 lo = *(const float4 *)(xb + 32 * ks), hi = *(const float4 *)(xb + 32 * ks + 4);
@@ -353,40 +507,72 @@ __global__ __launch_bounds__(WAVES * 64) void linear_fwd_b3_kernel(LinearFwdArgs
                 xr[h][ks][4] = hi.x; xr[h][ks][5] = hi.y; xr[h][ks][6] = hi.z; xr[h][ks][7] = hi.w;
             }
         }
-        f32x4 acc[2][NT16];
+    };
+    if (rc * WAVES + wave < nwt) load_tile(rc * WAVES + wave);
+    for (long long wt = rc * WAVES + wave; wt < nwt; wt += wt_step) {
+        const long long row0 = wt * TR;
+        const int rem = (int)min((long long)TR, a.T - row0);
+#ifdef SO_LIN_TRACE
+        SO_TR(2 + 5 * tr_i);
+#endif
+#ifdef SO_LIN_TRACE
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SO_TR(3 + 5 * tr_i);
+#endif
+        f32x4 acc[H][NT16];
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < H; ++h)
 #pragma unroll
             for (int t = 0; t < NT16; ++t)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) acc[h][t][j] = 0.0f;
+        // a pure matrix phase: every split of the tile first (VALU, beside the SIMD's other wave's MFMAs), then 36 K / 32 MFMAs per
+        // 16-column tile with the W fragments of group g + 1 read from LDS BEFORE the MFMAs of group g — round 6, s_memtime
+        // stamps: with the three ds_read_b128 of a group issued right in front of its MFMAs and the next k-step's ~100 split
+        // instructions between the groups, the phase took >= 5 600 cycles for 216 MFMAs x 16 cycles
         const __bf16 *bbase = wb + (size_t)n * KPB + 8 * kb;
+        bf16x8 a1[KS][H], a2[KS][H], a3[KS][H];
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-            bf16x8 a1[2], a2[2], a3[2];
-            so_split3(xr[0][ks], a1[0], a2[0], a3[0]);
-            so_split3(xr[1][ks], a1[1], a2[1], a3[1]);
 #pragma unroll
-            for (int t = 0; t < NT16; ++t) {
-                const __bf16 *bp = bbase + (size_t)(16 * t) * KPB + 32 * ks;
-                const bf16x8 b1 = *(const bf16x8 *)bp, b2 = *(const bf16x8 *)(bp + (size_t)NCOL * KPB),
-                             b3 = *(const bf16x8 *)(bp + (size_t)2 * NCOL * KPB);
+            for (int h = 0; h < H; ++h) so_split3(xr[h][ks], a1[ks][h], a2[ks][h], a3[ks][h]);
+        }
+        if (wt + wt_step < nwt) load_tile(wt + wt_step);
+        bf16x8 wq[2][3];
+        auto wfrag = [&](int g, bf16x8 (&dst)[3]) __attribute__((always_inline)) {
+            const int ks = g / NT16, t = g - ks * NT16;
+            const __bf16 *bp = bbase + (size_t)(16 * t) * KPB + 32 * ks;
+            dst[0] = *(const bf16x8 *)bp; dst[1] = *(const bf16x8 *)(bp + (size_t)NCOL * KPB);
+            dst[2] = *(const bf16x8 *)(bp + (size_t)2 * NCOL * KPB);
+        };
+        wfrag(0, wq[0]);
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {      // small terms first
-                    acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a3[h], b1, acc[h][t], 0, 0, 0);
-                    acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[h], b3, acc[h][t], 0, 0, 0);
-                    acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[h], b2, acc[h][t], 0, 0, 0);
-                }
+        for (int g = 0; g < KS * NT16; ++g) {
+            const int ks = g / NT16, t = g - ks * NT16;
+            if (g + 1 < KS * NT16) wfrag(g + 1, wq[(g + 1) & 1]);
+            const bf16x8 b1 = wq[g & 1][0], b2 = wq[g & 1][1], b3 = wq[g & 1][2];
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a2[h], b1, acc[h][t], 0, 0, 0);
-                    acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[h], b2, acc[h][t], 0, 0, 0);
-                    acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1[h], b1, acc[h][t], 0, 0, 0);
-                }
+            for (int h = 0; h < H; ++h) {      // small terms first
+                acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, a3[ks][h], acc[h][t], 0, 0, 0);
+                acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b3, a1[ks][h], acc[h][t], 0, 0, 0);
+                acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2, a2[ks][h], acc[h][t], 0, 0, 0);
+            }
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, a2[ks][h], acc[h][t], 0, 0, 0);
+                acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2, a1[ks][h], acc[h][t], 0, 0, 0);
+                acc[h][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1, a1[ks][h], acc[h][t], 0, 0, 0);
             }
         }
+#ifdef SO_LIN_TRACE
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < H; ++h)
+#pragma unroll
+            for (int t = 0; t < NT16; ++t) asm volatile("" : "+v"(acc[h][t]));
+        SO_TR(4 + 5 * tr_i);
+#endif
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
             const long long r0 = row0 + 16 * h;
             const int rm = rem - 16 * h;
             if (rm <= 0) break;
@@ -399,15 +585,25 @@ __global__ __launch_bounds__(WAVES * 64) void linear_fwd_b3_kernel(LinearFwdArgs
             asm volatile("" : "+v"(no));
             if (!LN && NT == 3 && a.hm_nv > 0) {
                 if constexpr (!LN && NT == 3)
-                    so_linear_epilogue16_hm<NT16>(acc[h], bv, relu_lo, a.y + (size_t)cb * a.hm_sg, r0, rmc, a.hm_nv, no, kb);
-            } else if (rmc == 16 && full_cols)
-                so_linear_epilogue16<LN, true, NT16>(acc[h], bv, gv, bt, cok, relu_lo, rb, a.ldr, yb, a.ldy, pb, mb, sb, a.N, a.eps,
-                                                     rmc, no, kb);
+                    so_linear_epilogue_t_hm<NT16>(acc[h], bv, relu_lo, a.y + (size_t)cb * a.hm_sg, r0, rmc, a.hm_nv, no, kb);
+            } else if (rmc == 16 && full_cols && vec)
+                so_linear_epilogue_t<LN, true, true, NT16>(acc[h], bv, lnp, nval, relu_lo, rb, a.ldr, yb, a.ldy, pb, mb, sb, a.N,
+                                                           a.eps, rmc, no, kb);
+            else if (vec)
+                so_linear_epilogue_t<LN, false, true, NT16>(acc[h], bv, lnp, nval, relu_lo, rb, a.ldr, yb, a.ldy, pb, mb, sb, a.N,
+                                                            a.eps, rmc, no, kb);
             else
-                so_linear_epilogue16<LN, false, NT16>(acc[h], bv, gv, bt, cok, relu_lo, rb, a.ldr, yb, a.ldy, pb, mb, sb, a.N, a.eps,
-                                                      rmc, no, kb);
+                so_linear_epilogue_t<LN, false, false, NT16>(acc[h], bv, lnp, nval, relu_lo, rb, a.ldr, yb, a.ldy, pb, mb, sb, a.N,
+                                                             a.eps, rmc, no, kb);
         }
+#ifdef SO_LIN_TRACE
+        SO_TR(5 + 5 * tr_i);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SO_TR(6 + 5 * tr_i);
+        ++tr_i;
+#endif
     }
+    SO_TR(63);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -631,6 +827,7 @@ static int so_linear_fwd_launch(const float *x, const float *w, const float *bia
     a.relu = (flags & SO_LINEAR_RELU) ? 1 : 0;
     a.eps = ln_eps;
     a.hm_nv = hm_nv;
+    a.vec = (((uintptr_t)y | (uintptr_t)residual | (uintptr_t)y_pre) & 15) == 0 && ldy % 4 == 0 && (!residual || ldr % 4 == 0) && N % 4 == 0;
     a.hm_sg = hm_nv > 0 ? (unsigned)(T * 96) : 0u;
     hipStream_t st = (hipStream_t)stream;
     // main launch: the full 96-column blocks (three accumulator tiles per wave); tail launch: the last 1 - 64 columns with
@@ -652,12 +849,17 @@ static int so_linear_fwd_launch(const float *x, const float *w, const float *bia
         if (use_b3) {
             const size_t lds_b3 = (size_t)3 * nt * 32 * (K + 8) * 2;
             long long per_cu3 = std::max<long long>(1, std::min<long long>(2, (160 * 1024) / (long long)(lds_b3 + 512)));
-            const long long nwt3 = (T + 31) / 32;
+            // wave tile: 32 rows x 96 columns where the column blocks share the x rows (N >= 288: the two 16-row halves use
+            // every W fragment read from LDS twice); 16 rows where one or two column blocks make short launches (N <= 192: the
+            // launch is a ramp, a W staging and 1 - 2 tiles per wave — half-size tiles spread it better; round 6, same box:
+            // 78 899 x 96 24.5 -> 19.5 us, 66 049 x 96 19.3 -> 16.7 us, 78 899 x 192 30.0 -> 28.1 us, the wide shapes unchanged)
+            const bool half_tiles = N <= 192;
+            const long long nwt3 = half_tiles ? (T + 15) / 16 : (T + 31) / 32;
             long long groups3 = std::max(1LL, 256 * per_cu3 / a.ncb);
             groups3 = std::min(groups3, (nwt3 + 3) / 4);
             a.groups = (int)groups3;
             const long long nblk3 = groups3 * a.ncb;
-#define SO_B3_1(KS_, LN_, NT_)                                                                                        \
+#define SO_B3_0(KS_, LN_, NT_, H_)                                                                                    \
     do {                                                                                                             \
         /* the attribute is per device: set once per (device, instantiation) — the call is a driver round trip of tens of */ \
         /* microseconds, which at ~45 launches per frame would make the host the bottleneck                                */ \
@@ -666,11 +868,16 @@ static int so_linear_fwd_launch(const float *x, const float *w, const float *bia
         (void)hipGetDevice(&dev_);                                                                                   \
         const unsigned long long bit_ = 1ull << (dev_ & 63);                                                         \
         if (lds_b3 > 48 * 1024 && !(done_mask.load(std::memory_order_relaxed) & bit_)) {                             \
-            (void)hipFuncSetAttribute((const void *)linear_fwd_b3_kernel<KS_, LN_, NT_, 4>,                          \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);                 \
+            (void)hipFuncSetAttribute((const void *)linear_fwd_b3_kernel<KS_, LN_, NT_, 4, H_>,                      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);                \
             done_mask.fetch_or(bit_, std::memory_order_relaxed);                                                     \
         }                                                                                                            \
-        hipLaunchKernelGGL((linear_fwd_b3_kernel<KS_, LN_, NT_, 4>), dim3((unsigned)nblk3), dim3(256), lds_b3, st, a); \
+        hipLaunchKernelGGL((linear_fwd_b3_kernel<KS_, LN_, NT_, 4, H_>), dim3((unsigned)nblk3), dim3(256), lds_b3, st, a); \
+    } while (0)
+#define SO_B3_1(KS_, LN_, NT_)                                                                                        \
+    do {                                                                                                             \
+        if (half_tiles) SO_B3_0(KS_, LN_, NT_, 1);                                                                   \
+        else SO_B3_0(KS_, LN_, NT_, 2);                                                                              \
     } while (0)
 #define SO_B3_2(KS_, LN_)                                                                                             \
     do {                                                                                                             \
@@ -692,6 +899,7 @@ static int so_linear_fwd_launch(const float *x, const float *w, const float *bia
 #undef SO_B3_3
 #undef SO_B3_2
 #undef SO_B3_1
+#undef SO_B3_0
             continue;
         }
         const size_t lds_blk = (size_t)nt * 32 * (K + 4) * sizeof(float);

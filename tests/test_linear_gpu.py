@@ -58,7 +58,8 @@ def test_tall_linear_backward_uses_fused_wgrad(hip):
 
 # ---- selfocc_linear_fwd (csrc/linear_fwd.hip): y = LN?(relu?(x W^T + b) + residual) -------------------------------
 FWD_SHAPES = [(66049, 384, 96), (78899, 432, 96), (7967, 2304, 96), (78899, 96, 192), (78899, 216, 96), (8200, 25, 96),
-              (9000, 96, 32), (8192, 70, 64), (8193, 33, 128), (70, 96, 96), (1, 5, 96), (129, 288, 96), (4099, 192, 96)]
+              (9000, 96, 32), (8192, 70, 64), (8193, 33, 128), (70, 96, 96), (1, 5, 96), (129, 288, 96), (4099, 192, 96),
+              (78899, 648, 96), (4099, 648, 96), (4101, 84, 96), (4101, 172, 64)]
 
 
 @pytest.mark.parametrize("T,N,K", FWD_SHAPES)
@@ -87,6 +88,14 @@ def test_linear_fwd_matches_f64(hip, T, N, K):
     assert r.data_ptr() == out.data_ptr()
     assert (out.double() - (want.clamp_min(0) + res.double())).abs().max().item() < 2 * tol
     assert torch.all(buf[:, :N] == 7.0) and torch.all(buf[:, 2 * N:] == 7.0)      # nothing written outside the block
+    if N % 4 == 0:            # the same with 16-byte aligned row starts (the float4 epilogue of the b3 kernel)
+        wide = torch.randn(T, N + 40, generator=g).cuda()
+        res = wide[:, 8:8 + N]
+        buf = torch.full((T, 2 * N + 8), 7.0).cuda()
+        out = buf[:, N:2 * N]
+        linear_fwd(x, w, b, relu=True, residual=res, out=out)
+        assert (out.double() - (want.clamp_min(0) + res.double())).abs().max().item() < 2 * tol
+        assert torch.all(buf[:, :N] == 7.0) and torch.all(buf[:, 2 * N:] == 7.0)
 
 
 @pytest.mark.parametrize("T,N,K", [(78899, 96, 96), (78899, 96, 192), (7967, 96, 96), (130, 96, 96), (4100, 64, 96),
