@@ -510,7 +510,7 @@ int selfocc_linear_fwd(const float *x, const float *w, const float *bias, const 
  * projection itself:  x (T, K) = T / nv batch items (cameras) of nv pixels;  N = G * 96 output columns = G groups (one
  * attention module each: e.g. the three TPV planes' value_proj stacked) of 6 heads x 16 channels;
  *     y (G, T / nv, 6, nv, 16):   y[g][b][h][pix][c] = relu?(x[b * nv + pix] . w[96 g + 16 h + c] + bias[...])
- * nv >= 16, T a multiple of nv, T * N < 2^31.  flags: SO_LINEAR_RELU. */
+ * nv >= 16, T a multiple of nv, T * N < 2^31, y 16-byte aligned (written as float4).  flags: SO_LINEAR_RELU. */
 int selfocc_linear_fwd_heads(const float *x, const float *w, const float *bias, float *y, int64_t T, int32_t N, int32_t K,
                              int32_t nv, uint32_t flags, void *stream);
 

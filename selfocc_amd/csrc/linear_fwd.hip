@@ -962,6 +962,7 @@ extern "C" int selfocc_linear_fwd_heads(const float *x, const float *w, const fl
     SO_REQUIRE(nv >= 16 && T % nv == 0, "linear_fwd_heads: T = %lld rows must be a whole number of batch items of nv = %d >= 16 rows",
                (long long)T, nv);
     SO_REQUIRE((long long)T * N < (1LL << 31), "linear_fwd_heads: output too large for 32-bit offsets");
+    SO_REQUIRE(((uintptr_t)y & 15) == 0, "linear_fwd_heads: y must be 16-byte aligned (the head-major rows are written as float4)");
     return so_linear_fwd_launch(x, w, bias, nullptr, 0, nullptr, nullptr, 0.0f, y, N, nullptr, nullptr, nullptr, T, N, K, flags, nv,
                                 stream);
 }
