@@ -843,8 +843,36 @@ static int so_linear_fwd_launch(const float *x, const float *w, const float *bia
         // SELFOCC_LINEAR_B3=0 keeps the f32-MFMA kernel (A/B)
         static const bool b3_env = !(getenv("SELFOCC_LINEAR_B3") && atoi(getenv("SELFOCC_LINEAR_B3")) == 0);
         // where it pays (measured inside the eval encoder, profiles/r3_h_*): enough 32-row tiles per block to amortise the
-        // three-plane split of W at block start (the 6 - 8 k-row zh / wz planes at N = 96 ran 17 vs 9 us), and K <= 128 (at
-        // K = 192 the planes take 115 KB: one block per CU, one wave per SIMD)
+        // three-plane split of W at block start (the 6 - 8 k-row zh / wz planes at N = 96 ran 17 vs 9 us); K = 192 has its own
+        // launch above (round 6: 78 899 x 192 -> 96 with residual + LayerNorm 50.2 -> 37.3 us, plain 39.4 -> 31.0 us against
+        // the f32-MFMA kernel, same box)
+        // K = 192 (the FFN's second Linear + residual + LayerNorm): the planes take 115 KB, so ONE block of eight waves per CU shares
+        // them (two waves per SIMD, like two four-wave blocks at K <= 128), 16-row tiles
+        if (b3_env && K == 192 && T >= 16384) {
+            const size_t lds_b3 = (size_t)3 * nt * 32 * (K + 8) * 2;
+            const long long nwt3 = (T + 15) / 16;
+            long long groups3 = std::max(1LL, 256LL / a.ncb);
+            groups3 = std::min(groups3, (nwt3 + 7) / 8);
+            a.groups = (int)groups3;
+            const long long nblk3 = groups3 * a.ncb;
+#define SO_B3_K192(LN_, NT_)                                                                                          \
+    do {                                                                                                             \
+        static std::atomic<unsigned long long> done_mask{0};                                                         \
+        int dev_ = 0;                                                                                                \
+        (void)hipGetDevice(&dev_);                                                                                   \
+        const unsigned long long bit_ = 1ull << (dev_ & 63);                                                         \
+        if (!(done_mask.load(std::memory_order_relaxed) & bit_)) {                                                   \
+            (void)hipFuncSetAttribute((const void *)linear_fwd_b3_kernel<6, LN_, NT_, 8, 1>,                         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048);                \
+            done_mask.fetch_or(bit_, std::memory_order_relaxed);                                                     \
+        }                                                                                                            \
+        hipLaunchKernelGGL((linear_fwd_b3_kernel<6, LN_, NT_, 8, 1>), dim3((unsigned)nblk3), dim3(512), lds_b3, st, a); \
+    } while (0)
+            if (ln) { if (nt == 3) SO_B3_K192(true, 3); else if (nt == 2) SO_B3_K192(true, 2); else SO_B3_K192(true, 1); }
+            else { if (nt == 3) SO_B3_K192(false, 3); else if (nt == 2) SO_B3_K192(false, 2); else SO_B3_K192(false, 1); }
+#undef SO_B3_K192
+            continue;
+        }
         const bool use_b3 = b3_env && K <= 128 && (T >= 16384 || N >= 384);
         if (use_b3) {
             const size_t lds_b3 = (size_t)3 * nt * 32 * (K + 8) * 2;
@@ -894,7 +922,7 @@ static int so_linear_fwd_launch(const float *x, const float *w, const float *bia
                 case 32: SO_B3_3(1); break;
                 case 64: SO_B3_3(2); break;
                 case 96: SO_B3_3(3); break;
-                default: SO_B3_3(4); break;      // K = 128 (use_b3 excludes 192: its three planes would take 115 KB)
+                default: SO_B3_3(4); break;      // K = 128
             }
 #undef SO_B3_3
 #undef SO_B3_2
