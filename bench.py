@@ -394,7 +394,7 @@ def main():
         if "error" in hot_path_detail:
             hot_path = hot_path_detail
         else:
-            hot_path = {"unit": "ms, one training iteration (fwd + losses + bwd) / one frame of the config's eval entry, no backbone",
+            hot_path = {"unit": "ms (median), one training iteration (fwd + losses + bwd) / one frame of the config's eval entry, no backbone",
                         "train": {k: v["train"]["total_ms"] for k, v in hot_path_detail.items() if isinstance(v, dict) and "train" in v},
                         "eval": {k: v["eval"]["total_ms"] for k, v in hot_path_detail.items() if isinstance(v, dict) and "eval" in v},
                         "eval_entry": {k: v["eval"]["entry"] for k, v in hot_path_detail.items() if isinstance(v, dict) and "eval" in v}}

@@ -3,8 +3,12 @@ the registries at its shipped shapes, timed in ONE process: a training iteration
 forward, backward; clip_grad_norm_ + AdamW beside it) and the evaluation entry the docs pair with the config with the reference's
 eval-time overrides (scripts/hotpath_common.py: SHIPPED).  Synthetic stand-ins for what is out of scope (camera rig, FPN maps,
 images).  Prints one JSON line: {config: {train: {...stage ms, total}, eval: {...stage ms, total}}}.
+Stage times are the MEDIAN over the timed iterations, with Python's cyclic GC collected before and held off during them: a 3 ms
+eval frame whose enqueue takes 1.5 ms of host time shows a single 30 ms collection (the training modules of the same config
+were just deleted) as + 6 ms on the mean of five frames — seen twice in round 6, `host_enqueue_ms` 6 - 8 instead of 1.5 - 2.3.
     python scripts/bench_hotpath_all.py [--only NAME[,NAME]] [--iters 5]"""
 import argparse
+import gc
 import json
 import os
 import sys
@@ -29,9 +33,10 @@ res = {}
 
 
 def mean_stages(evs, keys):
+    """median over the timed iterations of every stage (see the module docstring)"""
     out = {}
     for k, (a, b) in keys.items():
-        out[k] = round(sum(e[a].elapsed_time(e[b]) for e in evs) / len(evs), 3)
+        out[k] = round(float(np.median([e[a].elapsed_time(e[b]) for e in evs])), 3)
     return out
 
 
@@ -51,6 +56,7 @@ for name in names:
         fr = hc.frame_inputs(cfg, name, d, seed=0)
         evs = []
         host = []
+        gc.collect(); gc.disable()
         for it in range(args.warm + args.iters):
             optimizer.zero_grad(set_to_none=True)
             e = {}
@@ -64,10 +70,11 @@ for name in names:
             if it >= args.warm:
                 evs.append(e)
                 host.append((h1 - h0) * 1e3)
+        gc.enable()
         t = mean_stages(evs, dict(encoder_fwd=('t0', 't1'), head_fwd=('t1', 't2'), losses_fwd=('t2', 't3'), backward=('t3', 't4'),
                                   clip_and_adamw=('t4', 't5')))
         t['total_ms'] = round(sum(v for k, v in t.items() if k != 'clip_and_adamw'), 2)
-        t['host_enqueue_ms'] = round(sum(host) / len(host), 2)      # the python / launch side of the same iteration (no device wait)
+        t['host_enqueue_ms'] = round(float(np.median(host)), 2)     # the python / launch side of the same iteration (no device wait)
         t['rays'] = cfg['num_rays'][0] * cfg['num_rays'][1] * cfg['model']['encoder']['num_cams']
         t['losses'] = [c['type'] for c in cfg['loss']['loss_cfgs']]
         r['train'] = t
@@ -81,6 +88,7 @@ for name in names:
             m.eval()
         fr = hc.frame_inputs(cfg, name, d, seed=1, want_images=False)
         evs, state, host = [], {}, []
+        gc.collect(); gc.disable()
         with torch.no_grad():
             for it in range(args.warm + args.iters):
                 e = {}
@@ -91,13 +99,14 @@ for name in names:
                 if it >= args.warm:
                     evs.append(e)
                     host.append((h1 - h0) * 1e3)
+        gc.enable()
         kind = hc.SHIPPED[name]['eval']
         second = {'render': 'prepare_volume', 'render_novel': 'prepare_volume', 'occ3d': 'volume_and_dense_query',
                   'occ_kitti': 'volume_and_dense_query'}[kind]
         third = {'render': 'render', 'render_novel': 'render', 'occ3d': 'resample_lut_iou_counts', 'occ_kitti': 'threshold_crop_iou_counts'}[kind]
         t = mean_stages(evs, {'encoder_fwd': ('t0', 't1'), second: ('t1', 't2'), third: ('t2', 't3')})
         t['total_ms'] = round(sum(t.values()), 2)
-        t['host_enqueue_ms'] = round(sum(host) / len(host), 2)
+        t['host_enqueue_ms'] = round(float(np.median(host)), 2)
         t['entry'] = kind
         if kind.startswith('render'):
             t['rays'] = int(out['ms_depths'][0].numel())
@@ -110,5 +119,6 @@ for name in names:
         torch.cuda.empty_cache()
     r['built_from'] = hc.shipped(name)['source']
     res[name] = r
+res['stat'] = f'median of {args.iters} iterations after {args.warm} warm-up, GC held off'
 res['max_mem_GB'] = round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)
 print(json.dumps(res))
