@@ -526,6 +526,10 @@ class NeuSHead(BaseModule):
         cfg = self._render_cfg(False)
         cfg.inv_s_dev = self.model.field.inv_s_device()
         vol = SDFVolume(vol.mapping, vol.sdf.detach(), None if vol.feat is None else vol.feat.detach(), vol.n_rgb, vol.n_sem)
+        if vol.n_rgb == 0 and cfg.bkgd_mode == abi.BKGD_PER_RAY:
+            # no colour is rendered (the depth configs): the random background would be drawn (2.16 M x 3 numbers per frame) and never
+            # read — nerfstudio's RGBRenderer, which draws it in the reference, is not called for a depth-only head either
+            cfg.bkgd_mode = abi.BKGD_NONE            # `cfg` is this call's own object (_render_cfg builds a new one)
         if self._sharding(rays):
             # every rank marches its row block of every camera; the per-ray maps are all-gathered back into the
             # full frame so that the reference's callers (eval_depth.py:166-190) see the usual dict
