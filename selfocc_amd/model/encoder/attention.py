@@ -10,6 +10,8 @@ The sampling itself is the HIP kernel behind MultiScaleDeformableAttnFunction (m
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -223,6 +225,21 @@ class BEVCrossAttention(BaseModule):
         return post_norm(slots) if post_norm is not None else slots
 
 
+# dev A/B (round 6): SELFOCC_PLANE_STREAMS=1 runs the three planes' inference branches on three streams.  Measured and left OFF:
+# the eval encoder gets SLOWER (5.45 -> 5.69 ms at nuscenes_occ, 5.95 -> 6.19 at nuscenes_depth, same box, twice; results unchanged,
+# scripts/diag/plane_streams_ab.sh) — the gather kernels already keep the texture path 70 - 77 % busy on their own and lose more
+# to each other than the short launches gain by hiding under them.
+PLANE_STREAMS = os.environ.get('SELFOCC_PLANE_STREAMS', '0') == '1'
+_PLANE_STREAMS = {}
+
+
+def _plane_streams(device):
+    key = str(device)
+    if key not in _PLANE_STREAMS:
+        _PLANE_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(3)]
+    return _PLANE_STREAMS[key]
+
+
 @MODELS.register_module()
 class TPVCrossAttention(BaseModule):
     """One BEVCrossAttention per TPV plane (hw, zh, wz) with num_points = [wz, zh, hw] pillar
@@ -270,11 +287,30 @@ class TPVCrossAttention(BaseModule):
                     if bricks.VALUE_BF16 and C // heads0 == 16:
                         v_hm = v_hm.to(torch.bfloat16)
                     vpre = list(v_hm)
-                    return [self.attns[i](query[i], key, value, residual[i] if residual is not None else None,
-                                          spatial_shapes=spatial_shapes, level_start_index=level_start_index,
-                                          reference_points_cams=reference_points_cams[i], bev_masks=tpv_masks[i],
-                                          rebatch_plan=plans[i], out=outs[i], value_pre=vpre[i],
-                                          post_norm=kwargs.get('post_norm')) for i in range(3)]
+
+                    def plane(i):
+                        return self.attns[i](query[i], key, value, residual[i] if residual is not None else None,
+                                             spatial_shapes=spatial_shapes, level_start_index=level_start_index,
+                                             reference_points_cams=reference_points_cams[i], bev_masks=tpv_masks[i],
+                                             rebatch_plan=plans[i], out=outs[i], value_pre=vpre[i],
+                                             post_norm=kwargs.get('post_norm'))
+                    if not PLANE_STREAMS:
+                        return [plane(i) for i in range(3)]
+                    # the three planes are independent until the layer's next step: each runs on its own stream (its
+                    # temporaries live and die in that stream's pool; inputs and the `outs` slices belong to the caller's
+                    # stream, which waits for all three before it goes on)
+                    main = torch.cuda.current_stream()
+                    side = _plane_streams(value.device)
+                    start = torch.cuda.Event()
+                    start.record(main)
+                    res = []
+                    for i in range(3):
+                        side[i].wait_event(start)
+                        with torch.cuda.stream(side[i]):
+                            res.append(plane(i))
+                    for st in side:
+                        main.wait_stream(st)
+                    return res
                 if bricks.FUSED_LINEAR_FWD and bricks._linear_fwd_ok(vin, w):
                     v_all = bricks.linear_fwd(vin, w, b).view(cams, l, 3 * C)
                 else:
